@@ -1,0 +1,515 @@
+/*
+ * trc_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE ONLY).  See trc_oracle.h for the rules.
+ *
+ * Own scalar restatement of the arithmetic described in SURVEY.md section 8a; nothing here is
+ * copied from the reference, each function cites the reference lines whose behaviour it follows.
+ * Parity pinned against oracle/_ref (the reference compiled in place) and tests/golden/.
+ */
+#include "trc_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+
+#define PROB_BITS 15u
+#define PROB_ONE  (1u << PROB_BITS)
+#define TOP32     ((uint64_t)1 << 32)
+
+static inline uint32_t ld32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+static inline uint16_t ld16(const uint8_t *p) { uint16_t v; memcpy(&v, p, 2); return v; }
+static inline void st32(uint8_t *p, uint32_t v) { memcpy(p, &v, 4); }
+static inline void st16(uint8_t *p, uint16_t v) { memcpy(p, &v, 2); }
+
+/* "incompressible" limit shared by the range coders: OVERFLOW, rcutil_.h:129-131.
+ * The reference compares pointers (op >= out + inlen*255/256 - 8); for tiny inlen the size_t
+ * expression wraps, which on a flat address space is the signed comparison below. */
+static inline int rc_overflow(size_t written, size_t inlen)
+{
+    int64_t lim = (int64_t)((inlen * 255) / 256) - 8;
+    return (int64_t)written >= lim;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* M0  cdfini  (rccdf.c:50-68)                                                                 */
+int orc_cdfini(const uint8_t *in, size_t inlen, uint16_t *cdf, unsigned cdfnum)
+{
+    uint64_t cnt[256] = {0}, best = 0, sum = 0;
+    unsigned besti = 0, i;
+    if (!inlen || !cdfnum || cdfnum > 256) return -1;
+    for (size_t k = 0; k < inlen; k++) cnt[in[k]]++;
+    for (i = 0; i < cdfnum; i++) {
+        uint64_t f = (cnt[i] << PROB_BITS) / inlen;
+        if (!f) f = 1;
+        cnt[i] = f;
+        sum += f;
+        if (f > best) { best = f; besti = i; }           /* strict '>' : lowest index wins */
+    }
+    cnt[besti] -= sum - PROB_ONE;                        /* modular, like the size_t original */
+    cdf[0] = 0;
+    for (i = 0; i < cdfnum; i++) cdf[i + 1] = (uint16_t)(cdf[i] + cnt[i]);
+    for (i = 0; i < cdfnum; i++) if (cdf[i] >= cdf[i + 1]) return -1;
+    if (cdf[cdfnum] != PROB_ONE) return -1;
+    return (int)inlen;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* M2  64-bit range coder core, 32-bit I/O, 15-bit probabilities (turborc_.h:103-158,215-229)  */
+typedef struct { uint64_t range, low, mark; uint8_t *op; } rce_t;   /* mark = low at last renorm */
+typedef struct { uint64_t range, code; const uint8_t *ip; } rcd_t;
+
+static inline void rce_start(rce_t *e, uint8_t *op) { e->range = ~(uint64_t)0; e->low = e->mark = 0; e->op = op; }
+
+/* deferred carry: if low wrapped since the last renorm, +1 ripples into the emitted words */
+static inline void rce_carry(rce_t *e)
+{
+    if (e->mark > e->low) {
+        uint8_t *p = e->op;
+        uint32_t w;
+        do { p -= 4; w = ld32(p) + 1; st32(p, w); } while (w == 0);
+    }
+}
+static inline void rce_put(rce_t *e, uint32_t w) { st32(e->op, w); e->op += 4; }
+
+static inline void rce_renorm(rce_t *e)                  /* single 'if': RC_IO=32 (_LOOP = if) */
+{
+    if (e->range < TOP32) {
+        rce_carry(e);
+        rce_put(e, (uint32_t)(e->low >> 32));
+        e->low <<= 32; e->range <<= 32; e->mark = e->low;
+    }
+}
+static inline void rce_sym(rce_t *e, uint32_t c0, uint32_t c1)      /* _rccdfenc_ + renorm */
+{
+    e->range >>= PROB_BITS;
+    e->low += e->range * c0;
+    e->range *= (c1 - c0);
+    rce_renorm(e);
+}
+static inline void rce_finish(rce_t *e)                  /* rceflush, turborc_.h:118-128 */
+{
+    rce_renorm(e);
+    if (e->range > ((uint64_t)1 << 33)) {
+        e->low += TOP32; rce_carry(e);
+        rce_put(e, (uint32_t)(e->low >> 32));
+    } else {
+        e->low += 1; rce_carry(e);
+        rce_put(e, (uint32_t)(e->low >> 32));
+        rce_put(e, (uint32_t)e->low);
+    }
+}
+static inline void rcd_start(rcd_t *d, const uint8_t *ip)
+{
+    d->range = ~(uint64_t)0;
+    d->code = ((uint64_t)ld32(ip) << 32) | ld32(ip + 4);
+    d->ip = ip + 8;
+}
+static inline void rcd_renorm(rcd_t *d)
+{
+    if (d->range < TOP32) { d->range <<= 32; d->code = (d->code << 32) | ld32(d->ip); d->ip += 4; }
+}
+static inline void rcd_consume(rcd_t *d, uint32_t c0, uint32_t c1)  /* _rccdfupdate (+renorm) */
+{
+    uint64_t rp = d->range * c0;
+    d->range = d->range * c1 - rp;
+    d->code -= rp;
+    rcd_renorm(d);
+}
+/* symbol search, identical result for the l/b/vl/vb reference decoders (turborc_.h:245,307-315) */
+static inline unsigned rcd_find(const rcd_t *d, const uint16_t *cdf, unsigned cdfnum)
+{
+    unsigned x = 0, hi = cdfnum;
+    while (x + 1 < hi) {
+        unsigned mid = (x + hi) >> 1;
+        if ((uint64_t)cdf[mid] * d->range > d->code) hi = mid; else x = mid;
+    }
+    return x;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* M3  rccdfsenc / rccdfs{l,b,vl,vb}dec  (rccdf.c:71-122)                                       */
+size_t orc_rccdfsenc(const uint8_t *in, size_t inlen, uint8_t *out, const uint16_t *cdf, unsigned cdfnum)
+{
+    rce_t e; (void)cdfnum;
+    rce_start(&e, out);
+    for (size_t i = 0; i < inlen; i++) {
+        unsigned x = in[i];
+        rce_sym(&e, cdf[x], cdf[x + 1]);
+        if (rc_overflow((size_t)(e.op - out), inlen)) { memcpy(out, in, inlen); return inlen; }
+    }
+    rce_finish(&e);
+    return (size_t)(e.op - out);
+}
+size_t orc_rccdfsdec(const uint8_t *in, size_t outlen, uint8_t *out, const uint16_t *cdf, unsigned cdfnum)
+{
+    rcd_t d; rcd_start(&d, in);
+    for (size_t i = 0; i < outlen; i++) {
+        d.range >>= PROB_BITS;
+        unsigned x = rcd_find(&d, cdf, cdfnum);
+        rcd_consume(&d, cdf[x], cdf[x + 1]);
+        out[i] = (uint8_t)x;
+    }
+    return outlen;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* M4  rccdfs2enc / rccdfs{l,b}2dec  (rccdf.c:125-184)                                          */
+size_t orc_rccdfs2enc(const uint8_t *in, size_t inlen, uint8_t *out, const uint16_t *cdf, unsigned cdfnum)
+{
+    (void)cdfnum;
+    /* inlen < 4 makes the reference compute a wild stream-1 pointer ((inlen-4) wraps); every
+     * input of 2..9 bytes falls into its raw branch anyway, 0/1 crash it: all of <10 is raw here */
+    if (inlen < 10) { memcpy(out, in, inlen); return inlen; }
+    uint8_t *base0 = out + 4, *base1 = out + 4 + ((inlen - 4) * 37) / 64;
+    rce_t e0, e1; rce_start(&e0, base0); rce_start(&e1, base1);
+    size_t i = 0, pairs = inlen & ~(size_t)1;
+    for (; i < pairs; i += 2) {
+        unsigned x0 = in[i], x1 = in[i + 1];
+        rce_sym(&e0, cdf[x0], cdf[x0 + 1]);
+        rce_sym(&e1, cdf[x1], cdf[x1 + 1]);
+        if (rc_overflow((size_t)(e1.op - out), inlen) || e0.op >= base1) { memcpy(out, in, inlen); return inlen; }
+    }
+    for (; i < inlen; i++) { unsigned x = in[i]; rce_sym(&e0, cdf[x], cdf[x + 1]); }
+    rce_finish(&e0);
+    rce_finish(&e1);
+    size_t len0 = (size_t)(e0.op - base0), len1 = (size_t)(e1.op - base1);
+    st32(out, (uint32_t)len0);
+    memmove(e0.op, base1, len1);
+    size_t total = 4 + len0 + len1;
+    if (rc_overflow(total, inlen)) { memcpy(out, in, inlen); return inlen; }
+    return total;
+}
+size_t orc_rccdfs2dec(const uint8_t *in, size_t outlen, uint8_t *out, const uint16_t *cdf, unsigned cdfnum)
+{
+    rcd_t d0, d1;
+    rcd_start(&d0, in + 4);
+    rcd_start(&d1, in + 4 + ld32(in));
+    size_t i = 0, pairs = outlen & ~(size_t)1;
+    for (; i < pairs; i += 2) {
+        d0.range >>= PROB_BITS; d1.range >>= PROB_BITS;
+        unsigned x0 = rcd_find(&d0, cdf, cdfnum), x1 = rcd_find(&d1, cdf, cdfnum);
+        rcd_consume(&d0, cdf[x0], cdf[x0 + 1]);
+        rcd_consume(&d1, cdf[x1], cdf[x1 + 1]);
+        out[i] = (uint8_t)x0; out[i + 1] = (uint8_t)x1;
+    }
+    for (; i < outlen; i++) {
+        d0.range >>= PROB_BITS;
+        unsigned x = rcd_find(&d0, cdf, cdfnum);
+        rcd_consume(&d0, cdf[x], cdf[x + 1]);
+        out[i] = (uint8_t)x;
+    }
+    return outlen;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* M1  adaptive 16-symbol CDF, rate 7 (cdf_.h:25-41 init, :46-50 / :87-97 SIMD update rule).   */
+typedef struct { uint16_t hi[17]; uint16_t lo[16][17]; } nibmodel_t;
+
+static void nib_reset(nibmodel_t *m)
+{
+    for (int j = 0; j <= 16; j++) {
+        m->hi[j] = (uint16_t)(j << 11);
+        for (int i = 0; i < 16; i++) m->lo[i][j] = (uint16_t)(j << 11);
+    }
+}
+/* after coding symbol x whose lower bound was c = t[x] (read BEFORE the update):
+ * every entry moves 1/128 of the way to 10*i (entries <= c) or 10*i + 32736 (entries > c),
+ * int16 lanes, arithmetic shift. */
+static inline void nib_adapt(uint16_t *t, unsigned x)
+{
+    int16_t c = (int16_t)t[x];
+    for (int i = 0; i < 16; i++) {
+        int16_t v = (int16_t)t[i];
+        int16_t d = (int16_t)((int16_t)(10 * i) - v);
+        if (v > c) d = (int16_t)(d + 32736);
+        t[i] = (uint16_t)(int16_t)(v + (d >> 7));
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* M5  rccdfenc / rccdfdec  (rccdf.c:187-211, rccdf_.h:28-34,48-54, turborc_.h:259-304)         */
+size_t orc_rccdfenc(const uint8_t *in, size_t inlen, uint8_t *out)
+{
+    nibmodel_t m; nib_reset(&m);
+    rce_t e; rce_start(&e, out);
+    for (size_t i = 0; i < inlen; i++) {
+        unsigned h = in[i] >> 4, l = in[i] & 15;
+        rce_sym(&e, m.hi[h], m.hi[h + 1]);       nib_adapt(m.hi, h);
+        uint16_t *t = m.lo[h];
+        rce_sym(&e, t[l], t[l + 1]);             nib_adapt(t, l);
+        if (rc_overflow((size_t)(e.op - out), inlen)) { memcpy(out, in, inlen); return inlen; }
+    }
+    rce_finish(&e);
+    return (size_t)(e.op - out);
+}
+static inline unsigned rcd_nibble(rcd_t *d, uint16_t *t)
+{
+    unsigned x = 0;
+    d->range >>= PROB_BITS;
+    while (x < 15 && (uint64_t)t[x + 1] * d->range <= d->code) x++;  /* first i with t[i+1]*r > code, else 15 */
+    rcd_consume(d, t[x], t[x + 1]);
+    nib_adapt(t, x);
+    return x;
+}
+size_t orc_rccdfdec(const uint8_t *in, size_t outlen, uint8_t *out)
+{
+    nibmodel_t m; nib_reset(&m);
+    rcd_t d; rcd_start(&d, in);
+    for (size_t i = 0; i < outlen; i++) {
+        unsigned h = rcd_nibble(&d, m.hi);
+        unsigned l = rcd_nibble(&d, m.lo[h]);
+        out[i] = (uint8_t)(h << 4 | l);
+    }
+    return outlen;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* M6  32-bit rANS core, 16-bit renorm, 15-bit scale (anscdf_.h:33-48,90-94)                   */
+#define ANS_LO (1u << 15)
+static inline void ans_put(uint32_t *st, uint32_t c0, uint32_t f, uint8_t **ep)
+{
+    uint32_t s = *st;
+    if (s >= (f << 16)) { *ep -= 2; st16(*ep, (uint16_t)s); s >>= 16; }
+    uint32_t q = s / f;
+    *st = s + (q << PROB_BITS) - q * f + c0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* M7  anscdf4senc / anscdf4sdec  (anscdf.c:57-85).  The pointer test of anscdf.c:63,66 (ep vs  */
+/* in) is not reproduced: with `out` above `in` it never fires.                      */
+size_t orc_anscdf4senc(const uint8_t *in, size_t inlen, uint8_t *out, const uint16_t *cdf)
+{
+    size_t cap = 2 * inlen + 16;                       /* <= 1 word per symbol + 2 states */
+    uint8_t *buf = (uint8_t *)malloc(cap), *ep = buf + cap;
+    uint32_t st[2] = { ANS_LO, ANS_LO };
+    size_t ip = inlen, body = inlen & ~(size_t)3;
+    if (!buf) return 0;
+    while (ip > body) { unsigned x = in[--ip]; ans_put(&st[0], cdf[x], (uint32_t)cdf[x + 1] - cdf[x], &ep); }
+    while (ip > 0) {
+        unsigned x;
+        x = in[--ip]; ans_put(&st[1], cdf[x], (uint32_t)cdf[x + 1] - cdf[x], &ep);
+        x = in[--ip]; ans_put(&st[0], cdf[x], (uint32_t)cdf[x + 1] - cdf[x], &ep);
+        x = in[--ip]; ans_put(&st[1], cdf[x], (uint32_t)cdf[x + 1] - cdf[x], &ep);
+        x = in[--ip]; ans_put(&st[0], cdf[x], (uint32_t)cdf[x + 1] - cdf[x], &ep);
+    }
+    ep -= 4; st32(ep, st[0]);
+    ep -= 4; st32(ep, st[1]);
+    size_t l = (size_t)(buf + cap - ep);
+    if (l >= inlen) { memcpy(out, in, inlen); l = inlen; } else memcpy(out, ep, l);
+    free(buf);
+    return l;
+}
+static inline unsigned ans_get(uint32_t *st, const uint16_t *cdf, unsigned cdfnum, const uint8_t **ip)
+{
+    uint32_t s = *st, slot = s & (PROB_ONE - 1);
+    unsigned x = 0, hi = cdfnum;                      /* largest x with cdf[x] <= slot */
+    while (x + 1 < hi) { unsigned mid = (x + hi) >> 1; if (cdf[mid] > slot) hi = mid; else x = mid; }
+    s = ((uint32_t)cdf[x + 1] - cdf[x]) * (s >> PROB_BITS) + slot - cdf[x];
+    if (s < ANS_LO) { s = s << 16 | ld16(*ip); *ip += 2; }
+    *st = s;
+    return x;
+}
+size_t orc_anscdf4sdec(const uint8_t *in, size_t outlen, uint8_t *out, const uint16_t *cdf, unsigned cdfnum)
+{
+    const uint8_t *ip = in;
+    uint32_t sa = ld32(ip), sb = ld32(ip + 4);        /* sa = encoder state 1, sb = encoder state 0 */
+    ip += 8;
+    size_t i = 0, body = outlen & ~(size_t)3;
+    for (; i < body; i += 4) {
+        out[i]     = (uint8_t)ans_get(&sb, cdf, cdfnum, &ip);
+        out[i + 1] = (uint8_t)ans_get(&sa, cdf, cdfnum, &ip);
+        out[i + 2] = (uint8_t)ans_get(&sb, cdf, cdfnum, &ip);
+        out[i + 3] = (uint8_t)ans_get(&sa, cdf, cdfnum, &ip);
+    }
+    for (; i < outlen; i++) out[i] = (uint8_t)ans_get(&sb, cdf, cdfnum, &ip);   /* encoder coded the tail on its state 0 */
+    return outlen;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* M8  anscdfenc / anscdfdec  (anscdf.c:567-605; anscdf_.h:106-162)                             */
+#define ANS_BLOCK ((size_t)1 << 22)
+size_t orc_anscdfenc(const uint8_t *in, size_t inlen, uint8_t *out)
+{
+    size_t blk = inlen < ANS_BLOCK ? inlen : ANS_BLOCK;
+    uint32_t *stack = (uint32_t *)malloc((blk + 1) * 2 * sizeof(uint32_t) + 64);
+    uint8_t *op = out, *oend = out + inlen;
+    size_t pos = 0;
+    if (!stack) return 0;
+    while (pos < inlen) {
+        size_t len = inlen - pos < blk ? inlen - pos : blk, k, ns = 0;
+        nibmodel_t m; nib_reset(&m);
+        /* pass 1 (forward): record {state id, cdf_lo, freq} per nibble, adapting as we go */
+        for (k = 0; k < len + (len & 1); k += 2) {
+            unsigned x0 = in[pos + k], x1 = (k + 1 < len) ? in[pos + k + 1] : 0;   /* odd tail pairs with a coded dummy 0 */
+            unsigned xs[2] = { x0, x1 };
+            for (int b = 0; b < 2; b++) {
+                unsigned h = xs[b] >> 4, l = xs[b] & 15, sid = 3u - 2u * (unsigned)b;
+                stack[ns++] = sid << 30 | (uint32_t)m.hi[h] << 15 | (uint32_t)(m.hi[h + 1] - m.hi[h]);
+                nib_adapt(m.hi, h);
+                uint16_t *t = m.lo[h];
+                stack[ns++] = (sid - 1) << 30 | (uint32_t)t[l] << 15 | (uint32_t)(t[l + 1] - t[l]);
+                nib_adapt(t, l);
+            }
+        }
+        /* pass 2 (backward): rANS steps, words grow downward from out+inlen */
+        uint32_t st[4] = { ANS_LO, ANS_LO, ANS_LO, ANS_LO };
+        uint8_t *ep = oend;
+        while (ns) {
+            uint32_t r = stack[--ns];
+            if (ep <= op + 2 + 16) goto raw;
+            ans_put(&st[r >> 30], (r >> 15) & 0x7fff, r & 0x7fff, &ep);
+        }
+        for (k = 0; k < 4; k++) { ep -= 4; st32(ep, st[k]); }
+        if (ep <= op) goto raw;
+        size_t l = (size_t)(oend - ep);
+        if (op + l >= oend) goto raw;
+        memmove(op, ep, l); op += l;
+        pos += len;
+    }
+    free(stack);
+    return (size_t)(op - out);
+raw:
+    /* reference quirk (anscdf.c:573,583): for a multi-block input its raw copy starts at the
+     * ADVANCED in pointer and over-reads; we copy the whole input from its true start. */
+    free(stack);
+    memcpy(out, in, inlen);
+    return inlen;
+}
+static inline unsigned ansd_nibble(uint32_t *st, uint16_t *t)   /* cdf16ansdec: search + state + model */
+{
+    uint32_t s = *st, slot = s & (PROB_ONE - 1);
+    unsigned x = 0;
+    while (x < 15 && t[x + 1] <= slot) x++;
+    *st = ((uint32_t)t[x + 1] - t[x]) * (s >> PROB_BITS) + slot - t[x];
+    nib_adapt(t, x);
+    return x;
+}
+static inline void ansd_renorm(uint32_t *st, const uint8_t **ip)
+{
+    if (*st < ANS_LO) { *st = *st << 16 | ld16(*ip); *ip += 2; }
+}
+size_t orc_anscdfdec(const uint8_t *in, size_t outlen, uint8_t *out)
+{
+    size_t blk = outlen < ANS_BLOCK ? outlen : ANS_BLOCK, pos = 0;
+    const uint8_t *ip = in;
+    while (pos < outlen) {
+        size_t len = outlen - pos < blk ? outlen - pos : blk, k;
+        nibmodel_t m; nib_reset(&m);
+        uint32_t st[4];
+        for (k = 0; k < 4; k++) { st[k] = ld32(ip); ip += 4; }
+        for (k = 0; k < len; k += 2) {
+            unsigned h0 = ansd_nibble(&st[0], m.hi), l0 = ansd_nibble(&st[1], m.lo[h0]);
+            unsigned h1 = ansd_nibble(&st[2], m.hi), l1 = ansd_nibble(&st[3], m.lo[h1]);
+            ansd_renorm(&st[0], &ip); ansd_renorm(&st[1], &ip);
+            ansd_renorm(&st[2], &ip); ansd_renorm(&st[3], &ip);
+            out[pos + k] = (uint8_t)(h0 << 4 | l0);
+            if (k + 1 < len) out[pos + k + 1] = (uint8_t)(h1 << 4 | l1);
+        }
+        pos += len;
+    }
+    return outlen;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* M9  rcsenc / rcsdec  (rc_.c:37-58, mb_o0.h:27-41,89-112, turborc_.h:417-452, mbc_s.h:53-55)  */
+static inline uint16_t bit_adapt(uint32_t p, uint32_t bit)
+{
+    return (uint16_t)(p - (((p - (bit ? PROB_ONE : 0u)) >> 5) + bit));   /* 32-bit unsigned, logical shift */
+}
+size_t orc_rcsenc(const uint8_t *in, size_t inlen, uint8_t *out)
+{
+    uint16_t mb[256];
+    rce_t e; rce_start(&e, out);
+    for (int i = 0; i < 256; i++) mb[i] = PROB_ONE >> 1;
+    for (size_t i = 0; i < inlen; i++) {
+        unsigned x = in[i], ctx = 1;
+        for (int b = 7; b >= 0; b--) {
+            if (b & 1) rce_renorm(&e);                 /* renorm only before bits 7,5,3,1 */
+            uint32_t p = mb[ctx], bit = (x >> b) & 1;
+            uint64_t cut = (e.range >> PROB_BITS) * p;
+            if (bit) e.range = cut; else { e.low += cut; e.range -= cut; }
+            mb[ctx] = bit_adapt(p, bit);
+            ctx = ctx * 2 + bit;
+        }
+        if (rc_overflow((size_t)(e.op - out), inlen)) { memcpy(out, in, inlen); return inlen; }
+    }
+    rce_finish(&e);
+    return (size_t)(e.op - out);
+}
+size_t orc_rcsdec(const uint8_t *in, size_t outlen, uint8_t *out)
+{
+    uint16_t mb[256];
+    rcd_t d; rcd_start(&d, in);
+    for (int i = 0; i < 256; i++) mb[i] = PROB_ONE >> 1;
+    for (size_t i = 0; i < outlen; i++) {
+        unsigned ctx = 1;
+        for (int b = 7; b >= 0; b--) {
+            if (b & 1) rcd_renorm(&d);
+            uint32_t p = mb[ctx], bit;
+            uint64_t cut = (d.range >> PROB_BITS) * p;
+            if (d.code < cut) { d.range = cut; bit = 1; } else { d.range -= cut; d.code -= cut; bit = 0; }
+            mb[ctx] = bit_adapt(p, bit);
+            ctx = ctx * 2 + bit;
+        }
+        out[i] = (uint8_t)ctx;
+    }
+    return outlen;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Per-chunk drivers (the product's unit of parallelism: payload(c) == coder(chunk c)).        */
+static size_t enc_one(int codec, const uint8_t *in, size_t n, uint8_t *out, const uint16_t *cdf, unsigned cdfnum)
+{
+    switch (codec) {
+    case ORC_ANS4S: return orc_anscdf4senc(in, n, out, cdf);
+    case ORC_RCS1:  return orc_rccdfsenc(in, n, out, cdf, cdfnum);
+    case ORC_RCS2:  return orc_rccdfs2enc(in, n, out, cdf, cdfnum);
+    case ORC_RCA:   return orc_rccdfenc(in, n, out);
+    case ORC_ANSA:  return orc_anscdfenc(in, n, out);
+    case ORC_RCB:   return orc_rcsenc(in, n, out);
+    }
+    return 0;
+}
+static void dec_one(int codec, const uint8_t *in, size_t n, uint8_t *out, const uint16_t *cdf, unsigned cdfnum)
+{
+    switch (codec) {
+    case ORC_ANS4S: orc_anscdf4sdec(in, n, out, cdf, cdfnum); break;
+    case ORC_RCS1:  orc_rccdfsdec(in, n, out, cdf, cdfnum); break;
+    case ORC_RCS2:  orc_rccdfs2dec(in, n, out, cdf, cdfnum); break;
+    case ORC_RCA:   orc_rccdfdec(in, n, out); break;
+    case ORC_ANSA:  orc_anscdfdec(in, n, out); break;
+    case ORC_RCB:   orc_rcsdec(in, n, out); break;
+    }
+}
+size_t orc_chunked_enc(int codec, const uint8_t *in, size_t n, size_t chunk,
+                       const uint16_t *cdf, unsigned cdfnum,
+                       uint8_t *payload, uint32_t *clen, uint64_t *poff)
+{
+    size_t nch = chunk ? (n + chunk - 1) / chunk : 0, off = 0;
+    uint8_t *tmp = (uint8_t *)malloc(chunk + 64);
+    if (!tmp) return 0;
+    for (size_t c = 0; c < nch; c++) {
+        size_t len = n - c * chunk < chunk ? n - c * chunk : chunk;
+        size_t l = enc_one(codec, in + c * chunk, len, tmp, cdf, cdfnum);
+        memcpy(payload + off, tmp, l);
+        clen[c] = (uint32_t)l; poff[c] = off; off += l;
+    }
+    poff[nch] = off;
+    free(tmp);
+    return off;
+}
+size_t orc_chunked_dec(int codec, const uint8_t *payload, const uint32_t *clen, size_t n, size_t chunk,
+                       const uint16_t *cdf, unsigned cdfnum, uint8_t *out)
+{
+    size_t nch = chunk ? (n + chunk - 1) / chunk : 0, off = 0;
+    uint8_t *tmp = (uint8_t *)malloc(chunk + 64);
+    if (!tmp) return 0;
+    for (size_t c = 0; c < nch; c++) {
+        size_t len = n - c * chunk < chunk ? n - c * chunk : chunk;
+        if (clen[c] == len) memcpy(out + c * chunk, payload + off, len);      /* stored raw */
+        else {
+            memcpy(tmp, payload + off, clen[c]); memset(tmp + clen[c], 0, 16);  /* decoders over-read <= 8 B */
+            dec_one(codec, tmp, len, out + c * chunk, cdf, cdfnum);
+        }
+        off += clen[c];
+    }
+    free(tmp);
+    return n;
+}

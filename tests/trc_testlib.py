@@ -1,0 +1,300 @@
+"""Shared helpers for the parity tests (TEST INFRASTRUCTURE).
+
+* deterministic synthetic inputs (own splitmix64 stream, so the GPU box regenerates the same bytes)
+* ctypes bindings for the CPU oracle (oracle/libtrc_oracle.so) and, when it was built in the
+  development container, the compiled reference (oracle/_ref/libtrc_ref.so)
+* `ref_*` wrappers that respect the reference's calling quirks: `out` is placed at a
+  HIGHER address than `in` with slack below it, and a decoder is never called on a raw stream.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libtrc_oracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libtrc_ref.so")
+
+# codec ids == include/trc_hip.h == oracle/trc_oracle.h
+ANS4S, RCS1, RCS2, RCA, ANSA, RCB = 1, 2, 3, 4, 5, 6
+CODEC_NAMES = {ANS4S: "anscdf4s", RCS1: "rccdfs", RCS2: "rccdfs2", RCA: "rccdf", ANSA: "anscdf", RCB: "rcs"}
+STATIC_CODECS = (ANS4S, RCS1, RCS2)
+
+_u8p = C.POINTER(C.c_uint8)
+_u16p = C.POINTER(C.c_uint16)
+
+
+# ------------------------------------------------------------------------------- inputs ---------
+def splitmix64(n, seed):
+    """n 64-bit words of the splitmix64 stream started at `seed` (vectorised)."""
+    with np.errstate(over="ignore"):
+        z = (np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) + np.uint64(seed)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def uniform_bytes(n, seed=1):
+    w = splitmix64((n + 7) // 8, seed)
+    return w.view(np.uint8)[:n].copy()
+
+
+def table_bytes(n, weights, seed=1):
+    """i.i.d. bytes drawn from `weights` (len <= 256) by inverse-CDF on the splitmix64 stream."""
+    w = np.asarray(weights, dtype=np.float64)
+    cum = np.cumsum(w / w.sum())
+    cum[-1] = 1.0
+    u = (splitmix64(n, seed) >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+    return np.searchsorted(cum, u, side="right").astype(np.uint8)
+
+
+def zipf_bytes(n, alpha=1.1, nsym=256, seed=1):
+    return table_bytes(n, 1.0 / np.arange(1, nsym + 1) ** alpha, seed)
+
+
+def text_bytes(n, seed=7):
+    """'enwik8 stand-in' (SURVEY 8d cfg 2): i.i.d. bytes, English-like order-0 table, ~5.1 bit/B."""
+    w = np.full(256, 2e-5)
+    common = b" etaoinshrdlcumwfgypbvkjxqz"
+    freq = [17.0, 9.6, 7.0, 6.2, 5.9, 5.5, 5.3, 5.0, 4.5, 4.4, 3.3, 3.1, 2.4, 2.2, 2.1, 1.9, 1.8, 1.6, 1.5, 1.3,
+            1.2, 0.8, 0.6, 0.15, 0.13, 0.1, 0.07]
+    for ch, f in zip(common, freq):
+        w[ch] = f
+    for ch in range(ord("A"), ord("Z") + 1):
+        w[ch] = 0.18
+    for ch in b"0123456789":
+        w[ch] = 0.45
+    for ch, f in zip(b"[]|=<>/&;:.,'\"\n-()", [1.2, 1.2, 0.7, 0.6, 0.9, 0.9, 0.6, 0.5, 0.5, 0.4, 0.9, 1.0, 0.5, 0.5, 1.3, 0.4, 0.2, 0.2]):
+        w[ch] = f
+    return table_bytes(n, w, seed)
+
+
+def runs_bytes(n, seed=3, mean_run=6.0, alpha=1.2):
+    """'enwik8bwt stand-in' (SURVEY 8d cfg 3): geometric runs over a Zipf alphabet."""
+    nr = int(n / mean_run * 1.3) + 16
+    sym = zipf_bytes(nr, alpha, 256, seed)
+    u = (splitmix64(nr, seed + 99) >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+    rl = (np.floor(np.log1p(-u) / np.log1p(-1.0 / mean_run)) + 1).astype(np.int64)
+    out = np.repeat(sym, rl)
+    while out.size < n:
+        out = np.concatenate([out, out])
+    return out[:n].copy()
+
+
+def fnv1a64(b):
+    """FNV-1a-64 of a bytes-like (for large-case fixtures)."""
+    h = 0xCBF29CE484222325
+    for x in bytes(b):
+        h = ((h ^ x) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+# ------------------------------------------------------------------------------- oracle ---------
+def build_oracle():
+    if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(os.path.join(ORACLE_DIR, "trc_oracle.c")):
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "libtrc_oracle.so"])
+    return ORACLE_SO
+
+
+_oracle = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        lib = C.CDLL(build_oracle())
+        sz = C.c_size_t
+        lib.orc_cdfini.restype = C.c_int
+        lib.orc_cdfini.argtypes = [_u8p, sz, _u16p, C.c_uint]
+        for name in ("orc_rccdfsenc", "orc_rccdfsdec", "orc_rccdfs2enc", "orc_rccdfs2dec"):
+            f = getattr(lib, name); f.restype = sz; f.argtypes = [_u8p, sz, _u8p, _u16p, C.c_uint]
+        lib.orc_anscdf4senc.restype = sz; lib.orc_anscdf4senc.argtypes = [_u8p, sz, _u8p, _u16p]
+        lib.orc_anscdf4sdec.restype = sz; lib.orc_anscdf4sdec.argtypes = [_u8p, sz, _u8p, _u16p, C.c_uint]
+        for name in ("orc_rccdfenc", "orc_rccdfdec", "orc_anscdfenc", "orc_anscdfdec", "orc_rcsenc", "orc_rcsdec"):
+            f = getattr(lib, name); f.restype = sz; f.argtypes = [_u8p, sz, _u8p]
+        lib.orc_chunked_enc.restype = sz
+        lib.orc_chunked_enc.argtypes = [C.c_int, _u8p, sz, sz, _u16p, C.c_uint, _u8p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+        lib.orc_chunked_dec.restype = sz
+        lib.orc_chunked_dec.argtypes = [C.c_int, _u8p, C.POINTER(C.c_uint32), sz, sz, _u16p, C.c_uint, _u8p]
+        _oracle = lib
+    return _oracle
+
+
+def _p8(a):
+    return a.ctypes.data_as(_u8p)
+
+
+def _p16(a):
+    return a.ctypes.data_as(_u16p)
+
+
+def orc_cdfini(data, cdfnum=None):
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    if cdfnum is None:
+        cdfnum = int(data.max()) + 1
+    cdf = np.zeros(257, dtype=np.uint16)
+    r = oracle().orc_cdfini(_p8(data), data.size, _p16(cdf), cdfnum)
+    return r, cdf, cdfnum
+
+
+def orc_enc(codec, data, cdf=None, cdfnum=256):
+    """Whole-buffer oracle encode -> bytes (np.uint8 array of the returned length)."""
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    n = data.size
+    out = np.zeros(n + 64, dtype=np.uint8)
+    o = oracle()
+    if codec == ANS4S:
+        l = o.orc_anscdf4senc(_p8(data), n, _p8(out), _p16(cdf))
+    elif codec == RCS1:
+        l = o.orc_rccdfsenc(_p8(data), n, _p8(out), _p16(cdf), cdfnum)
+    elif codec == RCS2:
+        l = o.orc_rccdfs2enc(_p8(data), n, _p8(out), _p16(cdf), cdfnum)
+    elif codec == RCA:
+        l = o.orc_rccdfenc(_p8(data), n, _p8(out))
+    elif codec == ANSA:
+        l = o.orc_anscdfenc(_p8(data), n, _p8(out))
+    elif codec == RCB:
+        l = o.orc_rcsenc(_p8(data), n, _p8(out))
+    else:
+        raise ValueError(codec)
+    return out[:l].copy()
+
+
+def orc_dec(codec, comp, n, cdf=None, cdfnum=256):
+    comp = np.ascontiguousarray(comp, dtype=np.uint8)
+    if comp.size == n:
+        return comp.copy()                      # stored raw (CCPY rule, turborc.c:434)
+    src = np.zeros(comp.size + 64, dtype=np.uint8)
+    src[:comp.size] = comp
+    out = np.zeros(n + 8, dtype=np.uint8)
+    o = oracle()
+    if codec == ANS4S:
+        o.orc_anscdf4sdec(_p8(src), n, _p8(out), _p16(cdf), cdfnum)
+    elif codec == RCS1:
+        o.orc_rccdfsdec(_p8(src), n, _p8(out), _p16(cdf), cdfnum)
+    elif codec == RCS2:
+        o.orc_rccdfs2dec(_p8(src), n, _p8(out), _p16(cdf), cdfnum)
+    elif codec == RCA:
+        o.orc_rccdfdec(_p8(src), n, _p8(out))
+    elif codec == ANSA:
+        o.orc_anscdfdec(_p8(src), n, _p8(out))
+    elif codec == RCB:
+        o.orc_rcsdec(_p8(src), n, _p8(out))
+    else:
+        raise ValueError(codec)
+    return out[:n].copy()
+
+
+def orc_chunked_enc(codec, data, chunk, cdf=None, cdfnum=256):
+    """-> (payload bytes, clen[nchunks] u32, poff[nchunks+1] u64): chunk c's payload = coder(chunk c)."""
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    n = data.size
+    nch = (n + chunk - 1) // chunk
+    payload = np.zeros(n + 64, dtype=np.uint8)
+    clen = np.zeros(max(nch, 1), dtype=np.uint32)
+    poff = np.zeros(nch + 1, dtype=np.uint64)
+    cdfp = _p16(cdf) if cdf is not None else None
+    tot = oracle().orc_chunked_enc(codec, _p8(data), n, chunk, cdfp, cdfnum, _p8(payload),
+                                   clen.ctypes.data_as(C.POINTER(C.c_uint32)), poff.ctypes.data_as(C.POINTER(C.c_uint64)))
+    return payload[:tot].copy(), clen[:nch].copy(), poff
+
+
+def orc_chunked_dec(codec, payload, clen, n, chunk, cdf=None, cdfnum=256):
+    payload = np.ascontiguousarray(payload, dtype=np.uint8)
+    clen = np.ascontiguousarray(clen, dtype=np.uint32)
+    out = np.zeros(n + 8, dtype=np.uint8)
+    cdfp = _p16(cdf) if cdf is not None else None
+    src = np.zeros(payload.size + 64, dtype=np.uint8); src[:payload.size] = payload
+    oracle().orc_chunked_dec(codec, _p8(src), clen.ctypes.data_as(C.POINTER(C.c_uint32)), n, chunk, cdfp, cdfnum, _p8(out))
+    return out[:n].copy()
+
+
+# ------------------------------------------------------------------------------- reference ------
+_ref = None
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        lib = C.CDLL(REF_SO)
+        sz = C.c_size_t
+        lib.cdfini.restype = C.c_int; lib.cdfini.argtypes = [_u8p, sz, _u16p, C.c_uint]
+        for name in ("rccdfsenc", "rccdfsbdec", "rccdfsldec", "rccdfsvbdec", "rccdfsvldec", "rccdfs2enc", "rccdfsb2dec"):
+            f = getattr(lib, name); f.restype = sz; f.argtypes = [_u8p, sz, _u8p, _u16p, C.c_uint]
+        for name in ("anscdf4senc", "anscdf4sencs", "anscdf4sencx"):
+            f = getattr(lib, name); f.restype = sz; f.argtypes = [_u8p, sz, _u8p, _u16p]
+        for name in ("rccdfenc", "rccdfdec", "anscdfenc", "anscdfdec", "anscdfencs", "anscdfdecs", "anscdfencx", "anscdfdecx", "rcsenc", "rcsdec"):
+            f = getattr(lib, name); f.restype = sz; f.argtypes = [_u8p, sz, _u8p]
+        _ref = lib
+    return _ref
+
+
+def _arena(n):
+    """One allocation with `in` low and `out` high and 2n+64 bytes of slack between
+    them (anscdf4senc writes downward from out+n and may under-run `out` on expanding data)."""
+    gap = 2 * n + 64
+    buf = np.zeros(n + gap + n + n // 2 + 1024, dtype=np.uint8)
+    return buf, 0, n + gap
+
+
+def ref_enc(codec, data, cdf=None, cdfnum=256, variant=""):
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    n = data.size
+    buf, io, oo = _arena(n)
+    buf[io:io + n] = data
+    base = buf.ctypes.data
+    pin = C.cast(base + io, _u8p); pout = C.cast(base + oo, _u8p)
+    r = ref()
+    if codec == ANS4S:
+        l = getattr(r, "anscdf4senc" + variant)(pin, n, pout, _p16(cdf))
+    elif codec == RCS1:
+        l = r.rccdfsenc(pin, n, pout, _p16(cdf), cdfnum)
+    elif codec == RCS2:
+        l = r.rccdfs2enc(pin, n, pout, _p16(cdf), cdfnum)
+    elif codec == RCA:
+        l = r.rccdfenc(pin, n, pout)
+    elif codec == ANSA:
+        l = getattr(r, "anscdfenc" + variant)(pin, n, pout)
+    elif codec == RCB:
+        l = r.rcsenc(pin, n, pout)
+    else:
+        raise ValueError(codec)
+    return buf[oo:oo + l].copy()
+
+
+def ref_dec(codec, comp, n, cdf=None, cdfnum=256, variant="", search="b"):
+    """Reference decode; ANS4S has no byte-alphabet reference decoder -> None."""
+    comp = np.ascontiguousarray(comp, dtype=np.uint8)
+    if comp.size == n:
+        return comp.copy()
+    if codec == ANS4S:
+        return None
+    src = np.zeros(comp.size + 1024, dtype=np.uint8); src[:comp.size] = comp
+    out = np.zeros(n + 64, dtype=np.uint8)
+    r = ref()
+    if codec == RCS1:
+        getattr(r, "rccdfs%sdec" % search)(_p8(src), n, _p8(out), _p16(cdf), cdfnum)
+    elif codec == RCS2:
+        r.rccdfsb2dec(_p8(src), n, _p8(out), _p16(cdf), cdfnum)
+    elif codec == RCA:
+        r.rccdfdec(_p8(src), n, _p8(out))
+    elif codec == ANSA:
+        getattr(r, "anscdfdec" + variant)(_p8(src), n, _p8(out))
+    elif codec == RCB:
+        r.rcsdec(_p8(src), n, _p8(out))
+    return out[:n].copy()
+
+
+def ref_cdfini(data, cdfnum=None):
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    if cdfnum is None:
+        cdfnum = int(data.max()) + 1
+    cdf = np.zeros(257, dtype=np.uint16)
+    r = ref().cdfini(_p8(data), data.size, _p16(cdf), cdfnum)
+    return r, cdf, cdfnum
