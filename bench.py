@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric: encode+decode MB/s, order-0 static-CDF rANS, 100 MB bytes.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+A "step" = one encode pass + one decode pass of the hot path over this rank's 100 MB shard, inputs
+already resident in HBM (weak scaling: every rank codes its own 100 MB of independent chunks; for
+N > 1 the per-rank compressed payloads are gathered to rank 0 with RCCL inside the timed region --
+the path's only exchange step).  value = bytes all ranks processed / max-over-ranks wall time, with
+MB = 10^6 (reference include_/time_.h:113,233), i.e. N / (t_enc + t_dec) per SURVEY 8d.
+
+Workload (configs[1]): "text100m" -- 100 000 000 i.i.d. bytes from an English-like order-0 table,
+the enwik8 stand-in of SURVEY 8d (no corpus, no network); set ENWIK8=/path/to/enwik8 to use the real
+file.  Coder: static-CDF rANS, payload(chunk) bit-identical to anscdf4senc(chunk); CDF from cdfini
+on device (untimed, as in the reference harness turborc.c:429-433).
+
+Extra objects on the JSON line:
+  roofline      dominant coder kernel: algorithmic bytes (N + C) per launch / mean launch duration
+                measured with HIP events recorded around that kernel on its own stream, vs 8 TB/s HBM
+  cpu_baseline  the reference (oracle/_ref) or, where absent, the oracle port, 1 thread, on a bounded
+                sample of the same workload (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "turbo-range-coder_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def make_input(n, rank):
+    import trc_testlib as T
+    path = os.environ.get("ENWIK8")
+    if path and os.path.exists(path):
+        d = np.fromfile(path, dtype=np.uint8)
+        reps = (n + d.size - 1) // d.size
+        return np.tile(d, reps)[:n].copy(), "enwik8"
+    return T.text_bytes(n, 7 + rank), "text100m"
+
+
+def cpu_baseline(d, cdf, cdfnum, sample):
+    """1-thread CPU timing on d[:sample]: reference anscdf4senc (oracle/_ref) when present, decode by
+    the oracle port (the reference has no byte-alphabet static-rANS decoder); plus the
+    literal `turborc -e45` pair rccdfs2enc/rccdfsb2dec for context."""
+    import trc_testlib as T
+    s = np.ascontiguousarray(d[:sample])
+    out = {"cores": 1, "unit": "MB/s"}
+    use_ref = T.have_ref()
+    best_e = best_d = 1e9
+    for _ in range(2):
+        t0 = time.perf_counter()
+        comp = T.ref_enc(T.ANS4S, s, cdf, cdfnum) if use_ref else T.orc_enc(T.ANS4S, s, cdf, cdfnum)
+        t1 = time.perf_counter()
+        dec = T.orc_dec(T.ANS4S, comp, s.size, cdf, cdfnum)
+        t2 = time.perf_counter()
+        best_e, best_d = min(best_e, t1 - t0), min(best_d, t2 - t1)
+    assert np.array_equal(dec, s)
+    out["value"] = round(s.size / (best_e + best_d) / 1e6, 2)
+    out["enc_MBps"] = round(s.size / best_e / 1e6, 2)
+    out["dec_MBps"] = round(s.size / best_d / 1e6, 2)
+    out["kind"] = "reference" if use_ref else "port"
+    out["sample"] = ("first %d bytes of the workload, whole-buffer call, min of 2 runs; encode = %s anscdf4senc, "
+                     "decode = oracle port orc_anscdf4sdec (no byte-alphabet decoder exists in the reference)"
+                     % (s.size, "reference" if use_ref else "oracle port"))
+    if use_ref:
+        t0 = time.perf_counter(); c45 = T.ref_enc(T.RCS2, s, cdf, cdfnum); t1 = time.perf_counter()
+        d45 = T.ref_dec(T.RCS2, c45, s.size, cdf, cdfnum); t2 = time.perf_counter()
+        assert np.array_equal(d45, s)
+        out["e45_reference_MBps"] = {"enc": round(s.size / (t1 - t0) / 1e6, 2), "dec": round(s.size / (t2 - t1) / 1e6, 2),
+                                     "encdec": round(s.size / (t2 - t0) / 1e6, 2)}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=100 * 1000 * 1000, help="bytes per GPU")
+    ap.add_argument("--chunk", type=int, default=int(os.environ.get("TRC_BENCH_CHUNK", "4096")))
+    ap.add_argument("--codec", default="anscdf4s")
+    ap.add_argument("--cpu-sample", type=int, default=32 * 1000 * 1000)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import trc
+    import trc_testlib as T
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs a GPU: libturborc_hip has no CPU path"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    codec = {v: k for k, v in trc.CODEC_NAMES.items()}[args.codec]
+    n, chunk = args.size, args.chunk
+    d, wname = make_input(n, rank)
+    d_in = torch.from_numpy(np.concatenate([d, np.zeros(512, np.uint8)])).to(dev)
+    dc = trc.DeviceCoder(codec, n, chunk, dev)
+    cdfnum = 256
+    if codec in trc.STATIC:
+        dc.cdfini(d_in, n, cdfnum)                         # untimed, like the reference harness
+        torch.cuda.synchronize(dev)
+        assert int(dc.status[0].item()) == n, "cdfini failed"
+    d_out = torch.zeros(n + 512, dtype=torch.uint8, device=dev)
+
+    # multi-GPU exchange buffers: rank 0 receives every rank's payload (variable size) + directory
+    gather_buf = None
+    if world > 1 and rank == 0:
+        gather_buf = [torch.empty(n + 1024, dtype=torch.uint8, device=dev) for _ in range(world - 1)]
+    tot_all = torch.zeros(world, dtype=torch.int64, device=dev) if world > 1 else None
+
+    def exchange():
+        """RCCL gather of the compressed payloads to rank 0: all_gather of the sizes, then one
+        point-to-point transfer per peer (each rides its own xGMI link)."""
+        dist.all_gather_into_tensor(tot_all, dc.total[:1])
+        sizes = tot_all.tolist()
+        ops = []
+        if rank == 0:
+            for r in range(1, world):
+                ops.append(dist.P2POp(dist.irecv, gather_buf[r - 1][:sizes[r]], r))
+        else:
+            ops.append(dist.P2POp(dist.isend, dc.payload[:sizes[rank]], 0))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+    def step():
+        dc.encode(d_in, n)
+        if world > 1:
+            exchange()
+        dc.decode(d_out, n)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if not args.no_verify:
+        assert torch.equal(d_out[:n], d_in[:n]), "round trip failed"
+
+    trc.timing_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    enc_ms, enc_cnt = trc.timing_read(False)
+    dec_ms, dec_cnt = trc.timing_read(True)
+    trc.timing_enable(False)
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    total_c = int(dc.total[0].item())
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        value = (n * world * args.steps) / dt / 1e6
+        enc_avg = enc_ms / max(enc_cnt, 1)
+        dec_avg = dec_ms / max(dec_cnt, 1)
+        # dominant kernel = the slower of the two coder kernels; algorithmic bytes = N + C per launch
+        dom = "enc" if enc_avg >= dec_avg else "dec"
+        dom_ms = max(enc_avg, dec_avg)
+        alg_bytes = n + total_c
+        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("%s_%s_chunk%d" % (args.codec, dom, chunk))
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "encode+decode MB/s, order-0 static-CDF rANS, 100 MB bytes",
+            "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "%s: %d B/GPU, static-CDF rANS (anscdf4senc/anscdf4sdec per chunk), chunk %d B, "
+                                   "1 lane = 1 chunk (2 rANS states), 64 chunks/wave, tables in LDS" % (wname, n, chunk),
+                       "codec": args.codec, "chunk": chunk, "bytes_per_gpu": n, "compressed_bytes_per_gpu": total_c,
+                       "ratio": round(total_c / n, 5), "exchange": "rccl gather of payloads to rank 0" if world > 1 else "none"},
+            "enc_MBps": round(n / (enc_avg * 1e-3) / 1e6, 1) if enc_avg else None,
+            "dec_MBps": round(n / (dec_avg * 1e-3) / 1e6, 1) if dec_avg else None,
+            "roofline": {"bound": "hbm", "kernel": trc.lib().trc_kernel_name(codec, dom == "dec").decode(),
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "alg_bytes_per_launch": alg_bytes,
+                         "enc_kernel_ms": round(enc_avg, 4), "dec_kernel_ms": round(dec_avg, 4), "launches_timed": enc_cnt},
+        }
+        if world == 1 and not args.no_cpu:
+            cdf = dc.cdf[:cdfnum + 1].cpu().numpy().view(np.uint16).copy()
+            cdf_full = np.zeros(257, dtype=np.uint16); cdf_full[:cdfnum + 1] = cdf
+            res["cpu_baseline"] = cpu_baseline(d, cdf_full, cdfnum, min(args.cpu_sample, n))
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,118 @@
+/*
+ * trc_hip.h -- C-ABI of libturborc_hip.so, the MI355X (gfx950) entropy-coding core.
+ *
+ * Two layers, both plain C (no torch / C++ types in any signature):
+ *
+ *  (1) the reference's own prototypes -- include/anscdf.h and include/turborc.h in this repo carry
+ *      the same signatures as the reference's include/anscdf.h:40-52,70-96 and
+ *      include/turborc.h:62-63,497-519 -- host pointers in, host pointers out, so a TurboRC-style
+ *      bench harness links unchanged;
+ *  (2) the device-resident entry points below (the "*_dev" extension SURVEY.md section 8b allows):
+ *      everything stays in HBM, the caller owns all buffers and the HIP stream.  bench.py, the
+ *      parity tests and the multi-GPU path use this layer.
+ *
+ * Unit of parallelism = CHUNK.  The input is cut into `chunk`-byte slices; chunk c is coded by the
+ * reference algorithm exactly as if the reference function had been called on that slice alone:
+ *
+ *        payload(c) == reference_fn(in + c*chunk, len_c)          (bit-exact, incl. raw fallback)
+ *
+ * clen[c] is the reference function's return value for the slice (== len_c means "stored raw",
+ * include/turborc.h:50-53).  Payloads are concatenated without padding in chunk order.
+ *
+ * Host-pointer calls wrap this in a self-describing container:
+ *        trc_container_hdr (32 B) | uint32 clen[nchunks] | payload bytes
+ * and keep the reference's return convention (== inlen  =>  out is a raw copy of in).
+ */
+#ifndef TRC_HIP_H_
+#define TRC_HIP_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* coder ids (container `codec` byte).  Reference function each one reproduces per chunk: */
+enum trc_codec {
+    TRC_ANS4S = 1,  /* anscdf4senc / anscdf4sdec   static-CDF rANS, 2 states      anscdf.c:57-85   (-e65) */
+    TRC_RCS1  = 2,  /* rccdfsenc   / rccdfs*dec    static-CDF RC, 1 stream        rccdf.c:71-122   (-e42/43) */
+    TRC_RCS2  = 3,  /* rccdfs2enc  / rccdfs*2dec   static-CDF RC, 2 streams       rccdf.c:125-184  (-e45) */
+    TRC_RCA   = 4,  /* rccdfenc    / rccdfdec      adaptive-CDF byte RC           rccdf.c:187-211  (-e46) */
+    TRC_ANSA  = 5,  /* anscdfenc   / anscdfdec     adaptive-CDF byte rANS, 4 st.  anscdf.c:567-605 (-e56) */
+    TRC_RCB   = 6   /* rcsenc      / rcsdec        bitwise order-0 RC             rc_.c:37-58      (-e1)  */
+};
+
+#define TRC_MAGIC        0x31435254u   /* "TRC1" */
+#define TRC_CHUNK_MIN    256u
+#define TRC_CHUNK_MAX    65536u        /* chunk must be a multiple of 64 in [MIN, MAX] */
+#define TRC_CHUNK_DEFAULT 4096u
+#define TRC_PAD          256u          /* readable slack the device entry points need after every buffer */
+
+typedef struct trc_container_hdr {
+    uint32_t magic;      /* TRC_MAGIC */
+    uint8_t  codec;      /* enum trc_codec */
+    uint8_t  version;    /* 1 */
+    uint16_t cdfnum;     /* static coders: alphabet size the CDF was built for, else 0 */
+    uint32_t chunk;      /* chunk size in bytes */
+    uint32_t nchunks;    /* ceil(n / chunk) */
+    uint64_t n;          /* original length */
+    uint64_t payload;    /* total payload bytes (sum of clen[]) */
+} trc_container_hdr;     /* 32 bytes, little endian */
+
+/* error codes of the *_dev layer (0 = ok) */
+enum { TRC_OK = 0, TRC_E_ARG = -1, TRC_E_HIP = -2, TRC_E_WORK = -3, TRC_E_CDF = -4, TRC_E_NODEV = -5 };
+
+/* last error text of the calling thread's most recent failing call ("" if none) */
+const char *trc_last_error(void);
+
+/* number of visible HIP devices (0 if the runtime cannot initialise -- no CPU fallback exists) */
+int trc_device_count(void);
+
+/* process-wide chunk size used by the host-pointer (reference-signature) calls; also TRC_CHUNK env */
+int      trc_set_chunk(uint32_t chunk);
+uint32_t trc_get_chunk(void);
+
+/* ---- device-resident layer --------------------------------------------------------------------
+ * All d_* pointers are device pointers on the current HIP device, 16-byte aligned, with TRC_PAD
+ * readable/writable bytes of slack behind the stated size.  `stream` is a hipStream_t (NULL =
+ * default stream).  Calls only enqueue work; they never synchronise.                            */
+
+/* bytes of device workspace trc_encode_dev / trc_decode_dev need for (codec, n, chunk) */
+size_t trc_work_bytes(int codec, size_t n, uint32_t chunk);
+
+/* cdfini on device (reference: rccdf.c:50-68): byte histogram of d_in[0..n) -> 15-bit CDF
+ * d_cdf[0..cdfnum] (uint16).  d_status (int32, device) receives (int)n or -1 where the reference
+ * would die().  d_work: >= trc_work_bytes(0, 0, 0) bytes.                                        */
+int trc_cdfini_dev(const void *d_in, size_t n, uint16_t *d_cdf, unsigned cdfnum,
+                   int32_t *d_status, void *d_work, void *stream);
+
+/* Encode n bytes at d_in with `codec`.
+ *   d_cdf/cdfnum : static coders only (uint16[cdfnum+1], cdf[cdfnum] == 32768), else NULL/0
+ *   d_clen       : uint32[nchunks]  <- per-chunk compressed length (== chunk length: raw)
+ *   d_payload    : >= n bytes       <- concatenated payloads
+ *   d_total      : uint64           <- sum of clen[]
+ *   d_work       : trc_work_bytes() bytes of scratch                                             */
+int trc_encode_dev(int codec, const void *d_in, size_t n, uint32_t chunk,
+                   const uint16_t *d_cdf, unsigned cdfnum,
+                   uint32_t *d_clen, void *d_payload, uint64_t *d_total,
+                   void *d_work, size_t work_bytes, void *stream);
+
+/* Decode: inverse of trc_encode_dev; d_out receives n bytes. */
+int trc_decode_dev(int codec, const uint32_t *d_clen, const void *d_payload, size_t n, uint32_t chunk,
+                   const uint16_t *d_cdf, unsigned cdfnum,
+                   void *d_out, void *d_work, size_t work_bytes, void *stream);
+
+/* Optional per-launch timing of the dominant (coder) kernel with HIP events recorded on the caller's
+ * stream immediately around that kernel.  enable(1) resets the counters; read() waits for the
+ * recorded events and returns the summed duration and the number of launches measured
+ * (at most 1024 per direction between two enable() calls). */
+int trc_timing_enable(int on);
+int trc_timing_read(int decode, double *total_ms, int *launches);
+
+/* name of the dominant kernel the last encode/decode of `codec` launched (for rocprof lookups) */
+const char *trc_kernel_name(int codec, int decode);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

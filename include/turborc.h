@@ -1,0 +1,39 @@
+/*
+ * turborc.h -- drop-in prototypes for the range-coder side of the hot path, served by
+ * libturborc_hip.so (MI355X / gfx950).  Own text; the prototypes mirror the reference's
+ * include/turborc.h so that a TurboRC-style harness compiles and links unchanged:
+ *
+ *   cdf_t                          reference include/turborc.h:497
+ *   cdfini                         reference include/turborc.h:500   (rccdf.c:50-68)
+ *   rccdfsenc / rccdfs{b,l,vb,vl}dec   include/turborc.h:502-506     (rccdf.c:71-122)
+ *   rccdfs2enc / rccdfs{l,b}2dec   include/turborc.h:508-510         (rccdf.c:125-184)
+ *   rccdfenc / rccdfdec            include/turborc.h:513-514         (rccdf.c:187-211)
+ *   rcsenc / rcsdec                include/turborc.h:62-63           (rc_.c:37-58)
+ *
+ * Calling convention (reference include/turborc.h:46-59), unchanged:
+ *   encoders: `out` holds at least inlen bytes (+ the harness's usual slack); the return value is
+ *             the compressed length, or exactly inlen when the data is incompressible, in which
+ *             case out[0..inlen) is a copy of the input and the caller must memcpy instead of
+ *             calling the decoder;
+ *   decoders: return outlen.
+ * Stream format: the TRC1 chunk container of include/trc_hip.h -- every chunk's payload is
+ * bit-identical to what the reference function returns for that chunk alone.
+ * Errors (no HIP device, HIP failure, malformed container): message on stderr, trc_last_error(),
+ * return value 0 (cdfini: -1).  The library never calls exit() and has no CPU coding path.
+ */
+#ifndef TURBORC_H_
+#define TURBORC_H_
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef unsigned short cdf_t;
+
+int cdfini(unsigned char *in, size_t inlen, cdf_t *cdf, unsigned cdfnum);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

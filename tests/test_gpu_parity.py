@@ -1,0 +1,170 @@
+"""GPU (-m gpu): the HIP path through the C-ABI against the CPU oracle, bit-exact.
+
+  * device layer (trc_encode_dev / trc_decode_dev): per-chunk payloads and lengths == oracle,
+    decode round trip, ragged / tiny / incompressible inputs, several chunk sizes;
+  * golden vectors from the reference (single-chunk containers == reference whole-buffer output);
+  * host-pointer layer (reference prototypes): container parse, round trip, raw convention;
+  * BASELINE-size property tests (100 MB): round trip, directory consistency, sampled chunks
+    bit-exact against the oracle.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import trc
+import trc_testlib as T
+from golden.make_golden import gen
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU (and must not silently fall back)"
+    return torch
+
+
+def to_dev(torch, a):
+    return torch.from_numpy(np.concatenate([a, np.zeros(512, np.uint8)])).to("cuda:0")
+
+
+def device_roundtrip(torch, codec, d, chunk, cdf, cdfnum):
+    n = d.size
+    dc = trc.DeviceCoder(codec, n, chunk, "cuda:0")
+    if codec in trc.STATIC:
+        dc.set_cdf(cdf, cdfnum)
+    d_in = to_dev(torch, d)
+    dc.encode(d_in, n)
+    clen, payload = dc.result(n)
+    exp_payload, exp_clen, _ = T.orc_chunked_enc(codec, d, chunk, cdf, cdfnum)
+    assert np.array_equal(clen, exp_clen), "clen mismatch"
+    assert payload.size == exp_payload.size and np.array_equal(payload, exp_payload), "payload mismatch"
+    d_out = torch.full((n + 512,), 0xA5, dtype=torch.uint8, device="cuda:0")
+    dc.decode(d_out, n)
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy()
+    assert np.array_equal(out[:n], d), "decode mismatch"
+    assert (out[n:] == 0xA5).all(), "decoder wrote past the end"
+    return clen, payload
+
+
+@pytest.mark.parametrize("codec", trc.AVAILABLE, ids=lambda c: trc.CODEC_NAMES[c])
+@pytest.mark.parametrize("kind", ["zipf", "text", "runs", "uniform", "nibble", "binary", "const"])
+def test_device_layer_matches_oracle(torch_cuda, codec, kind):
+    for n, chunk in [(1, 256), (5, 256), (255, 256), (256, 256), (257, 256), (4096, 4096), (4097, 4096), (70001, 1024),
+                     (300007, 4096), (1 << 20, 65536), (999999, 2048)]:
+        d = gen(kind, n, 4000 + n)
+        _, cdf, cdfnum = T.orc_cdfini(d)
+        device_roundtrip(torch_cuda, codec, d, chunk, cdf, cdfnum)
+
+
+@pytest.mark.parametrize("codec", trc.AVAILABLE, ids=lambda c: trc.CODEC_NAMES[c])
+def test_mixed_raw_and_coded_chunks(torch_cuda, codec):
+    """incompressible slices inside compressible data: per-chunk raw fallback + raw copy at decode"""
+    parts = [gen("zipf", 8192, 1), gen("uniform", 4096, 2), gen("const", 4096, 3), gen("uniform", 8192, 4), gen("text", 5000, 5)]
+    d = np.concatenate(parts)
+    _, cdf, cdfnum = T.orc_cdfini(d)
+    clen, _ = device_roundtrip(torch_cuda, codec, d, 4096, cdf, cdfnum)
+    assert clen[2] == 4096 and clen[4] == 4096 and clen[5] == 4096      # the uniform slices are stored raw
+    assert clen[3] < 4096                                             # the constant slice is coded
+
+
+@pytest.mark.parametrize("codec", trc.AVAILABLE, ids=lambda c: trc.CODEC_NAMES[c])
+def test_golden_vectors_single_chunk(torch_cuda, codec):
+    """n <= 65536 with chunk >= n: the one payload must equal the reference's whole-buffer output"""
+    z = np.load(os.path.join(GOLD, "vectors.npz"))
+    index = json.loads(bytes(z["index"]).decode())
+    name = trc.CODEC_NAMES[codec]
+    done = 0
+    for ent in index:
+        if name not in ent["out"] or ent["n"] > 65536:
+            continue
+        d = z["in_%d" % ent["case"]]
+        n = ent["n"]
+        chunk = min(65536, max(256, (n + 63) // 64 * 64))
+        cdf = np.zeros(257, dtype=np.uint16); cdf[:ent["cdfnum"] + 1] = z["cdf_%d" % ent["case"]]
+        dc = trc.DeviceCoder(codec, n, chunk, "cuda:0")
+        if codec in trc.STATIC:
+            dc.set_cdf(cdf, ent["cdfnum"])
+        dc.encode(to_dev(torch_cuda, d), n)
+        clen, payload = dc.result(n)
+        assert clen.size == 1 and int(clen[0]) == ent["out"][name], (ent["kind"], n)
+        exp = d if ent["out"][name] == n else z["out_%d_%s" % (ent["case"], name)]
+        assert np.array_equal(payload, exp), (ent["kind"], n)
+        done += 1
+    assert done > 100
+
+
+def test_cdfini_on_device(torch_cuda):
+    for kind, n in [("zipf", 1), ("zipf", 1000), ("text", 123457), ("nibble", 4096), ("uniform", 1 << 20), ("const", 777), ("runs", 3000001)]:
+        d = gen(kind, n, 77)
+        r0, cdf0, cdfnum = T.orc_cdfini(d)
+        r1, cdf1, _ = trc.host_cdfini(d, cdfnum)
+        assert r0 == r1 and np.array_equal(cdf0, cdf1), (kind, n)
+    # a distribution the reference cannot normalise (flat + sparse): reference die()s, we return -1
+    d = np.concatenate([np.arange(256, dtype=np.uint8)] * 3 + [np.zeros(5, np.uint8)])
+    r0, _, _ = T.orc_cdfini(d, 256)
+    r1, _, _ = trc.host_cdfini(d, 256)
+    assert r0 == r1
+
+
+@pytest.mark.parametrize("codec", trc.AVAILABLE, ids=lambda c: trc.CODEC_NAMES[c])
+def test_host_pointer_layer(torch_cuda, codec):
+    """the reference-named functions: container layout, per-chunk parity, round trip, raw rule"""
+    chunk = 1024
+    assert trc.lib().trc_set_chunk(chunk) == 0
+    try:
+        for kind, n in [("zipf", 100000), ("text", 70001), ("runs", 4096)]:
+            d = gen(kind, n, 31)
+            _, cdf, cdfnum = T.orc_cdfini(d)
+            comp = trc.host_encode(codec, d, cdf, cdfnum)
+            assert comp.size < n
+            hdr, clen, payload = trc.parse_container(comp)
+            assert hdr["magic"] == 0x31435254 and hdr["codec"] == codec and hdr["chunk"] == chunk and hdr["n"] == n
+            exp_payload, exp_clen, _ = T.orc_chunked_enc(codec, d, chunk, cdf, cdfnum)
+            assert np.array_equal(clen, exp_clen) and np.array_equal(payload, exp_payload)
+            assert comp.size == 32 + 4 * clen.size + payload.size
+            assert np.array_equal(trc.host_decode(codec, comp, n, cdf, cdfnum), d)
+        d = gen("uniform", 100000, 9)                      # incompressible: returns n, out == in
+        _, cdf, cdfnum = T.orc_cdfini(d)
+        comp = trc.host_encode(codec, d, cdf, cdfnum)
+        assert comp.size == d.size and np.array_equal(comp, d)
+        d = gen("zipf", 40, 9)                             # tiny: container overhead >= n -> raw
+        _, cdf, cdfnum = T.orc_cdfini(d)
+        assert trc.host_encode(codec, d, cdf, cdfnum).size == 40
+    finally:
+        trc.lib().trc_set_chunk(4096)
+
+
+@pytest.mark.parametrize("codec", trc.AVAILABLE, ids=lambda c: trc.CODEC_NAMES[c])
+def test_baseline_size_properties(torch_cuda, codec):
+    """100 MB (BASELINE.json configs): round trip on device, directory consistency, sampled chunks == oracle"""
+    torch = torch_cuda
+    n, chunk = 100 * 1000 * 1000, 4096
+    kind = "runs" if codec in (trc.RCA, trc.ANSA) else "text"
+    d = gen(kind, n, 7)
+    _, cdf, cdfnum = T.orc_cdfini(d)
+    dc = trc.DeviceCoder(codec, n, chunk, "cuda:0")
+    if codec in trc.STATIC:
+        dc.set_cdf(cdf, cdfnum)
+    d_in = to_dev(torch, d)
+    dc.encode(d_in, n)
+    d_out = torch.zeros(n + 512, dtype=torch.uint8, device="cuda:0")
+    dc.decode(d_out, n)
+    torch.cuda.synchronize()
+    assert torch.equal(d_out[:n], d_in[:n]), "100 MB round trip failed"
+    nch = trc.nchunks(n, chunk)
+    clen = dc.clen[:nch].cpu().numpy().view(np.uint32).astype(np.int64)
+    total = int(dc.total[0].item())
+    assert clen.sum() == total and total < n
+    off = np.concatenate([[0], np.cumsum(clen)])
+    rng = np.random.default_rng(5)
+    payload = dc.payload[:total].cpu().numpy()
+    for c in list(rng.integers(0, nch, 48)) + [0, nch - 1]:
+        sl = d[c * chunk:(c + 1) * chunk]
+        exp = T.orc_enc(codec, sl, cdf, cdfnum)
+        assert clen[c] == exp.size and np.array_equal(payload[off[c]:off[c + 1]], exp), "chunk %d" % c

@@ -1,0 +1,240 @@
+// trc_ans_static.hip -- static-CDF rANS, 2 interleaved states per chunk (codec TRC_ANS4S).
+//
+// Per chunk the emitted bytes are exactly what anscdf4senc (reference anscdf.c:57-73, core
+// anscdf_.h:46-48,90-94,101-103) returns for that slice:
+//     [u32 state1][u32 state0][u16 renorm words in decode order]          (raw copy if >= len)
+// The encoder walks its chunk BACKWARDS (n%4 tail bytes on state 0, then b3->s1 b2->s0 b1->s1
+// b0->s0 per 4-byte group) and its words grow DOWNWARD from the end of the chunk's private scratch
+// region; the decoder reads forward.  One lane = one chunk, 64 chunks per wave, so a wave64
+// carries 128 reference rANS states; the serial dependency is broken across chunks, never
+// inside one (that would change the bitstream).
+//
+// MI355X mapping: symbol tables in LDS (encoder: 256 x 16 B {reciprocal, 2^15-f | shift<<24,
+// f<<16, c0}; decoder: 32 KiB slot->symbol LUT + 256 x 8 B {f, -c0}); all HBM traffic in 64-byte
+// quad segments through the LDS tiles/rings of trc_io.h.  No MFMA: integer work, bounded by VALU
+// issue (4 cycles per wave64 op) and LDS, not by HBM (DESIGN.md has the arithmetic).
+#include "trc_io.h"
+#include "trc_launch.h"
+
+// ------------------------------------------------------------------------------------- encode ---
+// one rANS step (ece, anscdf_.h:90-94): renorm-emit, then st = (st/f)<<15 + st%f + c0.
+//   e = { m, (2^15-f) | sh<<24, f<<16, c0' }:  q = umulhi(st, m) >> sh == st / f  for st < 2^31
+//   (f == 1 uses m = 2^32-1, sh = 0, c0' = c0 + 2^15-1: umulhi gives st-1, see trc_dir.hip)
+__device__ __forceinline__ void ans_put(u32 &st, const uint4 e, StreamOut<true> &so)
+{
+    const bool emit = st >= e.z;                              // st >= f<<16
+    so.put16_if(emit, st);
+    st = emit ? st >> 16 : st;
+    const u32 q = __umulhi(st, e.x) >> (e.y >> 24);
+    st = st + e.w + __umul24(q, e.y);                         // mul24 ignores the shift byte
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void trc_ans4s_enc_kernel(
+    const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks,
+    const uint4 *__restrict__ etab_g, u8 *__restrict__ scratch, u32 stride,
+    u32 *__restrict__ clen, u32 *__restrict__ gsum)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    uint4 *etab = (uint4 *)smem;                                                     // 4096 B
+    const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    u8 *wbase = smem + 4096 + wv * (TRC_TILE_BYTES + TRC_SRING_BYTES + TRC_SEL_BYTES);
+    for (u32 i = tid; i < 256; i += BLOCK) etab[i] = etab_g[i];
+    __syncthreads();
+
+    WaveChunks wc;
+    wc.c0 = (blockIdx.x * (BLOCK / 64) + wv) * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
+    wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
+    if (wc.c0 >= nchunks) return;
+    wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
+
+    const bool alive = lane < wc.rows;
+    const u32 c = wc.c0 + lane;
+    const u32 len = alive ? wc.len_of(lane) : 0u;
+    TileIn tin; tin.tile = wbase; tin.base = in + (u64)wc.c0 * chunk;
+    StreamOut<true> so;
+    so.rings = wbase + TRC_TILE_BYTES; so.sel = wbase + TRC_TILE_BYTES + TRC_SRING_BYTES;
+    so.scratch = scratch; so.stride = stride; so.c0 = wc.c0; so.wpos = 0; so.nfl = 0;
+
+    const u32 S = chunk / TRC_SEG;
+    const u32 top = alive ? (len - 1u) / TRC_SEG : 0u;          // segment holding the chunk's last byte
+    const u32 toplen = len - TRC_SEG * top;                     // bytes of the chunk in that segment
+    u32 st0 = TRC_ANS_LOW, st1 = TRC_ANS_LOW;
+    bool ovf = false;
+
+    tin.issue(wc, (S - 1u) * TRC_SEG);
+    for (u32 s = S - 1u;; s--) {
+        tin.commit();
+        if (s) tin.issue(wc, (s - 1u) * TRC_SEG);               // next (lower) segment in flight during this one
+        bool act = alive && s <= top && !ovf;
+        const bool ragged = act && s == top && toplen != TRC_SEG;
+        if (ragged) {                                           // last chunk only: byte by byte
+            const u8 *row = tin.tile + lane * TRC_TILE_STRIDE;
+            const u32 body = len & ~3u;
+            for (u32 pos = len; pos > TRC_SEG * top;) {
+                pos--;
+                const uint4 e = etab[row[pos & 63u]];
+                if (pos >= body || !(pos & 1u)) ans_put(st0, e, so); else ans_put(st1, e, so);
+            }
+            act = false;
+        }
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+            if (act) {
+                const uint4 v = tin.read((u32)k);
+                const u32 w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+                for (int d = 3; d >= 0; d--) {
+                    // table entries depend only on the input bytes: fetch all four before the chains
+                    const uint4 e3 = etab[w[d] >> 24], e2 = etab[(w[d] >> 16) & 255u], e1 = etab[(w[d] >> 8) & 255u], e0 = etab[w[d] & 255u];
+                    ans_put(st1, e3, so); ans_put(st0, e2, so);
+                    ans_put(st1, e1, so); ans_put(st0, e0, so);
+                }
+            }
+            so.drain(false, alive);                             // <= 32 new bytes per lane since the last drain
+            ovf = ovf || (alive && so.wpos + 8u >= len);        // already incompressible: stop coding this chunk
+            act = act && !ovf;
+        }
+        if (s == 0) break;
+    }
+    u32 out_len = 0;
+    if (alive) {
+        if (!ovf) {
+            // ansflush: state0 then state1 as u32 below the words (hi half first going down)
+            so.put16(st0 >> 16); so.put16(st0); so.put16(st1 >> 16); so.put16(st1);
+            ovf = so.wpos >= len;
+        }
+        out_len = ovf ? len : so.wpos;
+    }
+    so.drain(true, alive && !ovf);
+    if (alive) clen[c] = out_len;
+    const u32 gs = trc_wave_sum(out_len);
+    if (lane == 0) gsum[wc.c0 >> 6] = gs;
+}
+
+// ------------------------------------------------------------------------------------- decode ---
+// cdf16sansdec + ecdnorm (cdf_.h:99-107, anscdf_.h:51-73) for a byte alphabet:
+// x = lut[slot]; st = f*(st>>15) + slot - c0; if (st < 2^15) st = st<<16 | next word
+__device__ __forceinline__ u32 ans_get(u32 &st, const u8 *lut, const uint2 *dtab, StreamIn &si)
+{
+    const u32 slot = st & (TRC_PROB_ONE - 1);
+    const u32 x = lut[slot];
+    const uint2 e = dtab[x];                                  // { f, -c0 }
+    st = __umul24(e.x, st >> TRC_PROB_BITS) + e.y + slot;
+    const u32 w = si.peek16();
+    const bool rn = st < TRC_ANS_LOW;
+    st = rn ? (st << 16) | w : st;
+    si.rpos += rn ? 2u : 0u;
+    return x;
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void trc_ans4s_dec_kernel(
+    const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff,
+    u64 n, u32 chunk, u32 nchunks,
+    const u8 *__restrict__ lut_g, const u32 *__restrict__ dtab_g, u8 *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    u8 *lut = smem;                                   // 32768
+    uint2 *dtab = (uint2 *)(smem + 32768);            // 256 x 8
+    const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    u8 *wbase = smem + 32768 + 2048 + wv * (TRC_TILE_BYTES + TRC_SRING_BYTES + TRC_SEL_BYTES);
+    for (u32 i = tid; i < 2048; i += BLOCK) ((uint4 *)lut)[i] = ((const uint4 *)lut_g)[i];
+    for (u32 i = tid; i < 256; i += BLOCK) { const u32 d = dtab_g[i]; dtab[i] = make_uint2(d >> 16, 0u - (d & 0xffffu)); }
+    __syncthreads();
+
+    WaveChunks wc;
+    wc.c0 = (blockIdx.x * (BLOCK / 64) + wv) * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
+    wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
+    if (wc.c0 >= nchunks) return;
+    wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
+
+    const bool alive = lane < wc.rows;
+    const u32 c = wc.c0 + lane;
+    const u32 len = alive ? wc.len_of(lane) : 0u;
+    const u32 cl = alive ? clen[c] : 0u;
+    const u32 ex = trc_wave_incl_scan(cl) - cl;
+    const u64 off = goff[wc.c0 >> 6] + ex;
+    const bool coded = alive && cl != len;
+
+    TileOut tout; tout.tile = wbase; tout.base = out + (u64)wc.c0 * chunk;
+    StreamIn si;
+    si.rings = wbase + TRC_TILE_BYTES; si.sel = wbase + TRC_TILE_BYTES + TRC_SRING_BYTES;
+    si.gbase = payload; si.soff = off + 8;                    // words follow the two states
+    u32 sa = 0, sb = 0;
+    if (coded) { sa = trc_ld32_a2(payload + off); sb = trc_ld32_a2(payload + off + 4); }   // sa = enc state 1, sb = enc state 0
+    si.prime(coded);
+
+    const u32 S = chunk / TRC_SEG;
+    const u32 body4 = len & ~3u;
+    u8 *dst = out + (u64)c * chunk;
+    for (u32 s = 0; s < S; s++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 p0 = s * TRC_SEG + (u32)k * 16u;          // chunk offset of this 16-byte piece
+            // period boundary: land the round requested 16 symbols ago, request the next one
+            si.commit();
+            if (__ballot(coded && si.avail() < 34u)) si.refill(coded, 1u << 30, true);      // (never on sane data)
+            si.refill(coded && p0 < len, TRC_SEG, false);
+            if (coded && p0 + 16u <= len) {
+                u32 w[4];
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const u32 x0 = ans_get(sb, lut, dtab, si), x1 = ans_get(sa, lut, dtab, si);
+                    const u32 x2 = ans_get(sb, lut, dtab, si), x3 = ans_get(sa, lut, dtab, si);
+                    w[d] = x0 | (x1 << 8) | (x2 << 16) | (x3 << 24);
+                }
+                tout.put((u32)k, make_uint4(w[0], w[1], w[2], w[3]));
+            } else if (coded && p0 < len) {                    // last chunk's final partial piece
+                for (u32 pos = p0; pos < len; pos++)
+                    dst[pos] = (u8)((pos >= body4 || !(pos & 1u)) ? ans_get(sb, lut, dtab, si) : ans_get(sa, lut, dtab, si));
+            }
+        }
+        tout.flush(wc, s * TRC_SEG);
+    }
+    // chunks stored raw (clen == len): the whole wave copies them, one after the other
+    u64 rawmask = __ballot(alive && cl == len && len != 0);
+    while (rawmask) {
+        const int k = __ffsll((long long)rawmask) - 1;
+        rawmask &= rawmask - 1;
+        const u32 olo = (u32)__shfl((int)(u32)off, k, 64), ohi = (u32)__shfl((int)(u32)(off >> 32), k, 64);
+        const u32 l = (u32)__shfl((int)len, k, 64);
+        trc_wave_copy(out + (u64)(wc.c0 + (u32)k) * chunk, payload + (((u64)ohi << 32) | olo), l);
+    }
+}
+
+// ------------------------------------------------------------------------------------- launch ---
+#define ENC_WAVE_LDS (TRC_TILE_BYTES + TRC_SRING_BYTES + TRC_SEL_BYTES)
+
+void trc_launch_ans4s_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w,
+                          uint32_t *d_clen, hipStream_t s)
+{
+    const uint4 *etab = (const uint4 *)(w.tables + TRC_TAB_ENC);
+    const u32 nwaves = w.ngroups;
+    const size_t sm = 4096 + ENC_WAVE_LDS;                      // one wave per workgroup: 17.4 KiB -> 9 waves/CU
+    hipLaunchKernelGGL(trc_ans4s_enc_kernel<64>, dim3(nwaves), dim3(64), sm, s,
+                       d_in, (u64)n, chunk, w.nchunks, etab, w.scratch, w.stride, d_clen, w.gsum);
+}
+
+void trc_launch_ans4s_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
+                          const TrcWork &w, uint8_t *d_out, hipStream_t s)
+{
+    const u8 *lut = w.tables + TRC_TAB_LUT;
+    const u32 *dtab = (const u32 *)(w.tables + TRC_TAB_DEC);
+    const u32 nwaves = w.ngroups;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)trc_ans4s_dec_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  32768 + 2048 + 8 * ENC_WAVE_LDS);
+        attr_set = true;
+    }
+    if (nwaves > 768) {          // plenty of waves: 8 per workgroup share one 32 KiB LUT (1 workgroup = 1 CU)
+        const size_t sm = 32768 + 2048 + 8 * ENC_WAVE_LDS;
+        hipLaunchKernelGGL(trc_ans4s_dec_kernel<512>, dim3((nwaves + 7) / 8), dim3(512), sm, s,
+                           d_payload, d_clen, w.goff, (u64)n, chunk, w.nchunks, lut, dtab, d_out);
+    } else {                     // few waves: one per workgroup so they spread over all CUs
+        const size_t sm = 32768 + 2048 + ENC_WAVE_LDS;
+        hipLaunchKernelGGL(trc_ans4s_dec_kernel<64>, dim3(nwaves), dim3(64), sm, s,
+                           d_payload, d_clen, w.goff, (u64)n, chunk, w.nchunks, lut, dtab, d_out);
+    }
+}

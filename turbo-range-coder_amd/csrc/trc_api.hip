@@ -1,0 +1,361 @@
+// trc_api.hip -- the C-ABI of libturborc_hip.so (include/trc_hip.h, include/anscdf.h, include/turborc.h).
+//
+// Layer 2 (*_dev): enqueue-only, caller-owned device buffers and stream.
+// Layer 1 (reference prototypes): host pointers; stage through a process-wide device context,
+// run layer 2, wrap the result in the TRC1 container.  There is NO CPU coding path in this
+// library: if HIP is unavailable every call fails loudly (stderr + trc_last_error, return 0).
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/trc_hip.h"
+#include "trc_launch.h"
+
+typedef unsigned short cdf_t;
+static const unsigned TRC_PROB_ONE_HOST = 32768u;
+
+// ------------------------------------------------------------------------------------ errors ---
+static thread_local char g_err[512];
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    fprintf(stderr, "turborc_hip: ERROR: %s\n", g_err);
+    return code;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(TRC_E_HIP, "%s -> %s", #x, hipGetErrorString(e_)); } while (0)
+
+extern "C" const char *trc_last_error(void) { return g_err; }
+
+extern "C" int trc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ------------------------------------------------------------------------------------ config ---
+static uint32_t g_chunk = 0;
+static bool chunk_ok(uint32_t c) { return c >= TRC_CHUNK_MIN && c <= TRC_CHUNK_MAX && (c % 64u) == 0; }
+extern "C" uint32_t trc_get_chunk(void)
+{
+    if (!g_chunk) {
+        const char *e = getenv("TRC_CHUNK");
+        uint32_t c = e ? (uint32_t)strtoul(e, 0, 10) : 0;
+        g_chunk = chunk_ok(c) ? c : TRC_CHUNK_DEFAULT;
+    }
+    return g_chunk;
+}
+extern "C" int trc_set_chunk(uint32_t chunk)
+{
+    if (!chunk_ok(chunk)) return fail(TRC_E_ARG, "chunk %u: must be a multiple of 64 in [%u,%u]", chunk, TRC_CHUNK_MIN, TRC_CHUNK_MAX);
+    g_chunk = chunk;
+    return TRC_OK;
+}
+
+// ------------------------------------------------------------------------------ workspace map ---
+static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+static inline bool is_static(int codec) { return codec == TRC_ANS4S || codec == TRC_RCS1 || codec == TRC_RCS2; }
+static inline bool codec_ok(int codec) { return codec == TRC_ANS4S; }
+
+static uint32_t scratch_stride(int codec, uint32_t chunk)
+{
+    (void)codec;
+    return chunk + 128;                // payload + one period of look-ahead, moved in whole 64-B segments (trc_io.h)
+}
+
+extern "C" size_t trc_work_bytes(int codec, size_t n, uint32_t chunk)
+{
+    if (codec == 0) return 4096;       // cdfini: histogram bins
+    if (!chunk_ok(chunk)) return 0;
+    const size_t nchunks = (n + chunk - 1) / chunk, ngroups = (nchunks + 63) / 64;
+    return up256(TRC_TAB_BYTES) + up256(4 * ngroups) + up256(8 * (ngroups + 1)) +
+           up256(nchunks * (size_t)scratch_stride(codec, chunk)) + 4096;
+}
+
+static int carve(int codec, size_t n, uint32_t chunk, void *d_work, size_t work_bytes, TrcWork &w)
+{
+    const size_t need = trc_work_bytes(codec, n, chunk);
+    if (!need || work_bytes < need) return fail(TRC_E_WORK, "workspace %zu B < required %zu B", work_bytes, need);
+    if (((uintptr_t)d_work) & 255) return fail(TRC_E_ARG, "workspace must be 256-byte aligned");
+    const size_t nchunks = (n + chunk - 1) / chunk, ngroups = (nchunks + 63) / 64;
+    uint8_t *p = (uint8_t *)d_work;
+    w.tables = p;               p += up256(TRC_TAB_BYTES);
+    w.gsum = (uint32_t *)p;     p += up256(4 * ngroups);
+    w.goff = (uint64_t *)p;     p += up256(8 * (ngroups + 1));
+    w.scratch = p;
+    w.stride = scratch_stride(codec, chunk);
+    w.nchunks = (uint32_t)nchunks; w.ngroups = (uint32_t)ngroups;
+    return TRC_OK;
+}
+
+static int check_common(int codec, size_t n, uint32_t chunk, const uint16_t *d_cdf, unsigned cdfnum)
+{
+    if (!codec_ok(codec)) return fail(TRC_E_ARG, "codec %d not available", codec);
+    if (!chunk_ok(chunk)) return fail(TRC_E_ARG, "chunk %u: must be a multiple of 64 in [%u,%u]", chunk, TRC_CHUNK_MIN, TRC_CHUNK_MAX);
+    if ((n + chunk - 1) / chunk > 0x7fffffffu) return fail(TRC_E_ARG, "too many chunks");
+    if (is_static(codec) && (!d_cdf || cdfnum < 1 || cdfnum > 256)) return fail(TRC_E_CDF, "static coder needs a CDF with 1..256 symbols");
+    return TRC_OK;
+}
+
+// ------------------------------------------------------------------ coder-kernel timing (opt-in) ---
+#define TRC_TM_MAX 1024
+static struct { bool on; int cnt[2]; hipEvent_t ev[2][TRC_TM_MAX][2]; bool made[2][TRC_TM_MAX]; } g_tm;
+extern "C" int trc_timing_enable(int on)
+{
+    g_tm.on = on != 0; g_tm.cnt[0] = g_tm.cnt[1] = 0;
+    return TRC_OK;
+}
+static inline int tm_begin(int dec, hipStream_t s)
+{
+    if (!g_tm.on || g_tm.cnt[dec] >= TRC_TM_MAX) return -1;
+    const int i = g_tm.cnt[dec];
+    if (!g_tm.made[dec][i]) {
+        if (hipEventCreate(&g_tm.ev[dec][i][0]) != hipSuccess || hipEventCreate(&g_tm.ev[dec][i][1]) != hipSuccess) return -1;
+        g_tm.made[dec][i] = true;
+    }
+    (void)hipEventRecord(g_tm.ev[dec][i][0], s);
+    return i;
+}
+static inline void tm_end(int dec, int i, hipStream_t s)
+{
+    if (i < 0) return;
+    (void)hipEventRecord(g_tm.ev[dec][i][1], s);
+    g_tm.cnt[dec] = i + 1;
+}
+extern "C" int trc_timing_read(int decode, double *total_ms, int *launches)
+{
+    const int d = decode ? 1 : 0;
+    double sum = 0;
+    for (int i = 0; i < g_tm.cnt[d]; i++) {
+        float ms = 0;
+        HIPCHK(hipEventSynchronize(g_tm.ev[d][i][1]));
+        HIPCHK(hipEventElapsedTime(&ms, g_tm.ev[d][i][0], g_tm.ev[d][i][1]));
+        sum += ms;
+    }
+    if (total_ms) *total_ms = sum;
+    if (launches) *launches = g_tm.cnt[d];
+    return TRC_OK;
+}
+
+// ------------------------------------------------------------------------------ layer 2: *_dev ---
+extern "C" int trc_cdfini_dev(const void *d_in, size_t n, uint16_t *d_cdf, unsigned cdfnum,
+                              int32_t *d_status, void *d_work, void *stream)
+{
+    if (!n || cdfnum < 1 || cdfnum > 256) return fail(TRC_E_ARG, "cdfini: n=%zu cdfnum=%u", n, cdfnum);
+    trc_launch_cdfini((const uint8_t *)d_in, n, d_cdf, cdfnum, d_status, (uint64_t *)d_work, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return TRC_OK;
+}
+
+extern "C" int trc_encode_dev(int codec, const void *d_in, size_t n, uint32_t chunk,
+                              const uint16_t *d_cdf, unsigned cdfnum,
+                              uint32_t *d_clen, void *d_payload, uint64_t *d_total,
+                              void *d_work, size_t work_bytes, void *stream)
+{
+    int rc = check_common(codec, n, chunk, d_cdf, cdfnum);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) { HIPCHK(hipMemsetAsync(d_total, 0, 8, s)); return TRC_OK; }
+    TrcWork w;
+    if ((rc = carve(codec, n, chunk, d_work, work_bytes, w))) return rc;
+    if (is_static(codec)) trc_launch_static_prep(d_cdf, cdfnum, w.tables, s);
+    int from_end = 0;
+    const int tmi = tm_begin(0, s);
+    switch (codec) {
+    case TRC_ANS4S: trc_launch_ans4s_enc((const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 1; break;
+    }
+    tm_end(0, tmi, s);
+    trc_launch_scan_groups(w.gsum, w.ngroups, w.goff, d_total, s);
+    trc_launch_gather((const uint8_t *)d_in, n, chunk, w, from_end, d_clen, (uint8_t *)d_payload, s);
+    HIPCHK(hipGetLastError());
+    return TRC_OK;
+}
+
+extern "C" int trc_decode_dev(int codec, const uint32_t *d_clen, const void *d_payload, size_t n, uint32_t chunk,
+                              const uint16_t *d_cdf, unsigned cdfnum,
+                              void *d_out, void *d_work, size_t work_bytes, void *stream)
+{
+    int rc = check_common(codec, n, chunk, d_cdf, cdfnum);
+    if (rc) return rc;
+    if (n == 0) return TRC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    TrcWork w;
+    if ((rc = carve(codec, n, chunk, d_work, work_bytes, w))) return rc;
+    if (is_static(codec)) trc_launch_static_prep(d_cdf, cdfnum, w.tables, s);
+    trc_launch_group_sums(d_clen, w.nchunks, w.gsum, s);
+    trc_launch_scan_groups(w.gsum, w.ngroups, w.goff, nullptr, s);
+    const int tmi = tm_begin(1, s);
+    switch (codec) {
+    case TRC_ANS4S: trc_launch_ans4s_dec((const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
+    }
+    tm_end(1, tmi, s);
+    HIPCHK(hipGetLastError());
+    return TRC_OK;
+}
+
+extern "C" const char *trc_kernel_name(int codec, int decode)
+{
+    switch (codec) {
+    case TRC_ANS4S: return decode ? "trc_ans4s_dec_kernel" : "trc_ans4s_enc_kernel";
+    }
+    return "";
+}
+
+// --------------------------------------------------- layer 1: reference prototypes (host pointers) ---
+namespace {
+struct HostCtx {
+    std::mutex mu;
+    bool init = false;
+    hipStream_t stream = nullptr;
+    uint8_t *d_in = nullptr;   size_t cap_in = 0;      // plain bytes (encode input / decode output)
+    uint8_t *d_cont = nullptr; size_t cap_cont = 0;    // container: hdr | clen[] | payload
+    uint8_t *d_work = nullptr; size_t cap_work = 0;
+    uint8_t *d_small = nullptr;                        // cdf (1 KiB) | total (8) | status (4)
+};
+HostCtx g_ctx;
+
+int ctx_init(HostCtx &c)
+{
+    if (c.init) return TRC_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(TRC_E_NODEV, "no HIP device: libturborc_hip has no CPU coding path");
+    HIPCHK(hipStreamCreate(&c.stream));
+    HIPCHK(hipMalloc((void **)&c.d_small, 4096));
+    c.init = true;
+    return TRC_OK;
+}
+int grow(uint8_t **p, size_t *cap, size_t need)
+{
+    need = up256(need + TRC_PAD);
+    if (*cap >= need) return TRC_OK;
+    if (*p) HIPCHK(hipFree(*p));
+    *p = nullptr; *cap = 0;
+    size_t want = need + need / 8;
+    HIPCHK(hipMalloc((void **)p, want));
+    *cap = want;
+    return TRC_OK;
+}
+// cdfnum = index of the terminating 1<<15 (cdf is strictly increasing from 0)
+int host_cdfnum(const cdf_t *cdf)
+{
+    if (!cdf || cdf[0] != 0) return -1;
+    for (int i = 1; i <= 256; i++) {
+        if (cdf[i] == TRC_PROB_ONE_HOST) return i;
+        if (cdf[i] <= cdf[i - 1] || cdf[i] > TRC_PROB_ONE_HOST) return -1;
+    }
+    return -1;
+}
+}  // namespace
+
+// ---- host-pointer encode/decode shared by every reference-signature export --------------------
+static size_t host_encode(int codec, const unsigned char *in, size_t inlen, unsigned char *out,
+                          const cdf_t *cdf, int cdfnum)
+{
+    HostCtx &c = g_ctx;
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (inlen == 0) return 0;
+    if (ctx_init(c)) return 0;
+    const uint32_t chunk = trc_get_chunk();
+    const size_t nchunks = (inlen + chunk - 1) / chunk, dir = 4 * nchunks, hdrsz = sizeof(trc_container_hdr);
+    if (is_static(codec)) {
+        if (cdfnum <= 0) cdfnum = host_cdfnum(cdf);
+        if (cdfnum <= 0 || cdfnum > 256) { fail(TRC_E_CDF, "bad CDF (need cdf[0]=0 < ... < cdf[cdfnum]=32768)"); return 0; }
+    } else cdfnum = 0;
+    const size_t wb = trc_work_bytes(codec, inlen, chunk);
+    if (grow(&c.d_in, &c.cap_in, inlen) || grow(&c.d_cont, &c.cap_cont, hdrsz + dir + inlen + 64) || grow(&c.d_work, &c.cap_work, wb)) return 0;
+    uint16_t *d_cdf = (uint16_t *)c.d_small;
+    uint64_t *d_total = (uint64_t *)(c.d_small + 2048);
+#define HCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fail(TRC_E_HIP, "%s -> %s", #x, hipGetErrorString(e_)); return 0; } } while (0)
+    HCHK(hipMemcpyAsync(c.d_in, in, inlen, hipMemcpyHostToDevice, c.stream));
+    if (cdfnum) HCHK(hipMemcpyAsync(d_cdf, cdf, (cdfnum + 1) * sizeof(cdf_t), hipMemcpyHostToDevice, c.stream));
+    uint32_t *d_clen = (uint32_t *)(c.d_cont + hdrsz);
+    uint8_t *d_payload = c.d_cont + hdrsz + dir;
+    if (trc_encode_dev(codec, c.d_in, inlen, chunk, cdfnum ? d_cdf : nullptr, (unsigned)cdfnum, d_clen, d_payload, d_total,
+                       c.d_work, c.cap_work, c.stream)) return 0;
+    uint64_t total = 0;
+    HCHK(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, c.stream));
+    HCHK(hipStreamSynchronize(c.stream));
+    const size_t clen_total = hdrsz + dir + (size_t)total;
+    if (clen_total >= inlen) { memcpy(out, in, inlen); return inlen; }      // reference convention: == inlen => raw
+    trc_container_hdr h;
+    memset(&h, 0, sizeof h);
+    h.magic = TRC_MAGIC; h.codec = (uint8_t)codec; h.version = 1; h.cdfnum = (uint16_t)cdfnum;
+    h.chunk = chunk; h.nchunks = (uint32_t)nchunks; h.n = inlen; h.payload = total;
+    memcpy(out, &h, hdrsz);
+    HCHK(hipMemcpyAsync(out + hdrsz, c.d_cont + hdrsz, dir + (size_t)total, hipMemcpyDeviceToHost, c.stream));
+    HCHK(hipStreamSynchronize(c.stream));
+    return clen_total;
+}
+
+static size_t host_decode(int codec, const unsigned char *in, size_t outlen, unsigned char *out,
+                          const cdf_t *cdf, int cdfnum)
+{
+    HostCtx &c = g_ctx;
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (outlen == 0) return 0;
+    if (ctx_init(c)) return 0;
+    trc_container_hdr h;
+    memcpy(&h, in, sizeof h);
+    if (h.magic != TRC_MAGIC || h.version != 1 || h.codec != codec || h.n != outlen ||
+        !chunk_ok(h.chunk) || h.nchunks != (outlen + h.chunk - 1) / h.chunk || h.payload > outlen) {
+        fail(TRC_E_ARG, "not a TRC1 container for codec %d / length %zu (raw streams must be memcpy'd by the caller)", codec, outlen);
+        return 0;
+    }
+    const size_t hdrsz = sizeof h, dir = 4 * (size_t)h.nchunks;
+    if (is_static(codec)) {
+        if (cdfnum <= 0) cdfnum = host_cdfnum(cdf);
+        if (cdfnum <= 0 || cdfnum > 256) { fail(TRC_E_CDF, "bad CDF"); return 0; }
+    } else cdfnum = 0;
+    const size_t wb = trc_work_bytes(codec, outlen, h.chunk);
+    if (grow(&c.d_in, &c.cap_in, outlen) || grow(&c.d_cont, &c.cap_cont, hdrsz + dir + outlen + 64) || grow(&c.d_work, &c.cap_work, wb)) return 0;
+    uint16_t *d_cdf = (uint16_t *)c.d_small;
+    HCHK(hipMemcpyAsync(c.d_cont + hdrsz, in + hdrsz, dir + (size_t)h.payload, hipMemcpyHostToDevice, c.stream));
+    if (cdfnum) HCHK(hipMemcpyAsync(d_cdf, cdf, (cdfnum + 1) * sizeof(cdf_t), hipMemcpyHostToDevice, c.stream));
+    if (trc_decode_dev(codec, (const uint32_t *)(c.d_cont + hdrsz), c.d_cont + hdrsz + dir, outlen, h.chunk,
+                       cdfnum ? d_cdf : nullptr, (unsigned)cdfnum, c.d_in, c.d_work, c.cap_work, c.stream)) return 0;
+    HCHK(hipMemcpyAsync(out, c.d_in, outlen, hipMemcpyDeviceToHost, c.stream));
+    HCHK(hipStreamSynchronize(c.stream));
+    return outlen;
+}
+
+// ---- exports with the reference's names (include/turborc.h:500, include/anscdf.h:40-96) ----------
+extern "C" {
+
+// cdfini: reference rccdf.c:50-68.  Returns (int)inlen; -1 where the reference would die().
+int cdfini(unsigned char *in, size_t inlen, cdf_t *cdf, unsigned cdfnum)
+{
+    HostCtx &c = g_ctx;
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (!inlen || cdfnum < 1 || cdfnum > 256) { fail(TRC_E_ARG, "cdfini: inlen=%zu cdfnum=%u", inlen, cdfnum); return -1; }
+    if (ctx_init(c)) return -1;
+    if (grow(&c.d_in, &c.cap_in, inlen) || grow(&c.d_work, &c.cap_work, 4096)) return -1;
+    uint16_t *d_cdf = (uint16_t *)c.d_small;
+    int32_t *d_status = (int32_t *)(c.d_small + 2056);
+#define ICHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fail(TRC_E_HIP, "%s -> %s", #x, hipGetErrorString(e_)); return -1; } } while (0)
+    ICHK(hipMemcpyAsync(c.d_in, in, inlen, hipMemcpyHostToDevice, c.stream));
+    if (trc_cdfini_dev(c.d_in, inlen, d_cdf, cdfnum, d_status, c.d_work, c.stream)) return -1;
+    int32_t st = -1;
+    ICHK(hipMemcpyAsync(&st, d_status, 4, hipMemcpyDeviceToHost, c.stream));
+    ICHK(hipMemcpyAsync(cdf, d_cdf, (cdfnum + 1) * sizeof(cdf_t), hipMemcpyDeviceToHost, c.stream));
+    ICHK(hipStreamSynchronize(c.stream));
+    if (st < 0) { fail(TRC_E_CDF, "cdfini: distribution cannot be normalised to a strictly increasing 15-bit CDF"); return -1; }
+    return (int)inlen;
+}
+
+void anscdfini(unsigned id) { (void)id; }   // reference: CPU ISA dispatch (anscdf.c:759-808); nothing to select here
+
+#define TRC_EXPORT_ANS4S(sfx) \
+    size_t anscdf4senc##sfx(unsigned char *in, size_t inlen, unsigned char *out, cdf_t *cdf) { return host_encode(TRC_ANS4S, in, inlen, out, cdf, 0); } \
+    size_t anscdf4sdec##sfx(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf) { return host_decode(TRC_ANS4S, in, outlen, out, cdf, 0); }
+TRC_EXPORT_ANS4S()
+TRC_EXPORT_ANS4S(0)
+TRC_EXPORT_ANS4S(s)
+TRC_EXPORT_ANS4S(x)
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+// trc_dev.h -- device-side building blocks shared by the gfx950 kernels (wave64 only).
+//
+// Layout conventions (DESIGN.md "Data layout in HBM"):
+//   * one LANE codes one CHUNK (64 chunks per wave); the coder state lives in VGPRs;
+//   * symbol/probability tables live in LDS, staged once per workgroup from a tiny global table
+//     that a prep kernel derived from the caller's CDF;
+//   * variable-rate coder output goes through a per-lane LDS ring (64 B, stride 68 B so that lanes
+//     at the same ring position hit 32 distinct banks) and leaves the CU as whole 16-byte stores.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint8_t  u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#define TRC_WAVE        64
+#define TRC_RING        64u          // bytes of LDS ring per lane (4 x 16 B blocks)
+#define TRC_RING_STRIDE 68u          // bytes between the rings of adjacent lanes (17 dwords: conflict-free)
+#define TRC_PROB_BITS   15u
+#define TRC_PROB_ONE    (1u << TRC_PROB_BITS)
+#define TRC_ANS_LOW     (1u << 15)   // rANS state lower bound (anscdf_.h:41)
+
+// ---- unaligned global access (payloads are only 2-byte aligned inside the container) -------------
+typedef u32 u32_a1 __attribute__((aligned(1)));
+typedef u32 u32_a2 __attribute__((aligned(2)));
+struct __attribute__((packed, aligned(2))) trc_u128_a2 { u32 x, y, z, w; };
+
+__device__ __forceinline__ uint4 trc_ld16_a2(const u8 *p)
+{
+    trc_u128_a2 v = *(const trc_u128_a2 *)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ u32 trc_ld32_a2(const u8 *p) { return *(const u32_a2 *)p; }
+
+// ---- wave64 helpers -----------------------------------------------------------------------------
+__device__ __forceinline__ u32 trc_lane() { return threadIdx.x & 63u; }
+
+// inclusive prefix sum over the 64 lanes of a wave (all lanes must call)
+__device__ __forceinline__ u32 trc_wave_incl_scan(u32 v)
+{
+    const u32 lane = trc_lane();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 t = __shfl_up(v, d, 64);
+        if (lane >= (u32)d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ u32 trc_wave_sum(u32 v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// ---- cooperative byte copy by one wave (dst/src arbitrary alignment) ------------------------------
+// dst-aligned 16-byte stores in the middle, byte granularity at both ends.
+__device__ __forceinline__ void trc_wave_copy(u8 *dst, const u8 *src, u32 len)
+{
+    const u32 lane = trc_lane();
+    if (((uintptr_t)src | (uintptr_t)dst) & 1u) {              // never on the product path (offsets are even)
+        for (u32 i = lane; i < len; i += 64) dst[i] = src[i];
+        return;
+    }
+    u32 head = (u32)((16u - ((uintptr_t)dst & 15u)) & 15u);
+    if (head > len) head = len;
+    if (lane < head) dst[lane] = src[lane];
+    const u32 nvec = (len - head) >> 4;
+    u8 *d = dst + head; const u8 *s = src + head;
+    for (u32 i = lane; i < nvec; i += 64)
+        *(uint4 *)(d + (size_t)i * 16) = trc_ld16_a2(s + (size_t)i * 16);
+    const u32 done = head + (nvec << 4);
+    if (lane < len - done) dst[done + lane] = src[done + lane];
+}

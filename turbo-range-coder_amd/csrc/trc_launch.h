@@ -1,0 +1,43 @@
+// trc_launch.h -- host-side launch entry points of the kernel translation units (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+// Workspace carve-up shared by encode and decode (all offsets 256-byte aligned).
+struct TrcWork {
+    uint8_t  *tables;    // per-call coder tables derived from the CDF (static coders)
+    uint32_t *gsum;      // per-group (64 chunks) payload bytes
+    uint64_t *goff;      // exclusive prefix of gsum, ngroups+1 entries
+    uint8_t  *scratch;   // encode only: per-chunk private output regions
+    uint32_t  stride;    // bytes per scratch region
+    uint32_t  nchunks, ngroups;
+};
+
+// table area layout (bytes from TrcWork::tables)
+#define TRC_TAB_ENC   0          // uint4[256]   encoder symbol table
+#define TRC_TAB_DEC   4096       // u32[256]     decoder symbol table
+#define TRC_TAB_LUT   8192       // u8[32768]    slot -> symbol
+#define TRC_TAB_CDF   40960      // u16[260]     sanitised CDF copy
+#define TRC_TAB_BYTES 45056
+
+// static-table prep (ANS4S / RCS1 / RCS2)
+void trc_launch_static_prep(const uint16_t *d_cdf, unsigned cdfnum, uint8_t *tables, hipStream_t s);
+
+// directory scan + payload gather
+void trc_launch_group_sums(const uint32_t *d_clen, uint32_t nchunks, uint32_t *gsum, hipStream_t s);
+void trc_launch_scan_groups(const uint32_t *gsum, uint32_t ngroups, uint64_t *goff, uint64_t *d_total, hipStream_t s);
+// part1 of every chunk sits either at the START (from_end=0) or at the END (from_end=1) of its
+// scratch region; raw chunks (clen == chunk length) are copied from the input instead.
+void trc_launch_gather(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, int from_end,
+                       const uint32_t *d_clen, uint8_t *d_payload, hipStream_t s);
+
+// ANS4S: static-CDF rANS (anscdf4senc / anscdf4sdec)
+void trc_launch_ans4s_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w,
+                          uint32_t *d_clen, hipStream_t s);
+void trc_launch_ans4s_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
+                          const TrcWork &w, uint8_t *d_out, hipStream_t s);
+
+// cdfini on device
+void trc_launch_cdfini(const uint8_t *d_in, size_t n, uint16_t *d_cdf, unsigned cdfnum,
+                       int32_t *d_status, uint64_t *d_hist /*256 u64*/, hipStream_t s);
