@@ -33,6 +33,20 @@ typedef unsigned short cdf_t;
 
 int cdfini(unsigned char *in, size_t inlen, cdf_t *cdf, unsigned cdfnum);
 
+/* static-CDF range coder, one stream (reference rccdf.c:71-122).  The four reference decoders differ
+ * only in how they search the CDF (linear / binary / division+linear / division+binary) and decode
+ * the same stream; all four names are served by the same kernel. */
+size_t rccdfsenc(unsigned char *in, size_t inlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum);
+size_t rccdfsldec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum);
+size_t rccdfsbdec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum);
+size_t rccdfsvldec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum);
+size_t rccdfsvbdec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum);
+
+/* static-CDF range coder, two interleaved streams (reference rccdf.c:125-184; `turborc -e45`) */
+size_t rccdfs2enc(unsigned char *in, size_t inlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum);
+size_t rccdfsl2dec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum);
+size_t rccdfsb2dec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,7 +60,8 @@ extern "C" int trc_set_chunk(uint32_t chunk)
 // ------------------------------------------------------------------------------ workspace map ---
 static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline bool is_static(int codec) { return codec == TRC_ANS4S || codec == TRC_RCS1 || codec == TRC_RCS2; }
-static inline bool codec_ok(int codec) { return codec == TRC_ANS4S; }
+static inline bool codec_ok(int codec) { return codec == TRC_ANS4S || codec == TRC_RCS1 || codec == TRC_RCS2; }
+static inline int nregions(int codec) { return codec == TRC_RCS2 ? 2 : 1; }
 
 static uint32_t scratch_stride(int codec, uint32_t chunk)
 {
@@ -74,7 +75,7 @@ extern "C" size_t trc_work_bytes(int codec, size_t n, uint32_t chunk)
     if (!chunk_ok(chunk)) return 0;
     const size_t nchunks = (n + chunk - 1) / chunk, ngroups = (nchunks + 63) / 64;
     return up256(TRC_TAB_BYTES) + up256(4 * ngroups) + up256(8 * (ngroups + 1)) +
-           up256(nchunks * (size_t)scratch_stride(codec, chunk)) + 4096;
+           nregions(codec) * up256(nchunks * (size_t)scratch_stride(codec, chunk)) + 4096;
 }
 
 static int carve(int codec, size_t n, uint32_t chunk, void *d_work, size_t work_bytes, TrcWork &w)
@@ -88,7 +89,8 @@ static int carve(int codec, size_t n, uint32_t chunk, void *d_work, size_t work_
     w.gsum = (uint32_t *)p;     p += up256(4 * ngroups);
     w.goff = (uint64_t *)p;     p += up256(8 * (ngroups + 1));
     w.scratch = p;
-    w.stride = scratch_stride(codec, chunk);
+    w.stride = w.stride2 = scratch_stride(codec, chunk);
+    w.scratch2 = p + up256(nchunks * (size_t)w.stride);
     w.nchunks = (uint32_t)nchunks; w.ngroups = (uint32_t)ngroups;
     return TRC_OK;
 }
@@ -168,6 +170,8 @@ extern "C" int trc_encode_dev(int codec, const void *d_in, size_t n, uint32_t ch
     const int tmi = tm_begin(0, s);
     switch (codec) {
     case TRC_ANS4S: trc_launch_ans4s_enc((const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 1; break;
+    case TRC_RCS1:  trc_launch_rcs_enc(1, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 0; break;
+    case TRC_RCS2:  trc_launch_rcs_enc(2, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 2; break;
     }
     tm_end(0, tmi, s);
     trc_launch_scan_groups(w.gsum, w.ngroups, w.goff, d_total, s);
@@ -192,6 +196,8 @@ extern "C" int trc_decode_dev(int codec, const uint32_t *d_clen, const void *d_p
     const int tmi = tm_begin(1, s);
     switch (codec) {
     case TRC_ANS4S: trc_launch_ans4s_dec((const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
+    case TRC_RCS1:  trc_launch_rcs_dec(1, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
+    case TRC_RCS2:  trc_launch_rcs_dec(2, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     }
     tm_end(1, tmi, s);
     HIPCHK(hipGetLastError());
@@ -202,6 +208,7 @@ extern "C" const char *trc_kernel_name(int codec, int decode)
 {
     switch (codec) {
     case TRC_ANS4S: return decode ? "trc_ans4s_dec_kernel" : "trc_ans4s_enc_kernel";
+    case TRC_RCS1: case TRC_RCS2: return decode ? "trc_rcs_dec_kernel" : "trc_rcs_enc_kernel";
     }
     return "";
 }
@@ -357,5 +364,16 @@ TRC_EXPORT_ANS4S()
 TRC_EXPORT_ANS4S(0)
 TRC_EXPORT_ANS4S(s)
 TRC_EXPORT_ANS4S(x)
+
+// static-CDF range coder: rccdfsenc + the four equivalent decoders, rccdfs2enc + its two decoders
+size_t rccdfsenc(unsigned char *in, size_t inlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum) { return host_encode(TRC_RCS1, in, inlen, out, cdf, (int)cdfnum); }
+#define TRC_EXPORT_RCS1DEC(name) size_t name(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum) { return host_decode(TRC_RCS1, in, outlen, out, cdf, (int)cdfnum); }
+TRC_EXPORT_RCS1DEC(rccdfsldec)
+TRC_EXPORT_RCS1DEC(rccdfsbdec)
+TRC_EXPORT_RCS1DEC(rccdfsvldec)
+TRC_EXPORT_RCS1DEC(rccdfsvbdec)
+size_t rccdfs2enc(unsigned char *in, size_t inlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum) { return host_encode(TRC_RCS2, in, inlen, out, cdf, (int)cdfnum); }
+size_t rccdfsl2dec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum) { return host_decode(TRC_RCS2, in, outlen, out, cdf, (int)cdfnum); }
+size_t rccdfsb2dec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum) { return host_decode(TRC_RCS2, in, outlen, out, cdf, (int)cdfnum); }
 
 }  // extern "C"

@@ -93,6 +93,7 @@ void trc_launch_scan_groups(const uint32_t *gsum, uint32_t ngroups, uint64_t *go
 // Gather: one workgroup (4 waves) per group of 64 chunks; wave w moves chunks w, w+4, ...
 __global__ __launch_bounds__(256) void trc_gather_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks,
                                                          const u8 *__restrict__ scratch, u32 stride, int from_end,
+                                                         const u8 *__restrict__ scratch2, u32 stride2,
                                                          const u32 *__restrict__ clen, const u64 *__restrict__ goff,
                                                          u8 *__restrict__ payload)
 {
@@ -107,17 +108,21 @@ __global__ __launch_bounds__(256) void trc_gather_kernel(const u8 *__restrict__ 
         const u32 l = __shfl(l_l, k, 64), ex = __shfl(ex_l, k, 64);
         const u64 cstart = (u64)c * chunk;
         const u32 len = (u32)((n - cstart) < chunk ? (n - cstart) : chunk);
-        const u8 *src;
-        if (l == len) src = in + cstart;
-        else src = from_end ? scratch + (u64)(c + 1) * stride - l : scratch + (u64)c * stride;
-        trc_wave_copy(payload + base + ex, src, l);
+        if (l == len) trc_wave_copy(payload + base + ex, in + cstart, l);
+        else if (from_end == 2) {
+            const u8 *a = scratch + (u64)c * stride;
+            const u32 la = 4u + *(const u32 *)a;
+            trc_wave_copy(payload + base + ex, a, la);
+            trc_wave_copy(payload + base + ex + la, scratch2 + (u64)c * stride2, l - la);
+        } else
+            trc_wave_copy(payload + base + ex, from_end ? scratch + (u64)(c + 1) * stride - l : scratch + (u64)c * stride, l);
     }
 }
 void trc_launch_gather(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, int from_end,
                        const uint32_t *d_clen, uint8_t *d_payload, hipStream_t s)
 {
     hipLaunchKernelGGL(trc_gather_kernel, dim3(w.ngroups), dim3(256), 0, s, d_in, (u64)n, chunk, w.nchunks,
-                       w.scratch, w.stride, from_end, d_clen, w.goff, d_payload);
+                       w.scratch, w.stride, from_end, w.scratch2, w.stride2, d_clen, w.goff, d_payload);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -108,13 +108,31 @@ struct StreamOut {
     // only advance when `take` (no exec-mask branch in the symbol loop)
     __device__ __forceinline__ void put16_if(bool take, u32 v)
     {
+#ifndef TRC_ABL_NOWRITE
         *(u16 *)(myring() + roff16(wpos)) = (u16)v;
+#endif
         wpos += take ? 2u : 0u;
     }
     __device__ __forceinline__ void put16(u32 v) { *(u16 *)(myring() + roff16(wpos)) = (u16)v; wpos += 2; }
     __device__ __forceinline__ void put32(u32 v) { *(u32 *)(myring() + roff32(wpos)) = v; wpos += 4; }
 
     __device__ __forceinline__ u32 pending() const { return wpos - TRC_SEG * nfl; }
+    // one lane moving its own oldest segment to the region (bursts only: runs of 0xFFFFFFFF words
+    // released by a range-coder carry can exceed what a period may append)
+    __device__ __forceinline__ void self_drain()
+    {
+        const u32 ro = DOWN ? ((0u - TRC_SEG * (nfl + 1u)) & (TRC_SRING - 1)) : ((TRC_SEG * nfl) & (TRC_SRING - 1));
+        const u32 *s = (const u32 *)(myring() + ro);
+        u8 *reg = scratch + (size_t)(c0 + trc_lane()) * stride;
+        u8 *d = DOWN ? reg + stride - (size_t)TRC_SEG * (nfl + 1u) : reg + (size_t)TRC_SEG * nfl;
+        for (int i = 0; i < 4; i++) ((uint4 *)d)[i] = make_uint4(s[4 * i], s[4 * i + 1], s[4 * i + 2], s[4 * i + 3]);
+        nfl++;
+    }
+    __device__ __forceinline__ void put32_slow(u32 v)
+    {
+        if (pending() + 4u > TRC_SRING - 4u && (size_t)TRC_SEG * (nfl + 2u) <= stride) self_drain();
+        put32(v);
+    }
 
     // Move finished segments to HBM.  Called by the whole wave at uniform points.
     // final = false: lanes holding >= 64 pending bytes;  final = true: every lane with pending bytes

@@ -11,6 +11,8 @@ struct TrcWork {
     uint64_t *goff;      // exclusive prefix of gsum, ngroups+1 entries
     uint8_t  *scratch;   // encode only: per-chunk private output regions
     uint32_t  stride;    // bytes per scratch region
+    uint8_t  *scratch2;  // second region array (RCS2: stream 1)
+    uint32_t  stride2;
     uint32_t  nchunks, ngroups;
 };
 
@@ -27,8 +29,9 @@ void trc_launch_static_prep(const uint16_t *d_cdf, unsigned cdfnum, uint8_t *tab
 // directory scan + payload gather
 void trc_launch_group_sums(const uint32_t *d_clen, uint32_t nchunks, uint32_t *gsum, hipStream_t s);
 void trc_launch_scan_groups(const uint32_t *gsum, uint32_t ngroups, uint64_t *goff, uint64_t *d_total, hipStream_t s);
-// part1 of every chunk sits either at the START (from_end=0) or at the END (from_end=1) of its
-// scratch region; raw chunks (clen == chunk length) are copied from the input instead.
+// mode 0: payload at the START of the chunk's scratch region; mode 1: at the END of it;
+// mode 2: [4 + len0 bytes at the start of region A][rest at the start of region B] (RCS2), len0 = u32 at region A.
+// Raw chunks (clen == chunk length) are copied from the input instead.
 void trc_launch_gather(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, int from_end,
                        const uint32_t *d_clen, uint8_t *d_payload, hipStream_t s);
 
@@ -37,6 +40,12 @@ void trc_launch_ans4s_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const T
                           uint32_t *d_clen, hipStream_t s);
 void trc_launch_ans4s_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                           const TrcWork &w, uint8_t *d_out, hipStream_t s);
+
+// RCS1 / RCS2: static-CDF range coder, 1 or 2 streams (rccdfsenc / rccdfs2enc and their decoders)
+void trc_launch_rcs_enc(int nstreams, const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w,
+                        uint32_t *d_clen, hipStream_t s);
+void trc_launch_rcs_dec(int nstreams, const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
+                        const TrcWork &w, uint8_t *d_out, hipStream_t s);
 
 // cdfini on device
 void trc_launch_cdfini(const uint8_t *d_in, size_t n, uint16_t *d_cdf, unsigned cdfnum,

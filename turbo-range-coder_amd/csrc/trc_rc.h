@@ -1,0 +1,131 @@
+// trc_rc.h -- device-side 64-bit range coder core shared by the RC kernels (RCS1/RCS2/RCA/RCB).
+//
+// Arithmetic = reference turborc_.h with RC_SIZE=64, RC_IO=32, RC_BITS=15 (rccdf.c:36-37,
+// rc_s.c:31-33): _rccdfenc_ :215, _rcenorm_ :105-109, _rccarry_ :103, rceflush :118-128,
+// rcdinit :152-158, _rccdfupdate_ :219-223, _rcdnorm_ :111, rcbe_ :417-421, rcbd_ :447-452.
+//
+// Carry handling.  The reference writes every 32-bit word at once and, when `low` wraps, walks
+// BACK through the words already written adding 1 (ripple).  Here output is append-only (words go
+// through an LDS ring and leave as coalesced segments, trc_io.h), so the encoder holds back the
+// last word (`cache`) and a count of 0xFFFFFFFF words behind it (`npend`): a carry turns
+// cache, FF.. into cache+1, 00..; a word is released only once no later carry can reach it.  A word
+// receives at most one carry in its lifetime (the value still to be added is always smaller than
+// the range at the time the word was emitted), so the released stream is word-for-word what the
+// reference's ripple produces.  `nwords` counts words the way the reference's pointer does
+// (held-back words included): the incompressibility test (OVERFLOW, rcutil_.h:130) uses it.
+#pragma once
+#include "trc_io.h"
+
+#define TRC_TOP32 ((u64)1 << 32)
+
+// signed limit of OVERFLOW: op - out >= inlen*255/256 - 8   (rcutil_.h:130)
+__device__ __forceinline__ int trc_rc_limit(u32 len) { return (int)((len * 255u) >> 8) - 8; }
+
+struct RcEnc {
+    u64 range, low, mark;
+    u32 cache, npend, nwords;
+    bool have;
+
+    __device__ __forceinline__ void start() { range = ~(u64)0; low = mark = 0; cache = 0; npend = 0; nwords = 0; have = false; }
+
+    // logical append of word W with carry flag cy (cy refers to the words BEFORE W)
+    template <class SO>
+    __device__ __forceinline__ void emit(SO &so, bool cy, u32 W)
+    {
+        nwords++;
+        if (have && !cy && npend == 0 && W != 0xffffffffu) {           // the common case
+            so.put32(cache); cache = W;
+            return;
+        }
+        if (cy) {                                                       // cache+1, then zeros: all final
+            so.put32(cache + 1u);
+            for (; npend; npend--) so.put32_slow(0u);
+            have = false;
+        }
+        if (!have) { cache = W; have = true; }
+        else if (W == 0xffffffffu) npend++;
+        else {
+            so.put32(cache);
+            for (; npend; npend--) so.put32_slow(0xffffffffu);
+            cache = W;
+        }
+    }
+    template <class SO>
+    __device__ __forceinline__ void renorm(SO &so)                      // single `if`: RC_IO = 32
+    {
+        if (range < TRC_TOP32) {
+            emit(so, mark > low, (u32)(low >> 32));
+            low <<= 32; range <<= 32; mark = low;
+        }
+    }
+    template <class SO>
+    __device__ __forceinline__ void sym(SO &so, u32 c0, u32 f)          // _rccdfenc_ + renorm
+    {
+        range >>= TRC_PROB_BITS;
+        low += range * c0;
+        range *= f;
+        renorm(so);
+    }
+    template <class SO>
+    __device__ __forceinline__ void bit(SO &so, u32 p, u32 b)           // rcbe_: p = P(bit==1) * 2^15
+    {
+        const u64 cut = (range >> TRC_PROB_BITS) * p;
+        if (b) range = cut; else { low += cut; range -= cut; }
+        (void)so;
+    }
+    // rceflush, then release everything still held back
+    template <class SO>
+    __device__ __forceinline__ void finish(SO &so)
+    {
+        renorm(so);
+        if (range > ((u64)1 << 33)) {
+            low += TRC_TOP32;
+            emit(so, mark > low, (u32)(low >> 32));
+        } else {
+            low += 1;
+            emit(so, mark > low, (u32)(low >> 32));
+            emit(so, false, (u32)low);
+        }
+        if (have) {
+            so.put32(cache);
+            for (; npend; npend--) so.put32_slow(0xffffffffu);
+            have = false;
+        }
+    }
+};
+
+struct RcDec {
+    u64 range, code;
+    __device__ __forceinline__ void start(u32 w0, u32 w1) { range = ~(u64)0; code = ((u64)w0 << 32) | w1; }
+    __device__ __forceinline__ void renorm(StreamIn &si)
+    {
+        const bool rn = range < TRC_TOP32;
+        const u32 w = si.peek32();
+        if (rn) { range <<= 32; code = (code << 32) | w; }
+        si.rpos += rn ? 4u : 0u;
+    }
+    // t = code / range exactly, for code < range * 2^15, 2^17 <= range < 2^49: f32 estimate of the
+    // quotient from the top 24 bits, then exact 64-bit correction.  Selects the same symbol as the
+    // reference's linear/binary/division searches (they all find x with cdf[x]*r <= code < cdf[x+1]*r).
+    __device__ __forceinline__ u32 quotient() const
+    {
+        const int bl = 64 - __clzll((long long)range);                   // bit length of range (18..49)
+        const int sh = bl > 24 ? bl - 24 : 0;                            // range >> sh is exact in f32
+        const float rf = (float)(u32)(range >> sh);
+        const u64 cs = code >> sh;                                       // < 2^39
+        const float cf = (float)(u32)(cs >> 16) * 65536.0f + (float)(u32)(cs & 0xffffu);
+        u32 t = (u32)(cf * __builtin_amdgcn_rcpf(rf));
+        if (t > TRC_PROB_ONE - 1) t = TRC_PROB_ONE - 1;
+        u64 p = range * t;
+        while (p > code) { t--; p -= range; }
+        while (code - p >= range && t < TRC_PROB_ONE - 1) { t++; p += range; }   // (bounded: corrupt input must not hang)
+        return t;
+    }
+    __device__ __forceinline__ void consume(StreamIn &si, u32 c0, u32 c1)   // _rccdfupdate + renorm
+    {
+        const u64 rp = range * c0;
+        range = range * c1 - rp;
+        code -= rp;
+        renorm(si);
+    }
+};

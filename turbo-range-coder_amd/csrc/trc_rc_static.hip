@@ -1,0 +1,238 @@
+// trc_rc_static.hip -- static-CDF range coder: one stream (TRC_RCS1) and two interleaved streams
+// (TRC_RCS2, what `turborc -e45` runs).
+//
+// Per chunk the payload is exactly what the reference returns for that slice:
+//   RCS1  rccdfsenc  (rccdf.c:71-81)   : [u32 words of one 64-bit range coder]
+//   RCS2  rccdfs2enc (rccdf.c:125-143) : [u32 len0][stream 0: even-index bytes (+ odd tail byte)][stream 1: odd-index bytes]
+// including the raw fallbacks (OVERFLOW rcutil_.h:130, OVERFLOWI rccdf.c:46).  All reference
+// decoders of a stream (linear/binary/division search, rccdf.c:84-122,146-184) select the same
+// symbols; here the symbol comes from code/range (exact, trc_rc.h) through the slot->symbol LUT.
+//
+// One lane = one chunk (RCS2: both of its coders).  Both overflow tests are monotone in the number
+// of words written, so evaluating them at 16-symbol periods and once after the last symbol decides
+// exactly like the reference's per-symbol test; the early exit only bounds the scratch writes.
+#include "trc_rc.h"
+#include "trc_launch.h"
+
+#define RCS_WAVE_LDS(NS) (TRC_TILE_BYTES + (NS) * TRC_SRING_BYTES + TRC_SEL_BYTES)
+
+template <int NS>
+__global__ __launch_bounds__(64) void trc_rcs_enc_kernel(
+    const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks, const u32 *__restrict__ tab_g,
+    u8 *__restrict__ scrA, u32 strideA, u8 *__restrict__ scrB, u32 strideB,
+    u32 *__restrict__ clen, u32 *__restrict__ gsum)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    u32 *tab = (u32 *)smem;                                    // 256 x {f<<16 | c0}
+    const u32 lane = threadIdx.x;
+    u8 *wbase = smem + 1024;
+    for (u32 i = lane; i < 256; i += 64) tab[i] = tab_g[i];
+    __syncthreads();
+
+    WaveChunks wc;
+    wc.c0 = blockIdx.x * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
+    wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
+    wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
+    const bool alive = lane < wc.rows;
+    const u32 c = wc.c0 + lane;
+    const u32 len = alive ? wc.len_of(lane) : 0u;
+    const int lim = trc_rc_limit(len);
+
+    TileIn tin; tin.tile = wbase; tin.base = in + (u64)wc.c0 * chunk;
+    StreamOut<false> so0, so1;
+    so0.rings = wbase + TRC_TILE_BYTES; so0.sel = wbase + TRC_TILE_BYTES + NS * TRC_SRING_BYTES;
+    so0.scratch = scrA; so0.stride = strideA; so0.c0 = wc.c0; so0.wpos = (NS == 2) ? 4u : 0u; so0.nfl = 0;
+    so1 = so0;
+    if (NS == 2) { so1.rings = so0.rings + TRC_SRING_BYTES; so1.scratch = scrB; so1.stride = strideB; so1.wpos = 0; }
+    RcEnc e0, e1; e0.start(); e1.start();
+    const u32 off1 = (NS == 2 && len >= 4u) ? 4u + ((len - 4u) * 37u) / 64u : 0u;   // stream-1 base inside `out` (rccdf.c:126)
+    bool ovf = alive && (NS == 2 ? len < 10u : lim <= 0);       // tiny inputs: always raw
+    const u32 pairs = len & ~1u;
+
+    const u32 S = chunk / TRC_SEG;
+    tin.issue(wc, 0);
+    for (u32 s = 0; s < S; s++) {
+        tin.commit();
+        if (s + 1 < S) tin.issue(wc, (s + 1) * TRC_SEG);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 p0 = s * TRC_SEG + (u32)k * 16u;
+            const bool act = alive && !ovf && p0 < len;
+            if (act && p0 + 16u <= len) {
+                const uint4 v = tin.read((u32)k);
+                const u32 w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const u32 t0 = tab[w[d] & 255u], t1 = tab[(w[d] >> 8) & 255u], t2 = tab[(w[d] >> 16) & 255u], t3 = tab[w[d] >> 24];
+                    if (NS == 1) {
+                        e0.sym(so0, t0 & 0xffffu, t0 >> 16); e0.sym(so0, t1 & 0xffffu, t1 >> 16);
+                        e0.sym(so0, t2 & 0xffffu, t2 >> 16); e0.sym(so0, t3 & 0xffffu, t3 >> 16);
+                    } else {
+                        e0.sym(so0, t0 & 0xffffu, t0 >> 16); e1.sym(so1, t1 & 0xffffu, t1 >> 16);
+                        e0.sym(so0, t2 & 0xffffu, t2 >> 16); e1.sym(so1, t3 & 0xffffu, t3 >> 16);
+                    }
+                }
+            } else if (act) {                                   // last chunk's final partial piece
+                const u8 *row = tin.tile + lane * TRC_TILE_STRIDE;
+                for (u32 pos = p0; pos < len; pos++) {
+                    const u32 t = tab[row[pos & 63u]];
+                    if (NS == 2 && pos < pairs && (pos & 1u)) {
+                        e1.sym(so1, t & 0xffffu, t >> 16);          // pair complete: OVERFLOWI (never after the odd tail byte)
+                        ovf = ovf || ((int)(off1 + 4u * e1.nwords) >= lim) || (4u + 4u * e0.nwords >= off1);
+                    } else e0.sym(so0, t & 0xffffu, t >> 16);
+                }
+            }
+            so0.drain(false, alive);
+            if (NS == 2) so1.drain(false, alive);
+            // monotone overflow tests (position = last byte coded so far is < pairs for every full piece)
+            if (NS == 1) ovf = ovf || (alive && (int)(4u * e0.nwords) >= lim);
+            else if (act && p0 + 16u <= len) ovf = ovf || ((int)(off1 + 4u * e1.nwords) >= lim) || (4u + 4u * e0.nwords >= off1);
+        }
+    }
+    u32 out_len = 0;
+    if (alive) {
+        if (!ovf) {
+            e0.finish(so0);
+            if (NS == 2) {
+                e1.finish(so1);
+                out_len = so0.wpos + so1.wpos;                  // 4 + len0 + len1
+                if ((int)out_len >= lim) ovf = true;
+            } else out_len = so0.wpos;
+        }
+        if (ovf) out_len = len;
+    }
+    so0.drain(true, alive && !ovf);
+    if (NS == 2) {
+        so1.drain(true, alive && !ovf);
+        if (alive && !ovf) *(u32 *)(scrA + (u64)c * strideA) = so0.wpos - 4u;   // header: len0 (the segment holding it is already in place)
+    }
+    if (alive) clen[c] = out_len;
+    const u32 gs = trc_wave_sum(out_len);
+    if (lane == 0) gsum[wc.c0 >> 6] = gs;
+}
+
+template <int NS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void trc_rcs_dec_kernel(
+    const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff,
+    u64 n, u32 chunk, u32 nchunks, const u8 *__restrict__ lut_g, const u32 *__restrict__ tab_g, u8 *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    u8 *lut = smem;                                            // 32768
+    u32 *tab = (u32 *)(smem + 32768);                          // 256 x {f<<16 | c0}
+    const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    u8 *wbase = smem + 32768 + 1024 + wv * RCS_WAVE_LDS(NS);
+    for (u32 i = tid; i < 2048; i += BLOCK) ((uint4 *)lut)[i] = ((const uint4 *)lut_g)[i];
+    for (u32 i = tid; i < 256; i += BLOCK) tab[i] = tab_g[i];
+    __syncthreads();
+
+    WaveChunks wc;
+    wc.c0 = (blockIdx.x * (BLOCK / 64) + wv) * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
+    wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
+    if (wc.c0 >= nchunks) return;
+    wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
+    const bool alive = lane < wc.rows;
+    const u32 c = wc.c0 + lane;
+    const u32 len = alive ? wc.len_of(lane) : 0u;
+    const u32 cl = alive ? clen[c] : 0u;
+    const u32 ex = trc_wave_incl_scan(cl) - cl;
+    const u64 off = goff[wc.c0 >> 6] + ex;
+    const bool coded = alive && cl != len;
+
+    TileOut tout; tout.tile = wbase; tout.base = out + (u64)wc.c0 * chunk;
+    StreamIn s0, s1;
+    s0.rings = wbase + TRC_TILE_BYTES; s0.sel = wbase + TRC_TILE_BYTES + NS * TRC_SRING_BYTES;
+    s0.gbase = payload; s0.soff = off + (NS == 2 ? 4u : 0u);
+    s1 = s0;
+    if (NS == 2) {
+        s1.rings = s0.rings + TRC_SRING_BYTES;
+        s1.soff = off + 4u + (coded ? trc_ld32_a2(payload + off) : 0u);
+    }
+    s0.prime(coded);
+    if (NS == 2) s1.prime(coded);
+    RcDec d0, d1;
+    { const u32 a = s0.peek32(); s0.rpos += 4; const u32 b = s0.peek32(); s0.rpos += 4; d0.start(a, b); }
+    if (NS == 2) { const u32 a = s1.peek32(); s1.rpos += 4; const u32 b = s1.peek32(); s1.rpos += 4; d1.start(a, b); }
+    else d1 = d0;
+
+    auto get = [&](RcDec &d, StreamIn &si) -> u32 {
+        d.range >>= TRC_PROB_BITS;
+        const u32 x = lut[d.quotient()];
+        const u32 t = tab[x];
+        d.consume(si, t & 0xffffu, (t & 0xffffu) + (t >> 16));
+        return x;
+    };
+
+    const u32 S = chunk / TRC_SEG;
+    const u32 pairs = len & ~1u;
+    u8 *dst = out + (u64)c * chunk;
+    for (u32 s = 0; s < S; s++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 p0 = s * TRC_SEG + (u32)k * 16u;
+            s0.commit();
+            if (__ballot(coded && s0.avail() < 36u)) s0.refill(coded, 1u << 30, true);
+            s0.refill(coded && p0 < len, TRC_SEG, false);
+            if (NS == 2) {
+                s1.commit();
+                if (__ballot(coded && s1.avail() < 36u)) s1.refill(coded, 1u << 30, true);
+                s1.refill(coded && p0 < len, TRC_SEG, false);
+            }
+            if (coded && p0 + 16u <= len) {
+                u32 w[4];
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    u32 x0, x1, x2, x3;
+                    if (NS == 1) { x0 = get(d0, s0); x1 = get(d0, s0); x2 = get(d0, s0); x3 = get(d0, s0); }
+                    else         { x0 = get(d0, s0); x1 = get(d1, s1); x2 = get(d0, s0); x3 = get(d1, s1); }
+                    w[d] = x0 | (x1 << 8) | (x2 << 16) | (x3 << 24);
+                }
+                tout.put((u32)k, make_uint4(w[0], w[1], w[2], w[3]));
+            } else if (coded && p0 < len) {
+                for (u32 pos = p0; pos < len; pos++)
+                    dst[pos] = (u8)((NS == 2 && pos < pairs && (pos & 1u)) ? get(d1, s1) : get(d0, s0));
+            }
+        }
+        tout.flush(wc, s * TRC_SEG);
+    }
+    u64 rawmask = __ballot(alive && cl == len && len != 0);
+    while (rawmask) {
+        const int k = __ffsll((long long)rawmask) - 1;
+        rawmask &= rawmask - 1;
+        const u32 olo = (u32)__shfl((int)(u32)off, k, 64), ohi = (u32)__shfl((int)(u32)(off >> 32), k, 64);
+        const u32 l = (u32)__shfl((int)len, k, 64);
+        trc_wave_copy(out + (u64)(wc.c0 + (u32)k) * chunk, payload + (((u64)ohi << 32) | olo), l);
+    }
+}
+
+// ------------------------------------------------------------------------------------- launch ---
+void trc_launch_rcs_enc(int nstreams, const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w,
+                        uint32_t *d_clen, hipStream_t s)
+{
+    const u32 *tab = (const u32 *)(w.tables + TRC_TAB_DEC);
+    if (nstreams == 1)
+        hipLaunchKernelGGL(trc_rcs_enc_kernel<1>, dim3(w.ngroups), dim3(64), 1024 + RCS_WAVE_LDS(1), s,
+                           d_in, (u64)n, chunk, w.nchunks, tab, w.scratch, w.stride, w.scratch, w.stride, d_clen, w.gsum);
+    else
+        hipLaunchKernelGGL(trc_rcs_enc_kernel<2>, dim3(w.ngroups), dim3(64), 1024 + RCS_WAVE_LDS(2), s,
+                           d_in, (u64)n, chunk, w.nchunks, tab, w.scratch, w.stride, w.scratch2, w.stride2, d_clen, w.gsum);
+}
+
+template <int NS, int BLOCK>
+static void launch_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
+                       const TrcWork &w, uint8_t *d_out, hipStream_t s)
+{
+    const size_t sm = 32768 + 1024 + (BLOCK / 64) * RCS_WAVE_LDS(NS);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void *)trc_rcs_dec_kernel<NS, BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr = true; }
+    const u32 wpb = BLOCK / 64;
+    hipLaunchKernelGGL((trc_rcs_dec_kernel<NS, BLOCK>), dim3((w.ngroups + wpb - 1) / wpb), dim3(BLOCK), sm, s,
+                       d_payload, d_clen, w.goff, (u64)n, chunk, w.nchunks, w.tables + TRC_TAB_LUT,
+                       (const u32 *)(w.tables + TRC_TAB_DEC), d_out);
+}
+void trc_launch_rcs_dec(int nstreams, const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
+                        const TrcWork &w, uint8_t *d_out, hipStream_t s)
+{
+    const bool many = w.ngroups > 768;
+    if (nstreams == 1) { if (many) launch_dec<1, 512>(d_payload, d_clen, n, chunk, w, d_out, s); else launch_dec<1, 64>(d_payload, d_clen, n, chunk, w, d_out, s); }
+    else               { if (many) launch_dec<2, 256>(d_payload, d_clen, n, chunk, w, d_out, s); else launch_dec<2, 64>(d_payload, d_clen, n, chunk, w, d_out, s); }
+}
