@@ -47,6 +47,10 @@ size_t rccdfs2enc(unsigned char *in, size_t inlen, unsigned char *out, cdf_t *cd
 size_t rccdfsl2dec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum);
 size_t rccdfsb2dec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum);
 
+/* bitwise order-0 range coder, "s" predictor (reference rc_.c:37-58; `turborc -e1`, file codec 1) */
+size_t rcsenc(unsigned char *in, size_t inlen, unsigned char *out);
+size_t rcsdec(unsigned char *in, size_t outlen, unsigned char *out);
+
 #ifdef __cplusplus
 }
 #endif

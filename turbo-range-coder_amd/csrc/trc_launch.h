@@ -47,6 +47,11 @@ void trc_launch_rcs_enc(int nstreams, const uint8_t *d_in, size_t n, uint32_t ch
 void trc_launch_rcs_dec(int nstreams, const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                         const TrcWork &w, uint8_t *d_out, hipStream_t s);
 
+// RCB: bitwise order-0 range coder (rcsenc / rcsdec)
+void trc_launch_rcb_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s);
+void trc_launch_rcb_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
+                        const TrcWork &w, uint8_t *d_out, hipStream_t s);
+
 // cdfini on device
 void trc_launch_cdfini(const uint8_t *d_in, size_t n, uint16_t *d_cdf, unsigned cdfnum,
                        int32_t *d_status, uint64_t *d_hist /*256 u64*/, hipStream_t s);
