@@ -47,6 +47,10 @@ size_t rccdfs2enc(unsigned char *in, size_t inlen, unsigned char *out, cdf_t *cd
 size_t rccdfsl2dec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum);
 size_t rccdfsb2dec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum);
 
+/* adaptive-CDF byte range coder (reference rccdf.c:187-211; `turborc -e46`) */
+size_t rccdfenc(unsigned char *in, size_t inlen, unsigned char *out);
+size_t rccdfdec(unsigned char *in, size_t outlen, unsigned char *out);
+
 /* bitwise order-0 range coder, "s" predictor (reference rc_.c:37-58; `turborc -e1`, file codec 1) */
 size_t rcsenc(unsigned char *in, size_t inlen, unsigned char *out);
 size_t rcsdec(unsigned char *in, size_t outlen, unsigned char *out);

@@ -60,7 +60,7 @@ extern "C" int trc_set_chunk(uint32_t chunk)
 // ------------------------------------------------------------------------------ workspace map ---
 static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline bool is_static(int codec) { return codec == TRC_ANS4S || codec == TRC_RCS1 || codec == TRC_RCS2; }
-static inline bool codec_ok(int codec) { return codec == TRC_ANS4S || codec == TRC_RCS1 || codec == TRC_RCS2 || codec == TRC_RCB; }
+static inline bool codec_ok(int codec) { return codec == TRC_ANS4S || codec == TRC_RCS1 || codec == TRC_RCS2 || codec == TRC_RCB || codec == TRC_RCA; }
 static inline int nregions(int codec) { return codec == TRC_RCS2 ? 2 : 1; }
 
 static uint32_t scratch_stride(int codec, uint32_t chunk)
@@ -173,6 +173,7 @@ extern "C" int trc_encode_dev(int codec, const void *d_in, size_t n, uint32_t ch
     case TRC_RCS1:  trc_launch_rcs_enc(1, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 0; break;
     case TRC_RCS2:  trc_launch_rcs_enc(2, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 2; break;
     case TRC_RCB:   trc_launch_rcb_enc((const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 0; break;
+    case TRC_RCA:   trc_launch_rca_enc((const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 0; break;
     }
     tm_end(0, tmi, s);
     trc_launch_scan_groups(w.gsum, w.ngroups, w.goff, d_total, s);
@@ -200,6 +201,7 @@ extern "C" int trc_decode_dev(int codec, const uint32_t *d_clen, const void *d_p
     case TRC_RCS1:  trc_launch_rcs_dec(1, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     case TRC_RCS2:  trc_launch_rcs_dec(2, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     case TRC_RCB:   trc_launch_rcb_dec((const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
+    case TRC_RCA:   trc_launch_rca_dec((const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     }
     tm_end(1, tmi, s);
     HIPCHK(hipGetLastError());
@@ -212,6 +214,7 @@ extern "C" const char *trc_kernel_name(int codec, int decode)
     case TRC_ANS4S: return decode ? "trc_ans4s_dec_kernel" : "trc_ans4s_enc_kernel";
     case TRC_RCS1: case TRC_RCS2: return decode ? "trc_rcs_dec_kernel" : "trc_rcs_enc_kernel";
     case TRC_RCB: return decode ? "trc_rcb_dec_kernel" : "trc_rcb_enc_kernel";
+    case TRC_RCA: return decode ? "trc_rca_dec_kernel" : "trc_rca_enc_kernel";
     }
     return "";
 }
@@ -382,5 +385,9 @@ size_t rccdfsb2dec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *
 // bitwise order-0 range coder, "s" predictor (reference rc_.c:37-58; turborc -e1 / file codec 1)
 size_t rcsenc(unsigned char *in, size_t inlen, unsigned char *out) { return host_encode(TRC_RCB, in, inlen, out, nullptr, 0); }
 size_t rcsdec(unsigned char *in, size_t outlen, unsigned char *out) { return host_decode(TRC_RCB, in, outlen, out, nullptr, 0); }
+
+// adaptive-CDF byte range coder (reference rccdf.c:187-211; turborc -e46)
+size_t rccdfenc(unsigned char *in, size_t inlen, unsigned char *out) { return host_encode(TRC_RCA, in, inlen, out, nullptr, 0); }
+size_t rccdfdec(unsigned char *in, size_t outlen, unsigned char *out) { return host_decode(TRC_RCA, in, outlen, out, nullptr, 0); }
 
 }  // extern "C"
