@@ -35,6 +35,29 @@ LIBAPI size_t anscdf4sdecs(unsigned char *in, size_t outlen, unsigned char *out,
 LIBAPI size_t anscdf4sencx(unsigned char *in, size_t inlen, unsigned char *out, cdf_t *cdf);
 LIBAPI size_t anscdf4sdecx(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf);
 
+/* adaptive-CDF byte rANS, 4 states (reference include/anscdf.h:46-47,76-81; anscdf.c:567-605;
+ * `turborc -e56` auto, -e57 "s" build, -e58 "x" build -- identical bitstreams, one kernel here) */
+LIBAPI size_t anscdfenc(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdfdec(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdfenc0(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdfdec0(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdfencs(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdfdecs(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdfencx(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdfdecx(unsigned char *in, size_t outlen, unsigned char *out);
+
+#ifdef __cplusplus
+}
+#endif
+
+/* dispatch globals of the reference (include/anscdf.h:27-33); both point at the functions above */
+typedef LIBAPI size_t (*fanscdfenc)(unsigned char *in, size_t inlen, unsigned char *out);
+typedef LIBAPI size_t (*fanscdfdec)(unsigned char *in, size_t inlen, unsigned char *out);
+#ifdef __cplusplus
+extern "C" {
+#endif
+extern fanscdfenc _anscdfenc;
+extern fanscdfdec _anscdfdec;
 #ifdef __cplusplus
 }
 #endif

@@ -60,8 +60,10 @@ extern "C" int trc_set_chunk(uint32_t chunk)
 // ------------------------------------------------------------------------------ workspace map ---
 static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline bool is_static(int codec) { return codec == TRC_ANS4S || codec == TRC_RCS1 || codec == TRC_RCS2; }
-static inline bool codec_ok(int codec) { return codec == TRC_ANS4S || codec == TRC_RCS1 || codec == TRC_RCS2 || codec == TRC_RCB || codec == TRC_RCA; }
+static inline bool codec_ok(int codec) { return codec == TRC_ANS4S || codec == TRC_RCS1 || codec == TRC_RCS2 || codec == TRC_RCB || codec == TRC_RCA || codec == TRC_ANSA; }
 static inline int nregions(int codec) { return codec == TRC_RCS2 ? 2 : 1; }
+// second scratch array: RCS2 stream 1 (same stride) or ANSA's record stack (8 B per input byte + one segment)
+static inline size_t scratch2_stride(int codec, uint32_t chunk) { return codec == TRC_RCS2 ? chunk + 128 : codec == TRC_ANSA ? 8 * (size_t)chunk : 0; }
 
 static uint32_t scratch_stride(int codec, uint32_t chunk)
 {
@@ -75,7 +77,7 @@ extern "C" size_t trc_work_bytes(int codec, size_t n, uint32_t chunk)
     if (!chunk_ok(chunk)) return 0;
     const size_t nchunks = (n + chunk - 1) / chunk, ngroups = (nchunks + 63) / 64;
     return up256(TRC_TAB_BYTES) + up256(4 * ngroups) + up256(8 * (ngroups + 1)) +
-           nregions(codec) * up256(nchunks * (size_t)scratch_stride(codec, chunk)) + 4096;
+           up256(nchunks * (size_t)scratch_stride(codec, chunk)) + up256(nchunks * scratch2_stride(codec, chunk) + 256) + 4096;
 }
 
 static int carve(int codec, size_t n, uint32_t chunk, void *d_work, size_t work_bytes, TrcWork &w)
@@ -89,7 +91,8 @@ static int carve(int codec, size_t n, uint32_t chunk, void *d_work, size_t work_
     w.gsum = (uint32_t *)p;     p += up256(4 * ngroups);
     w.goff = (uint64_t *)p;     p += up256(8 * (ngroups + 1));
     w.scratch = p;
-    w.stride = w.stride2 = scratch_stride(codec, chunk);
+    w.stride = scratch_stride(codec, chunk);
+    w.stride2 = (uint32_t)scratch2_stride(codec, chunk);
     w.scratch2 = p + up256(nchunks * (size_t)w.stride);
     w.nchunks = (uint32_t)nchunks; w.ngroups = (uint32_t)ngroups;
     return TRC_OK;
@@ -174,6 +177,7 @@ extern "C" int trc_encode_dev(int codec, const void *d_in, size_t n, uint32_t ch
     case TRC_RCS2:  trc_launch_rcs_enc(2, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 2; break;
     case TRC_RCB:   trc_launch_rcb_enc((const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 0; break;
     case TRC_RCA:   trc_launch_rca_enc((const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 0; break;
+    case TRC_ANSA:  trc_launch_ansa_enc((const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 1; break;
     }
     tm_end(0, tmi, s);
     trc_launch_scan_groups(w.gsum, w.ngroups, w.goff, d_total, s);
@@ -202,6 +206,7 @@ extern "C" int trc_decode_dev(int codec, const uint32_t *d_clen, const void *d_p
     case TRC_RCS2:  trc_launch_rcs_dec(2, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     case TRC_RCB:   trc_launch_rcb_dec((const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     case TRC_RCA:   trc_launch_rca_dec((const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
+    case TRC_ANSA:  trc_launch_ansa_dec((const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     }
     tm_end(1, tmi, s);
     HIPCHK(hipGetLastError());
@@ -215,6 +220,7 @@ extern "C" const char *trc_kernel_name(int codec, int decode)
     case TRC_RCS1: case TRC_RCS2: return decode ? "trc_rcs_dec_kernel" : "trc_rcs_enc_kernel";
     case TRC_RCB: return decode ? "trc_rcb_dec_kernel" : "trc_rcb_enc_kernel";
     case TRC_RCA: return decode ? "trc_rca_dec_kernel" : "trc_rca_enc_kernel";
+    case TRC_ANSA: return decode ? "trc_ansa_dec_kernel" : "trc_ansa_code_kernel";
     }
     return "";
 }
@@ -389,5 +395,18 @@ size_t rcsdec(unsigned char *in, size_t outlen, unsigned char *out) { return hos
 // adaptive-CDF byte range coder (reference rccdf.c:187-211; turborc -e46)
 size_t rccdfenc(unsigned char *in, size_t inlen, unsigned char *out) { return host_encode(TRC_RCA, in, inlen, out, nullptr, 0); }
 size_t rccdfdec(unsigned char *in, size_t outlen, unsigned char *out) { return host_decode(TRC_RCA, in, outlen, out, nullptr, 0); }
+
+// adaptive-CDF byte rANS (reference anscdf.c:567-605, dispatch :816-817; turborc -e56 / -e57 / -e58)
+#define TRC_EXPORT_ANSA(sfx) \
+    size_t anscdfenc##sfx(unsigned char *in, size_t inlen, unsigned char *out) { return host_encode(TRC_ANSA, in, inlen, out, nullptr, 0); } \
+    size_t anscdfdec##sfx(unsigned char *in, size_t outlen, unsigned char *out) { return host_decode(TRC_ANSA, in, outlen, out, nullptr, 0); }
+TRC_EXPORT_ANSA()
+TRC_EXPORT_ANSA(0)
+TRC_EXPORT_ANSA(s)
+TRC_EXPORT_ANSA(x)
+typedef size_t (*fanscdfenc)(unsigned char *in, size_t inlen, unsigned char *out);
+typedef size_t (*fanscdfdec)(unsigned char *in, size_t inlen, unsigned char *out);
+fanscdfenc _anscdfenc = anscdfenc;      // the reference's dispatch globals (include/anscdf.h:32-33)
+fanscdfdec _anscdfdec = anscdfdec;
 
 }  // extern "C"

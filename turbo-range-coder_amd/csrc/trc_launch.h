@@ -57,6 +57,11 @@ void trc_launch_rca_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const Trc
 void trc_launch_rca_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                         const TrcWork &w, uint8_t *d_out, hipStream_t s);
 
+// ANSA: adaptive-CDF byte rANS (anscdfenc / anscdfdec); scratch2 holds the 8 B/byte record stack
+void trc_launch_ansa_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s);
+void trc_launch_ansa_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
+                         const TrcWork &w, uint8_t *d_out, hipStream_t s);
+
 // cdfini on device
 void trc_launch_cdfini(const uint8_t *d_in, size_t n, uint16_t *d_cdf, unsigned cdfnum,
                        int32_t *d_status, uint64_t *d_hist /*256 u64*/, hipStream_t s);

@@ -19,7 +19,7 @@ LIB = os.environ.get("TRC_LIB") or os.path.join(PKG, "libturborc_hip.so")   # TR
 ANS4S, RCS1, RCS2, RCA, ANSA, RCB = 1, 2, 3, 4, 5, 6
 CODEC_NAMES = {ANS4S: "anscdf4s", RCS1: "rccdfs", RCS2: "rccdfs2", RCA: "rccdf", ANSA: "anscdf", RCB: "rcs"}
 STATIC = (ANS4S, RCS1, RCS2)
-AVAILABLE = (ANS4S, RCS1, RCS2, RCB, RCA)          # codecs with HIP kernels behind them (grows per round)
+AVAILABLE = (ANS4S, RCS1, RCS2, RCB, RCA, ANSA)          # codecs with HIP kernels behind them (grows per round)
 PAD = 256
 HDR = 32
 
