@@ -86,7 +86,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=100 * 1000 * 1000, help="bytes per GPU")
-    ap.add_argument("--chunk", type=int, default=int(os.environ.get("TRC_BENCH_CHUNK", "4096")))
+    ap.add_argument("--chunk", type=int, default=int(os.environ.get("TRC_BENCH_CHUNK", "1024")),
+                    help="chunk bytes (parallel unit); 1024 fills the 1024 SIMDs at 100 MB, ratio cost vs 4096: +0.7 %% (DESIGN.md)")
     ap.add_argument("--codec", default="anscdf4s")
     ap.add_argument("--cpu-sample", type=int, default=32 * 1000 * 1000)
     ap.add_argument("--no-cpu", action="store_true")
@@ -94,6 +95,7 @@ def main():
     args = ap.parse_args()
 
     import torch
+    import shard
     import trc
     import trc_testlib as T
 
@@ -118,31 +120,29 @@ def main():
     d_in = torch.from_numpy(np.concatenate([d, np.zeros(512, np.uint8)])).to(dev)
     dc = trc.DeviceCoder(codec, n, chunk, dev)
     cdfnum = 256
-    if codec in trc.STATIC:
-        dc.cdfini(d_in, n, cdfnum)                         # untimed, like the reference harness
+    if codec in trc.STATIC:                                # untimed, like the reference harness (turborc.c:429-433)
+        if world > 1:                                      # one CDF for the whole job: all-reduce the 256-bin histogram
+            hist = torch.zeros(256, dtype=torch.int64, device=dev)
+            dc.hist(d_in, n, hist)
+            shard.allreduce_hist(dist, hist)
+            dc.cdf_from_hist(hist, n * world, cdfnum)
+        else:
+            dc.cdfini(d_in, n, cdfnum)
         torch.cuda.synchronize(dev)
-        assert int(dc.status[0].item()) == n, "cdfini failed"
+        assert int(dc.status[0].item()) > 0, "cdfini failed"
     d_out = torch.zeros(n + 512, dtype=torch.uint8, device=dev)
 
-    # multi-GPU exchange buffers: rank 0 receives every rank's payload (variable size) + directory
-    gather_buf = None
+    # multi-GPU exchange buffers: rank 0 receives every rank's directory slice + payload (variable size)
+    nch = trc.nchunks(n, chunk)
+    recv_clen = recv_payload = None
     if world > 1 and rank == 0:
-        gather_buf = [torch.empty(n + 1024, dtype=torch.uint8, device=dev) for _ in range(world - 1)]
-    tot_all = torch.zeros(world, dtype=torch.int64, device=dev) if world > 1 else None
+        recv_clen = [torch.empty(nch, dtype=torch.int32, device=dev) for _ in range(world - 1)]
+        recv_payload = [torch.empty(n + 1024, dtype=torch.uint8, device=dev) for _ in range(world - 1)]
 
     def exchange():
-        """RCCL gather of the compressed payloads to rank 0: all_gather of the sizes, then one
-        point-to-point transfer per peer (each rides its own xGMI link)."""
-        dist.all_gather_into_tensor(tot_all, dc.total[:1])
-        sizes = tot_all.tolist()
-        ops = []
-        if rank == 0:
-            for r in range(1, world):
-                ops.append(dist.P2POp(dist.irecv, gather_buf[r - 1][:sizes[r]], r))
-        else:
-            ops.append(dist.P2POp(dist.isend, dc.payload[:sizes[rank]], 0))
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+        """RCCL gather of the compressed results to rank 0 (shard.py): all_gather of the sizes, then one
+        point-to-point transfer per peer -- over xGMI each rides its own direct link."""
+        shard.gather_to_root(dist, rank, world, dc.total[:1], dc.clen[:nch], dc.payload, recv_clen, recv_payload)
 
     def step():
         dc.encode(d_in, n)

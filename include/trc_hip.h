@@ -86,6 +86,13 @@ size_t trc_work_bytes(int codec, size_t n, uint32_t chunk);
 int trc_cdfini_dev(const void *d_in, size_t n, uint16_t *d_cdf, unsigned cdfnum,
                    int32_t *d_status, void *d_work, void *stream);
 
+/* The two halves of trc_cdfini_dev, for sharded inputs: every rank histograms its shard
+ * (d_hist: uint64[256], zeroed by the call), the histograms are summed across ranks (one RCCL
+ * all-reduce of 2 KiB), then every rank builds the same CDF from the global histogram. */
+int trc_hist_dev(const void *d_in, size_t n, uint64_t *d_hist, void *stream);
+int trc_cdf_from_hist_dev(const uint64_t *d_hist, size_t n_total, uint16_t *d_cdf, unsigned cdfnum,
+                          int32_t *d_status, void *stream);
+
 /* Encode n bytes at d_in with `codec`.
  *   d_cdf/cdfnum : static coders only (uint16[cdfnum+1], cdf[cdfnum] == 32768), else NULL/0
  *   d_clen       : uint32[nchunks]  <- per-chunk compressed length (== chunk length: raw)

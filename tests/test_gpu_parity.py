@@ -168,3 +168,18 @@ def test_baseline_size_properties(torch_cuda, codec):
         sl = d[c * chunk:(c + 1) * chunk]
         exp = T.orc_enc(codec, sl, cdf, cdfnum)
         assert clen[c] == exp.size and np.array_equal(payload[off[c]:off[c + 1]], exp), "chunk %d" % c
+
+
+def test_c_harness_links_and_roundtrips(torch_cuda):
+    """the plain-C TurboRC-style harness (harness/trcbench.c: only include/turborc.h + anscdf.h) round-trips
+    every hot-path id through the reference-named functions with host pointers"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "harness", "trcbench")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "harness")])
+    for args in (["--zipf", "3000001"], ["--text", "1000000", "-c", "1024"], ["--uniform", "500000"]):
+        r = subprocess.run([exe, "-I", "1", "-e", "1,42,43,45,46,56,57,58,65,79"] + args, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "MISMATCH" not in r.stdout and "failed" not in r.stdout, r.stdout
+        assert r.stdout.count(":") >= 11, r.stdout            # every requested id printed its row

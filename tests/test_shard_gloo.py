@@ -1,0 +1,77 @@
+"""CPU, world_size 2, gloo: the N>1 path (shard -> histogram all-reduce -> per-rank coding ->
+gather to rank 0 -> container) with the CPU oracle standing in for the HIP coders.  The assembled
+container must equal the single-process container of the whole input, and decode back."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import trc_testlib as T
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "turbo-range-coder_amd"))
+import shard  # noqa: E402
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, codec, n, chunk, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        data = T.zipf_bytes(n, 1.1, 256, 99)
+        start, ln = shard.shard_bounds(n, world, chunk)[rank]
+        mine = data[start:start + ln]
+        cdf, cdfnum = None, 0
+        if codec in T.STATIC_CODECS:
+            hist = torch.from_numpy(np.bincount(mine, minlength=256).astype(np.int64))
+            shard.allreduce_hist(dist, hist)
+            # CDF from the GLOBAL histogram with the reference's rule == cdfini(whole input)
+            _, cdf, cdfnum = T.orc_cdfini(data)
+            assert np.array_equal(hist.numpy(), np.bincount(data, minlength=256))
+        payload, clen, _ = T.orc_chunked_enc(codec, mine, chunk, cdf, cdfnum or 256) if ln else (np.zeros(0, np.uint8), np.zeros(0, np.uint32), None)
+        total = torch.tensor([payload.size], dtype=torch.int64)
+        sizes, cl, pl = shard.gather_to_root(dist, rank, world, total, torch.from_numpy(clen.view(np.int32).copy()),
+                                             torch.from_numpy(np.concatenate([payload, np.zeros(8, np.uint8)])))
+        if rank == 0:
+            cont = shard.assemble_container(codec, n, chunk, cdfnum, [c.numpy().view(np.uint32) for c in cl], [p.numpy() for p in pl])
+            full_payload, full_clen, _ = T.orc_chunked_enc(codec, data, chunk, cdf, cdfnum or 256)
+            ref = shard.assemble_container(codec, n, chunk, cdfnum, [full_clen], [full_payload])
+            ok = np.array_equal(cont, ref)
+            nch = full_clen.size
+            dec = T.orc_chunked_dec(codec, cont[32 + 4 * nch:], cont[32:32 + 4 * nch].view(np.uint32), n, chunk, cdf, cdfnum or 256)
+            q.put(bool(ok and np.array_equal(dec, data)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("codec,n,chunk", [(T.ANS4S, 300001, 4096), (T.RCS2, 70000, 1024), (T.RCB, 20000, 4096), (T.ANS4S, 3000, 4096)])
+def test_two_rank_shard_gather_matches_single(codec, n, chunk):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, codec, n, chunk, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+def test_shard_bounds_cover_everything():
+    for n, world, chunk in [(100, 2, 64), (10**6, 8, 4096), (4096, 8, 4096), (1, 4, 256)]:
+        b = shard.shard_bounds(n, world, chunk)
+        assert sum(l for _, l in b) == n
+        pos = 0
+        for s, l in b:
+            assert s == pos or l == 0
+            assert s % chunk == 0 or l == 0
+            pos += l

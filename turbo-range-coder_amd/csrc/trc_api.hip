@@ -157,6 +157,23 @@ extern "C" int trc_cdfini_dev(const void *d_in, size_t n, uint16_t *d_cdf, unsig
     return TRC_OK;
 }
 
+extern "C" int trc_hist_dev(const void *d_in, size_t n, uint64_t *d_hist, void *stream)
+{
+    if (!d_hist) return fail(TRC_E_ARG, "hist: null histogram");
+    if (n) trc_launch_hist((const uint8_t *)d_in, n, d_hist, (hipStream_t)stream);
+    else HIPCHK(hipMemsetAsync(d_hist, 0, 256 * sizeof(uint64_t), (hipStream_t)stream));
+    HIPCHK(hipGetLastError());
+    return TRC_OK;
+}
+extern "C" int trc_cdf_from_hist_dev(const uint64_t *d_hist, size_t n_total, uint16_t *d_cdf, unsigned cdfnum,
+                                     int32_t *d_status, void *stream)
+{
+    if (!n_total || cdfnum < 1 || cdfnum > 256) return fail(TRC_E_ARG, "cdf_from_hist: n=%zu cdfnum=%u", n_total, cdfnum);
+    trc_launch_cdf_build(d_hist, n_total, d_cdf, cdfnum, d_status, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return TRC_OK;
+}
+
 extern "C" int trc_encode_dev(int codec, const void *d_in, size_t n, uint32_t chunk,
                               const uint16_t *d_cdf, unsigned cdfnum,
                               uint32_t *d_clen, void *d_payload, uint64_t *d_total,

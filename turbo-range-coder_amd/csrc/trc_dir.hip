@@ -174,15 +174,23 @@ __global__ __launch_bounds__(256) void trc_cdf_build_kernel(const u64 *__restric
     if (tid == 0 && pre[cdfnum] != (TRC_PROB_ONE & 0xffffu)) atomicOr(&bad, 1);
     __syncthreads();
     for (u32 i = tid; i <= cdfnum; i += 256) cdf[i] = (u16)pre[i];
-    if (tid == 0) *status = bad ? -1 : (int)n;
+    if (tid == 0) *status = bad ? -1 : (int)(n > 0x7fffffffull ? 0x7fffffffull : n);   // (int)inlen like the reference, saturated
 }
-void trc_launch_cdfini(const uint8_t *d_in, size_t n, uint16_t *d_cdf, unsigned cdfnum,
-                       int32_t *d_status, uint64_t *d_hist, hipStream_t s)
+void trc_launch_hist(const uint8_t *d_in, size_t n, uint64_t *d_hist, hipStream_t s)
 {
     (void)hipMemsetAsync(d_hist, 0, 256 * sizeof(uint64_t), s);
     u64 blocks = ((n >> 4) + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(trc_hist_kernel, dim3((u32)blocks), dim3(256), 0, s, d_in, (u64)n, d_hist);
-    hipLaunchKernelGGL(trc_cdf_build_kernel, dim3(1), dim3(256), 0, s, d_hist, (u64)n, (u32)cdfnum, d_cdf, d_status);
+}
+void trc_launch_cdf_build(const uint64_t *d_hist, size_t n_total, uint16_t *d_cdf, unsigned cdfnum, int32_t *d_status, hipStream_t s)
+{
+    hipLaunchKernelGGL(trc_cdf_build_kernel, dim3(1), dim3(256), 0, s, d_hist, (u64)n_total, (u32)cdfnum, d_cdf, d_status);
+}
+void trc_launch_cdfini(const uint8_t *d_in, size_t n, uint16_t *d_cdf, unsigned cdfnum,
+                       int32_t *d_status, uint64_t *d_hist, hipStream_t s)
+{
+    trc_launch_hist(d_in, n, d_hist, s);
+    trc_launch_cdf_build(d_hist, n, d_cdf, cdfnum, d_status, s);
 }

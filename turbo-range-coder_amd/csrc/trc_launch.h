@@ -63,5 +63,7 @@ void trc_launch_ansa_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_
                          const TrcWork &w, uint8_t *d_out, hipStream_t s);
 
 // cdfini on device
+void trc_launch_hist(const uint8_t *d_in, size_t n, uint64_t *d_hist, hipStream_t s);
+void trc_launch_cdf_build(const uint64_t *d_hist, size_t n_total, uint16_t *d_cdf, unsigned cdfnum, int32_t *d_status, hipStream_t s);
 void trc_launch_cdfini(const uint8_t *d_in, size_t n, uint16_t *d_cdf, unsigned cdfnum,
                        int32_t *d_status, uint64_t *d_hist /*256 u64*/, hipStream_t s);

@@ -1,0 +1,86 @@
+"""Multi-GPU sharding of the chunked coders: one process per GPU, torch.distributed.
+
+Chunks are independent, so the path shards by contiguous chunk ranges with NO data-path collective
+inside the coders.  The only exchanges are
+  * (static coders) one all-reduce of the 256-bin byte histogram, so every rank builds the same CDF
+    and the assembled container equals the single-GPU container of the whole input bit for bit;
+  * the gather of the per-rank results to rank 0: all_gather of the payload sizes, then one
+    point-to-point transfer per peer (over xGMI each rides its own direct link; a ring would
+    serialise on single links) for the directory slice and the payload.
+Everything here works on CPU tensors with the gloo backend too (tests/test_shard_gloo.py).
+"""
+import struct
+
+import numpy as np
+
+HDR = 32
+MAGIC = 0x31435254
+
+
+def shard_bounds(n, world, chunk):
+    """-> list of (byte_start, byte_len) per rank: contiguous ranges of whole chunks, last rank ragged."""
+    nch = (n + chunk - 1) // chunk
+    per, rem = divmod(nch, world)
+    out, c = [], 0
+    for r in range(world):
+        k = per + (1 if r < rem else 0)
+        start = c * chunk
+        end = min(n, (c + k) * chunk)
+        out.append((start, max(0, end - start)))
+        c += k
+    return out
+
+
+def allreduce_hist(dist, hist):
+    """sum the per-rank 256-bin histograms in place (int64 tensor on the backend's device)"""
+    dist.all_reduce(hist, op=dist.ReduceOp.SUM)
+    return hist
+
+
+def gather_to_root(dist, rank, world, total, clen, payload, recv_clen=None, recv_payload=None):
+    """Gather every rank's (clen slice, payload) to rank 0.
+
+    total   : int64[1] tensor   this rank's payload bytes
+    clen    : int32 tensor      this rank's chunk lengths (already trimmed to its chunk count)
+    payload : uint8 tensor      at least total bytes
+    recv_*  : rank 0 only: lists (len world-1) of pre-allocated receive tensors, or None to allocate
+    Returns on rank 0: (sizes list, [clen tensors per rank], [payload tensors per rank]); else (sizes, None, None).
+    """
+    import torch
+    meta = torch.stack([total.reshape(()).to(torch.int64), torch.tensor(clen.numel(), dtype=torch.int64, device=total.device)])
+    allmeta = torch.empty(2 * world, dtype=torch.int64, device=total.device)
+    dist.all_gather_into_tensor(allmeta, meta)
+    m = allmeta.tolist()
+    sizes = [(m[2 * r], m[2 * r + 1]) for r in range(world)]
+    ops = []
+    if rank == 0:
+        cl = [clen]
+        pl = [payload[:sizes[0][0]]]
+        for r in range(1, world):
+            tb, nc = sizes[r]
+            c_r = recv_clen[r - 1][:nc] if recv_clen else torch.empty(nc, dtype=clen.dtype, device=clen.device)
+            p_r = recv_payload[r - 1][:tb] if recv_payload else torch.empty(tb, dtype=torch.uint8, device=payload.device)
+            cl.append(c_r); pl.append(p_r)
+            if nc:
+                ops.append(dist.P2POp(dist.irecv, c_r, r))
+            if tb:
+                ops.append(dist.P2POp(dist.irecv, p_r, r))
+    else:
+        cl = pl = None
+        tb, nc = sizes[rank]
+        if nc:
+            ops.append(dist.P2POp(dist.isend, clen, 0))
+        if tb:
+            ops.append(dist.P2POp(dist.isend, payload[:tb], 0))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return sizes, cl, pl
+
+
+def assemble_container(codec, n, chunk, cdfnum, clens, payloads):
+    """rank 0: TRC1 container bytes (include/trc_hip.h) from the gathered per-rank pieces (numpy arrays)."""
+    clen = np.concatenate([np.asarray(c, dtype=np.uint32) for c in clens]) if clens else np.zeros(0, np.uint32)
+    pay = np.concatenate([np.asarray(p, dtype=np.uint8) for p in payloads]) if payloads else np.zeros(0, np.uint8)
+    hdr = struct.pack("<IBBHIIQQ", MAGIC, codec, 1, cdfnum, chunk, clen.size, n, pay.size)
+    return np.concatenate([np.frombuffer(hdr, dtype=np.uint8), clen.view(np.uint8), pay])

@@ -54,6 +54,8 @@ def lib():
         l.trc_work_bytes.restype = _sz; l.trc_work_bytes.argtypes = [C.c_int, _sz, C.c_uint32]
         l.trc_cdfini_dev.restype = C.c_int
         l.trc_cdfini_dev.argtypes = [_vp, _sz, _vp, C.c_uint, _vp, _vp, _vp]
+        l.trc_hist_dev.restype = C.c_int; l.trc_hist_dev.argtypes = [_vp, _sz, _vp, _vp]
+        l.trc_cdf_from_hist_dev.restype = C.c_int; l.trc_cdf_from_hist_dev.argtypes = [_vp, _sz, _vp, C.c_uint, _vp, _vp]
         l.trc_encode_dev.restype = C.c_int
         l.trc_encode_dev.argtypes = [C.c_int, _vp, _sz, C.c_uint32, _vp, C.c_uint, _vp, _vp, _vp, _vp, _sz, _vp]
         l.trc_decode_dev.restype = C.c_int
@@ -124,6 +126,14 @@ class DeviceCoder:
         """Device cdfini: histogram of d_in[:n] -> self.cdf (stays on device)."""
         _chk(lib().trc_cdfini_dev(d_in.data_ptr(), n, self.cdf.data_ptr(), cdfnum, self.status.data_ptr(),
                                   self.work.data_ptr(), self._stream()))
+        self.cdfnum = cdfnum
+
+    def hist(self, d_in, n, d_hist):
+        """byte histogram of d_in[:n] into d_hist (int64[256] device tensor)"""
+        _chk(lib().trc_hist_dev(d_in.data_ptr(), n, d_hist.data_ptr(), self._stream()))
+
+    def cdf_from_hist(self, d_hist, n_total, cdfnum):
+        _chk(lib().trc_cdf_from_hist_dev(d_hist.data_ptr(), n_total, self.cdf.data_ptr(), cdfnum, self.status.data_ptr(), self._stream()))
         self.cdfnum = cdfnum
 
     def encode(self, d_in, n=None):
