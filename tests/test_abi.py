@@ -34,8 +34,16 @@ def test_every_declared_symbol_is_exported(lib, header):
 
 def test_expected_reference_names_present():
     names = set(declared("turborc.h")) | set(declared("anscdf.h"))
-    for n in ("cdfini", "anscdf4senc", "anscdf4sdec", "anscdfini"):
+    for n in ("cdfini", "anscdf4senc", "anscdf4sdec", "anscdfini", "anscdfenc", "anscdfdec", "anscdfencs", "anscdfdecx",
+              "rccdfsenc", "rccdfsbdec", "rccdfsldec", "rccdfsvbdec", "rccdfsvldec", "rccdfs2enc", "rccdfsb2dec", "rccdfsl2dec",
+              "rccdfenc", "rccdfdec", "rcsenc", "rcsdec"):
         assert n in names
+
+
+def test_reference_dispatch_globals_exported(lib):
+    """include/anscdf.h declares the reference's dispatch globals (reference include/anscdf.h:32-33)"""
+    for g in ("_anscdfenc", "_anscdfdec"):
+        assert ctypes.c_void_p.in_dll(lib, g).value, g
 
 
 def test_config_calls_work_without_gpu(lib):
