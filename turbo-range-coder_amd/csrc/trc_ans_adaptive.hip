@@ -162,7 +162,7 @@ __global__ __launch_bounds__(64) void trc_ansa_code_kernel(
 
 // ------------------------------------------------------------------------------------- decode ---
 __global__ __launch_bounds__(64) void trc_ansa_dec_kernel(
-    const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff,
+    const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
     u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64) void trc_ansa_dec_kernel(
     const u32 len = alive ? wc.len_of(lane) : 0u;
     const u32 cl = alive ? clen[c] : 0u;
     const u32 ex = trc_wave_incl_scan(cl) - cl;
-    const u64 off = goff[wc.c0 >> 6] + ex;
+    const u64 off = trc_group_base(goff, gsum, wc.c0 >> 6) + ex;
     const bool coded = alive && cl != len;
 
     TileOut tout; tout.tile = wbase; tout.base = out + (u64)wc.c0 * chunk;
@@ -222,9 +222,7 @@ __global__ __launch_bounds__(64) void trc_ansa_dec_kernel(
 #pragma unroll
             for (int hh = 0; hh < 2; hh++) {                   // period = 8 bytes = 4 pairs: <= 16 renorm words = 32 B
                 const u32 q0 = p0 + (u32)hh * 8u;
-                si.commit();
-                if (__ballot(coded && si.avail() < 36u)) si.refill(coded, 1u << 30, true);
-                si.refill(coded && q0 < len, TRC_SEG, false);
+                si.period(coded && q0 < len, hh);
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const u32 pos = q0 + 2u * (u32)j;
@@ -268,5 +266,5 @@ void trc_launch_ansa_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void *)trc_ansa_dec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ANSA_DEC_LDS); attr = true; }
     hipLaunchKernelGGL(trc_ansa_dec_kernel, dim3(w.ngroups), dim3(64), ANSA_DEC_LDS, s,
-                       d_payload, d_clen, w.goff, (u64)n, chunk, w.nchunks, d_out);
+                       d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, d_out);
 }

@@ -13,6 +13,7 @@
 // f<<16, c0}; decoder: 32 KiB slot->symbol LUT + 256 x 8 B {f, -c0}); all HBM traffic in 64-byte
 // quad segments through the LDS tiles/rings of trc_io.h.  No MFMA: integer work, bounded by VALU
 // issue (4 cycles per wave64 op) and LDS, not by HBM (DESIGN.md has the arithmetic).
+#include <stdlib.h>
 #include "trc_io.h"
 #include "trc_launch.h"
 
@@ -132,16 +133,15 @@ __device__ __forceinline__ u32 ans_get(u32 &st, const u8 *lut, const uint2 *dtab
     return x;
 }
 
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void trc_ans4s_dec_kernel(
-    const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff,
+__global__ __launch_bounds__(512) void trc_ans4s_dec_kernel(
+    const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
     u64 n, u32 chunk, u32 nchunks,
     const u8 *__restrict__ lut_g, const u32 *__restrict__ dtab_g, u8 *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     u8 *lut = smem;                                   // 32768
     uint2 *dtab = (uint2 *)(smem + 32768);            // 256 x 8
-    const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, BLOCK = blockDim.x;
     u8 *wbase = smem + 32768 + 2048 + wv * (TRC_TILE_BYTES + TRC_SRING_BYTES + TRC_SEL_BYTES);
     for (u32 i = tid; i < 2048; i += BLOCK) ((uint4 *)lut)[i] = ((const uint4 *)lut_g)[i];
     for (u32 i = tid; i < 256; i += BLOCK) { const u32 d = dtab_g[i]; dtab[i] = make_uint2(d >> 16, 0u - (d & 0xffffu)); }
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(BLOCK) void trc_ans4s_dec_kernel(
     const u32 len = alive ? wc.len_of(lane) : 0u;
     const u32 cl = alive ? clen[c] : 0u;
     const u32 ex = trc_wave_incl_scan(cl) - cl;
-    const u64 off = goff[wc.c0 >> 6] + ex;
+    const u64 off = trc_group_base(goff, gsum, wc.c0 >> 6) + ex;
     const bool coded = alive && cl != len;
 
     TileOut tout; tout.tile = wbase; tout.base = out + (u64)wc.c0 * chunk;
@@ -177,9 +177,7 @@ __global__ __launch_bounds__(BLOCK) void trc_ans4s_dec_kernel(
         for (int k = 0; k < 4; k++) {
             const u32 p0 = s * TRC_SEG + (u32)k * 16u;          // chunk offset of this 16-byte piece
             // period boundary: land the round requested 16 symbols ago, request the next one
-            si.commit();
-            if (__ballot(coded && si.avail() < 34u)) si.refill(coded, 1u << 30, true);      // (never on sane data)
-            si.refill(coded && p0 < len, TRC_SEG, false);
+            si.period(coded && p0 < len, k & 1);
             if (coded && p0 + 16u <= len) {
                 u32 w[4];
 #pragma unroll
@@ -228,17 +226,16 @@ void trc_launch_ans4s_dec(const uint8_t *d_payload, const uint32_t *d_clen, size
     const u32 nwaves = w.ngroups;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)trc_ans4s_dec_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void *)trc_ans4s_dec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   32768 + 2048 + 8 * ENC_WAVE_LDS);
         attr_set = true;
     }
-    if (nwaves > 768) {          // plenty of waves: 8 per workgroup share one 32 KiB LUT (1 workgroup = 1 CU)
-        const size_t sm = 32768 + 2048 + 8 * ENC_WAVE_LDS;
-        hipLaunchKernelGGL(trc_ans4s_dec_kernel<512>, dim3((nwaves + 7) / 8), dim3(512), sm, s,
-                           d_payload, d_clen, w.goff, (u64)n, chunk, w.nchunks, lut, dtab, d_out);
-    } else {                     // few waves: one per workgroup so they spread over all CUs
-        const size_t sm = 32768 + 2048 + ENC_WAVE_LDS;
-        hipLaunchKernelGGL(trc_ans4s_dec_kernel<64>, dim3(nwaves), dim3(64), sm, s,
-                           d_payload, d_clen, w.goff, (u64)n, chunk, w.nchunks, lut, dtab, d_out);
-    }
+    // the 34 KiB of tables are per workgroup, so waves share a workgroup -- but no more than it takes to
+    // give every one of the 256 CUs a workgroup (1526 waves: 6 per workgroup -> 255 workgroups)
+    u32 wpb = (nwaves + 255u) / 256u;
+    wpb = wpb < 1u ? 1u : wpb > 8u ? 8u : wpb;
+    if (const char *e = getenv("TRC_DEC_WPB")) { const u32 v = (u32)atoi(e); if (v >= 1 && v <= 8) wpb = v; }   // tuning aid
+    const size_t sm = 32768 + 2048 + wpb * ENC_WAVE_LDS;
+    hipLaunchKernelGGL(trc_ans4s_dec_kernel, dim3((nwaves + wpb - 1) / wpb), dim3(64 * wpb), sm, s,
+                       d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, lut, dtab, d_out);
 }

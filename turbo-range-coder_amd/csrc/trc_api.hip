@@ -58,6 +58,9 @@ extern "C" int trc_set_chunk(uint32_t chunk)
 }
 
 // ------------------------------------------------------------------------------ workspace map ---
+// up to this many groups every consumer wave sums the per-group byte counts itself (one scan kernel less
+// per call); beyond it a single-workgroup scan kernel runs
+#define TRC_INKERNEL_SCAN_MAX 8192u
 static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline bool is_static(int codec) { return codec == TRC_ANS4S || codec == TRC_RCS1 || codec == TRC_RCS2; }
 static inline bool codec_ok(int codec) { return codec == TRC_ANS4S || codec == TRC_RCS1 || codec == TRC_RCS2 || codec == TRC_RCB || codec == TRC_RCA || codec == TRC_ANSA; }
@@ -89,7 +92,7 @@ static int carve(int codec, size_t n, uint32_t chunk, void *d_work, size_t work_
     uint8_t *p = (uint8_t *)d_work;
     w.tables = p;               p += up256(TRC_TAB_BYTES);
     w.gsum = (uint32_t *)p;     p += up256(4 * ngroups);
-    w.goff = (uint64_t *)p;     p += up256(8 * (ngroups + 1));
+    w.goff = ngroups > TRC_INKERNEL_SCAN_MAX ? (uint64_t *)p : nullptr;     p += up256(8 * (ngroups + 1));
     w.scratch = p;
     w.stride = scratch_stride(codec, chunk);
     w.stride2 = (uint32_t)scratch2_stride(codec, chunk);
@@ -197,8 +200,8 @@ extern "C" int trc_encode_dev(int codec, const void *d_in, size_t n, uint32_t ch
     case TRC_ANSA:  trc_launch_ansa_enc((const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 1; break;
     }
     tm_end(0, tmi, s);
-    trc_launch_scan_groups(w.gsum, w.ngroups, w.goff, d_total, s);
-    trc_launch_gather((const uint8_t *)d_in, n, chunk, w, from_end, d_clen, (uint8_t *)d_payload, s);
+    if (w.goff) trc_launch_scan_groups(w.gsum, w.ngroups, w.goff, d_total, s);
+    trc_launch_gather((const uint8_t *)d_in, n, chunk, w, from_end, d_clen, (uint8_t *)d_payload, d_total, s);
     HIPCHK(hipGetLastError());
     return TRC_OK;
 }
@@ -215,7 +218,7 @@ extern "C" int trc_decode_dev(int codec, const uint32_t *d_clen, const void *d_p
     if ((rc = carve(codec, n, chunk, d_work, work_bytes, w))) return rc;
     if (is_static(codec)) trc_launch_static_prep(d_cdf, cdfnum, w.tables, s);
     trc_launch_group_sums(d_clen, w.nchunks, w.gsum, s);
-    trc_launch_scan_groups(w.gsum, w.ngroups, w.goff, nullptr, s);
+    if (w.goff) trc_launch_scan_groups(w.gsum, w.ngroups, w.goff, nullptr, s);
     const int tmi = tm_begin(1, s);
     switch (codec) {
     case TRC_ANS4S: trc_launch_ans4s_dec((const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;

@@ -74,3 +74,26 @@ __device__ __forceinline__ void trc_wave_copy(u8 *dst, const u8 *src, u32 len)
     const u32 done = head + (nvec << 4);
     if (lane < len - done) dst[done + lane] = src[done + lane];
 }
+
+// Payload offset of group g (64 chunks): goff[g] when the caller ran the scan kernel, otherwise the sum
+// of the per-group byte counts below g, computed by the calling wave (all 64 lanes must call).
+__device__ __forceinline__ u64 trc_group_base(const u64 *goff, const u32 *gsum, u32 g)
+{
+    if (goff) return goff[g];
+    u64 acc = 0;
+    u32 i = trc_lane();
+    for (; i + 448u < g; i += 512u) {                          // 8 independent loads in flight per trip
+        const u32 a0 = gsum[i], a1 = gsum[i + 64], a2 = gsum[i + 128], a3 = gsum[i + 192];
+        const u32 a4 = gsum[i + 256], a5 = gsum[i + 320], a6 = gsum[i + 384], a7 = gsum[i + 448];
+        acc += (u64)a0 + a1 + a2 + a3 + ((u64)a4 + a5 + a6 + a7);
+    }
+    for (; i < g; i += 64) acc += gsum[i];
+    u32 lo = (u32)acc, hi = (u32)(acc >> 32);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const u32 l2 = (u32)__shfl_xor((int)lo, d, 64), h2 = (u32)__shfl_xor((int)hi, d, 64);
+        const u64 t = ((((u64)hi) << 32) | lo) + ((((u64)h2) << 32) | l2);
+        lo = (u32)t; hi = (u32)(t >> 32);
+    }
+    return (((u64)hi) << 32) | lo;
+}

@@ -164,6 +164,11 @@ struct StreamOut {
 };
 
 // ---------------------------------------------------------------------------------- StreamIn ---
+// Look-ahead is TWO periods: the round requested in period k lands in period k+2 (two register sets
+// A/B alternate by period parity; `par` is a literal after unrolling), which covers HBM/MALL latency
+// with ~32 symbols of work.  A lane asks for its next segment as soon as its ring has room
+// (avail + in-flight <= 64), i.e. long before it runs dry; if a lane nevertheless gets low
+// (adversarial data: every symbol renormalising) the caller falls back to sync_refill().
 struct StreamIn {
     u8 *rings;           // this wave's ring array (LDS)
     u8 *sel;
@@ -171,62 +176,84 @@ struct StreamIn {
     u64 soff;            // this lane's stream start, bytes from gbase (2-byte aligned)
     u32 rpos;            // bytes consumed
     u32 lbytes;          // bytes committed to the ring
-    bool pend;           // this lane has a segment in flight
-    // helper-side state of the round in flight (this lane moves one 16-B piece for lane j)
-    uint4 hv; u32 hdst; bool hvalid;
+    u32 infl;            // segments requested for this lane and not yet committed (0..2)
+    bool mineA, mineB;   // ... and in which register set they travel
+    // helper side: this lane moves one 16-byte piece of some lane's segment, per register set
+    uint4 hvA, hvB; u32 hdA, hdB; bool hokA, hokB;
 
     __device__ __forceinline__ const u8 *myring() const { return rings + trc_lane() * TRC_SRING_STRIDE; }
     __device__ __forceinline__ u32 peek16() const { return *(const u16 *)(myring() + (rpos & (TRC_SRING - 1))); }
     __device__ __forceinline__ u32 peek32() const { return *(const u32 *)(myring() + (rpos & (TRC_SRING - 1))); }
     __device__ __forceinline__ u32 avail() const { return lbytes - rpos; }
 
-    // first fill: every live lane's first 128 bytes, 16 lanes per round, synchronous
+    // first fill: every live lane fetches its own first 128 bytes (8 independent loads, one round trip)
     __device__ __forceinline__ void prime(bool alive)
     {
-        rpos = 0; lbytes = 0; pend = false; hvalid = false;
-        for (int rep = 0; rep < 2; rep++) {
-            refill(alive, 1u << 30, true);
-            commit();
+        rpos = 0; lbytes = 0; infl = 0; mineA = mineB = false; hokA = hokB = false;
+        hvA = hvB = make_uint4(0, 0, 0, 0); hdA = hdB = 0;
+        if (alive) {
+            uint4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = trc_ld16_a2(gbase + soff + 16 * i);
+            u32 *d = (u32 *)(rings + trc_lane() * TRC_SRING_STRIDE);
+#pragma unroll
+            for (int i = 0; i < 8; i++) { d[4 * i] = v[i].x; d[4 * i + 1] = v[i].y; d[4 * i + 2] = v[i].z; d[4 * i + 3] = v[i].w; }
+            lbytes = TRC_SRING;
         }
     }
-    // land the round in flight (uniform point)
-    __device__ __forceinline__ void commit()
+    // land the round that travels in set `par` (requested two periods ago)
+    __device__ __forceinline__ void commit(int par)
     {
-        if (hvalid) {
-            u32 *d = (u32 *)(rings + hdst);
-            d[0] = hv.x; d[1] = hv.y; d[2] = hv.z; d[3] = hv.w;
-            hvalid = false;
+        if (par == 0) {
+            if (hokA) { u32 *d = (u32 *)(rings + hdA); d[0] = hvA.x; d[1] = hvA.y; d[2] = hvA.z; d[3] = hvA.w; hokA = false; }
+            if (mineA) { lbytes += TRC_SEG; infl--; mineA = false; }
+        } else {
+            if (hokB) { u32 *d = (u32 *)(rings + hdB); d[0] = hvB.x; d[1] = hvB.y; d[2] = hvB.z; d[3] = hvB.w; hokB = false; }
+            if (mineB) { lbytes += TRC_SEG; infl--; mineB = false; }
         }
-        if (pend) { lbytes += TRC_SEG; pend = false; }
     }
-    // request one more segment for lanes whose ring has room (avail <= 64): up to 16 lanes per
-    // round.  all = true drains every needy lane (synchronous rounds: used for priming/emergencies).
-    __device__ __forceinline__ void refill(bool alive, u32 thresh, bool all)
+    // request one more segment for up to 16 lanes whose ring has room, into register set `par`
+    __device__ __forceinline__ void refill(bool alive, int par)
     {
         const u32 lane = trc_lane();
-        bool needy = alive && !pend && avail() <= TRC_SEG && avail() <= thresh;
-        u64 mask = __ballot(needy);
-        while (mask) {
-            const u32 rank = trc_mbcnt(mask);
-            const bool pick = needy && rank < 16u;
-            if (pick) sel[rank] = (u8)lane;
-            const u32 cnt = (u32)__popcll(mask);
-            const u32 q = lane >> 2, part = (lane & 3u) << 4;
-            const u32 j = sel[q];
-            const u32 lb_j = (u32)__shfl((int)lbytes, (int)j, 64);
-            const u32 lo = (u32)__shfl((int)(u32)soff, (int)j, 64);
-            const u32 hi = (u32)__shfl((int)(u32)(soff >> 32), (int)j, 64);
-            if (q < cnt && q < 16u) {
-                const u8 *s = gbase + ((((u64)hi) << 32) | lo) + lb_j + part;
-                hv = trc_ld16_a2(s);
-                hdst = j * TRC_SRING_STRIDE + (lb_j & (TRC_SRING - 1)) + part;
-                hvalid = true;
-            }
-            if (pick) { pend = true; needy = false; }
-            if (!all) break;
-            commit();
-            needy = alive && avail() <= TRC_SEG;
-            mask = __ballot(needy);
+        const bool needy = alive && avail() + TRC_SEG * infl <= TRC_SEG;
+        const u64 mask = __ballot(needy);
+        if (!mask) return;
+        const u32 rank = trc_mbcnt(mask);
+        const bool pick = needy && rank < 16u;
+        if (pick) sel[rank] = (u8)lane;
+        const u32 cnt = (u32)__popcll(mask);
+        const u32 q = lane >> 2, part = (lane & 3u) << 4;
+        const u32 j = sel[q];
+        const u32 nx = lbytes + TRC_SEG * infl;                 // stream offset of this lane's next segment
+        const u32 nx_j = (u32)__shfl((int)nx, (int)j, 64);
+        const u32 lo = (u32)__shfl((int)(u32)soff, (int)j, 64);
+        const u32 hi = (u32)__shfl((int)(u32)(soff >> 32), (int)j, 64);
+        if (q < cnt && q < 16u) {
+            const u8 *s = gbase + ((((u64)hi) << 32) | lo) + nx_j + part;
+            const uint4 v = trc_ld16_a2(s);
+            const u32 dd = j * TRC_SRING_STRIDE + (nx_j & (TRC_SRING - 1)) + part;
+            if (par == 0) { hvA = v; hdA = dd; hokA = true; } else { hvB = v; hdB = dd; hokB = true; }
         }
+        if (pick) { infl++; if (par == 0) mineA = true; else mineB = true; }
+    }
+    // emergency: some lane is about to run dry.  Land everything in flight (older set first: at this
+    // point only set !par can still be in flight), then fill every ring synchronously.
+    __device__ __forceinline__ void sync_refill(bool alive, int par)
+    {
+        commit(par ^ 1);
+        for (;;) {
+            const bool needy = alive && avail() <= TRC_SEG;
+            if (!__ballot(needy)) break;
+            refill(alive, 0);
+            commit(0);
+        }
+    }
+    // the per-period protocol every decoder runs at a uniform point (<= 32 bytes consumed per period)
+    __device__ __forceinline__ void period(bool alive, int par)
+    {
+        commit(par);
+        if (__ballot(alive && avail() < 36u)) sync_refill(alive, par);
+        refill(alive, par);
     }
 };

@@ -8,7 +8,7 @@
 struct TrcWork {
     uint8_t  *tables;    // per-call coder tables derived from the CDF (static coders)
     uint32_t *gsum;      // per-group (64 chunks) payload bytes
-    uint64_t *goff;      // exclusive prefix of gsum, ngroups+1 entries
+    uint64_t *goff;      // exclusive prefix of gsum (ngroups+1 entries) when the scan kernel runs; NULL = kernels sum gsum themselves
     uint8_t  *scratch;   // encode only: per-chunk private output regions
     uint32_t  stride;    // bytes per scratch region
     uint8_t  *scratch2;  // second region array (RCS2: stream 1)
@@ -33,7 +33,7 @@ void trc_launch_scan_groups(const uint32_t *gsum, uint32_t ngroups, uint64_t *go
 // mode 2: [4 + len0 bytes at the start of region A][rest at the start of region B] (RCS2), len0 = u32 at region A.
 // Raw chunks (clen == chunk length) are copied from the input instead.
 void trc_launch_gather(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, int from_end,
-                       const uint32_t *d_clen, uint8_t *d_payload, hipStream_t s);
+                       const uint32_t *d_clen, uint8_t *d_payload, uint64_t *d_total, hipStream_t s);
 
 // ANS4S: static-CDF rANS (anscdf4senc / anscdf4sdec)
 void trc_launch_ans4s_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w,

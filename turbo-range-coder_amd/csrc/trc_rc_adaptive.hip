@@ -83,7 +83,7 @@ __global__ __launch_bounds__(64) void trc_rca_enc_kernel(
 }
 
 __global__ __launch_bounds__(64) void trc_rca_dec_kernel(
-    const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff,
+    const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
     u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(64) void trc_rca_dec_kernel(
     const u32 len = alive ? wc.len_of(lane) : 0u;
     const u32 cl = alive ? clen[c] : 0u;
     const u32 ex = trc_wave_incl_scan(cl) - cl;
-    const u64 off = goff[wc.c0 >> 6] + ex;
+    const u64 off = trc_group_base(goff, gsum, wc.c0 >> 6) + ex;
     const bool coded = alive && cl != len;
 
     TileOut tout; tout.tile = wbase; tout.base = out + (u64)wc.c0 * chunk;
@@ -131,9 +131,7 @@ __global__ __launch_bounds__(64) void trc_rca_dec_kernel(
 #pragma unroll
             for (int d = 0; d < 4; d++) {
                 const u32 q0 = p0 + (u32)d * 4u;
-                si.commit();
-                if (__ballot(coded && si.avail() < 36u)) si.refill(coded, 1u << 30, true);
-                si.refill(coded && q0 < len, TRC_SEG, false);
+                si.period(coded && q0 < len, d & 1);
                 if (coded && q0 < len) {
                     const u32 nb = len - q0 < 4u ? len - q0 : 4u;
                     for (u32 i = 0; i < nb; i++) {
@@ -172,5 +170,5 @@ void trc_launch_rca_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void *)trc_rca_dec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RCA_WAVE_LDS); attr = true; }
     hipLaunchKernelGGL(trc_rca_dec_kernel, dim3(w.ngroups), dim3(64), RCA_WAVE_LDS, s,
-                       d_payload, d_clen, w.goff, (u64)n, chunk, w.nchunks, d_out);
+                       d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, d_out);
 }

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64) void trc_rcs_enc_kernel(
 
 template <int NS, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void trc_rcs_dec_kernel(
-    const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff,
+    const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
     u64 n, u32 chunk, u32 nchunks, const u8 *__restrict__ lut_g, const u32 *__restrict__ tab_g, u8 *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(BLOCK) void trc_rcs_dec_kernel(
     const u32 len = alive ? wc.len_of(lane) : 0u;
     const u32 cl = alive ? clen[c] : 0u;
     const u32 ex = trc_wave_incl_scan(cl) - cl;
-    const u64 off = goff[wc.c0 >> 6] + ex;
+    const u64 off = trc_group_base(goff, gsum, wc.c0 >> 6) + ex;
     const bool coded = alive && cl != len;
 
     TileOut tout; tout.tile = wbase; tout.base = out + (u64)wc.c0 * chunk;
@@ -169,14 +169,8 @@ __global__ __launch_bounds__(BLOCK) void trc_rcs_dec_kernel(
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const u32 p0 = s * TRC_SEG + (u32)k * 16u;
-            s0.commit();
-            if (__ballot(coded && s0.avail() < 36u)) s0.refill(coded, 1u << 30, true);
-            s0.refill(coded && p0 < len, TRC_SEG, false);
-            if (NS == 2) {
-                s1.commit();
-                if (__ballot(coded && s1.avail() < 36u)) s1.refill(coded, 1u << 30, true);
-                s1.refill(coded && p0 < len, TRC_SEG, false);
-            }
+            s0.period(coded && p0 < len, k & 1);
+            if (NS == 2) s1.period(coded && p0 < len, k & 1);
             if (coded && p0 + 16u <= len) {
                 u32 w[4];
 #pragma unroll
@@ -226,7 +220,7 @@ static void launch_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t 
     if (!attr) { (void)hipFuncSetAttribute((const void *)trc_rcs_dec_kernel<NS, BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr = true; }
     const u32 wpb = BLOCK / 64;
     hipLaunchKernelGGL((trc_rcs_dec_kernel<NS, BLOCK>), dim3((w.ngroups + wpb - 1) / wpb), dim3(BLOCK), sm, s,
-                       d_payload, d_clen, w.goff, (u64)n, chunk, w.nchunks, w.tables + TRC_TAB_LUT,
+                       d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, w.tables + TRC_TAB_LUT,
                        (const u32 *)(w.tables + TRC_TAB_DEC), d_out);
 }
 void trc_launch_rcs_dec(int nstreams, const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
