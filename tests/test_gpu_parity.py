@@ -170,6 +170,47 @@ def test_baseline_size_properties(torch_cuda, codec):
         assert clen[c] == exp.size and np.array_equal(payload[off[c]:off[c + 1]], exp), "chunk %d" % c
 
 
+@pytest.mark.parametrize("codec", [trc.ANS4S, trc.RCS1], ids=lambda c: trc.CODEC_NAMES[c])
+def test_many_groups_uses_scan_kernel(torch_cuda, codec):
+    """> 8192 groups of 64 chunks: the directory goes through the single-workgroup scan kernel instead of
+    in-kernel group sums (150 MB at chunk 256 = 9156 groups)"""
+    torch = torch_cuda
+    n, chunk = 150 * 1000 * 1000, 256
+    d = gen("zipf", n, 21)
+    _, cdf, cdfnum = T.orc_cdfini(d)
+    dc = trc.DeviceCoder(codec, n, chunk, "cuda:0")
+    dc.set_cdf(cdf, cdfnum)
+    d_in = to_dev(torch, d)
+    dc.encode(d_in, n)
+    d_out = torch.zeros(n + 512, dtype=torch.uint8, device="cuda:0")
+    dc.decode(d_out, n)
+    torch.cuda.synchronize()
+    assert torch.equal(d_out[:n], d_in[:n])
+    nch = trc.nchunks(n, chunk)
+    clen = dc.clen[:nch].cpu().numpy().view(np.uint32).astype(np.int64)
+    total = int(dc.total[0].item())
+    assert clen.sum() == total
+    off = np.concatenate([[0], np.cumsum(clen)])
+    payload = dc.payload[:total].cpu().numpy()
+    for c in [0, 1, 63, 64, 8192 * 64 - 1, 8192 * 64, nch - 1] + list(np.random.default_rng(1).integers(0, nch, 20)):
+        exp = T.orc_enc(codec, d[c * chunk:(c + 1) * chunk], cdf, cdfnum)
+        assert clen[c] == exp.size and np.array_equal(payload[off[c]:off[c + 1]], exp), "chunk %d" % c
+
+
+def test_device_layer_rejects_bad_arguments(torch_cuda):
+    torch = torch_cuda
+    l = trc.lib()
+    buf = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda:0")
+    p = buf.data_ptr()
+    wb = l.trc_work_bytes(trc.RCB, 4096, 4096)
+    assert l.trc_encode_dev(trc.RCB, p + 1, 4096, 4096, None, 0, p + 8192, p + 16384, p + 32768, p + 65536, wb, None) == -1     # misaligned input
+    assert l.trc_encode_dev(trc.RCB, p, 4096, 100, None, 0, p + 8192, p + 16384, p + 32768, p + 65536, wb, None) == -1        # bad chunk
+    assert l.trc_encode_dev(trc.RCB, p, 4096, 4096, None, 0, p + 8192, p + 16384, p + 32768, p + 65536, 16, None) == -3        # workspace too small
+    assert l.trc_encode_dev(trc.ANS4S, p, 4096, 4096, None, 0, p + 8192, p + 16384, p + 32768, p + 65536, wb, None) == -4      # static coder without CDF
+    assert l.trc_encode_dev(99, p, 4096, 4096, None, 0, p + 8192, p + 16384, p + 32768, p + 65536, wb, None) == -1             # unknown codec
+    assert b"codec" in l.trc_last_error()
+
+
 def test_c_harness_links_and_roundtrips(torch_cuda):
     """the plain-C TurboRC-style harness (harness/trcbench.c: only include/turborc.h + anscdf.h) round-trips
     every hot-path id through the reference-named functions with host pointers"""

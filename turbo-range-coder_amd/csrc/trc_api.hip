@@ -185,6 +185,8 @@ extern "C" int trc_encode_dev(int codec, const void *d_in, size_t n, uint32_t ch
     int rc = check_common(codec, n, chunk, d_cdf, cdfnum);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
+    if (((uintptr_t)d_in & 15) || ((uintptr_t)d_clen & 3) || ((uintptr_t)d_payload & 1) || ((uintptr_t)d_total & 7))
+        return fail(TRC_E_ARG, "encode: d_in must be 16-byte, d_clen 4-byte, d_payload 2-byte, d_total 8-byte aligned");
     if (n == 0) { HIPCHK(hipMemsetAsync(d_total, 0, 8, s)); return TRC_OK; }
     TrcWork w;
     if ((rc = carve(codec, n, chunk, d_work, work_bytes, w))) return rc;
@@ -213,6 +215,8 @@ extern "C" int trc_decode_dev(int codec, const uint32_t *d_clen, const void *d_p
     int rc = check_common(codec, n, chunk, d_cdf, cdfnum);
     if (rc) return rc;
     if (n == 0) return TRC_OK;
+    if (((uintptr_t)d_out & 15) || ((uintptr_t)d_clen & 3) || ((uintptr_t)d_payload & 1))
+        return fail(TRC_E_ARG, "decode: d_out must be 16-byte, d_clen 4-byte, d_payload 2-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     TrcWork w;
     if ((rc = carve(codec, n, chunk, d_work, work_bytes, w))) return rc;
