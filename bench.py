@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=32 * 1000 * 1000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the exchange code even with 1 rank (self-test)")
     args = ap.parse_args()
 
     import torch
@@ -109,9 +110,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     codec = {v: k for k, v in trc.CODEC_NAMES.items()}[args.codec]
@@ -121,7 +124,7 @@ def main():
     dc = trc.DeviceCoder(codec, n, chunk, dev)
     cdfnum = 256
     if codec in trc.STATIC:                                # untimed, like the reference harness (turborc.c:429-433)
-        if world > 1:                                      # one CDF for the whole job: all-reduce the 256-bin histogram
+        if use_dist:                                       # one CDF for the whole job: all-reduce the 256-bin histogram
             hist = torch.zeros(256, dtype=torch.int64, device=dev)
             dc.hist(d_in, n, hist)
             shard.allreduce_hist(dist, hist)
@@ -146,7 +149,7 @@ def main():
 
     def step():
         dc.encode(d_in, n)
-        if world > 1:
+        if use_dist:
             exchange()
         dc.decode(d_out, n)
 
@@ -157,14 +160,14 @@ def main():
         assert torch.equal(d_out[:n], d_in[:n]), "round trip failed"
 
     trc.timing_enable(True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
@@ -172,7 +175,7 @@ def main():
     dec_ms, dec_cnt = trc.timing_read(True)
     trc.timing_enable(False)
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -217,7 +220,7 @@ def main():
             cdf_full = np.zeros(257, dtype=np.uint16); cdf_full[:cdfnum + 1] = cdf
             res["cpu_baseline"] = cpu_baseline(d, cdf_full, cdfnum, min(args.cpu_sample, n))
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -27,6 +27,19 @@
 #define TRC_SRING_BYTES  (64u * TRC_SRING_STRIDE)           // 8448 per wave
 #define TRC_SEL_BYTES    64u      // per-wave scratch for the rank -> lane table
 
+// Byte address, inside one wave's ring array, of ring offset `off` (0..127) of lane `lane`.
+//   default: lane-major rows of 132 bytes (33 dwords: conflict-free while lanes sit at equal offsets,
+//     ~3-way conflicts once the data-dependent offsets drift apart).
+//   TRC_RING_INTERLEAVED: dword d of every lane's ring in row d -> ((off>>2)*64 + lane)*4 + (off&3): never
+//     conflicts, but costs one more VALU op per access.  Measured on MI355X (same box, interleaved runs):
+//     decode 124 vs 113 us, encode 101 vs 99 us in favour of the linear form -- the ring is not where the
+//     LDS conflict cycles come from (the random table reads are).
+#ifdef TRC_RING_INTERLEAVED
+__device__ __forceinline__ u32 trc_raddr(u32 lane, u32 off) { return (((off & 0x7cu) << 6) | (off & 3u)) + (lane << 2); }
+#else
+__device__ __forceinline__ u32 trc_raddr(u32 lane, u32 off) { return lane * TRC_SRING_STRIDE + off; }
+#endif
+
 __device__ __forceinline__ u32 trc_mbcnt(u64 mask)   // number of set bits of mask below this lane
 {
     return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
@@ -100,8 +113,7 @@ struct StreamOut {
     u32 wpos;            // bytes appended by this lane so far
     u32 nfl;             // 64-byte segments already moved to the region
 
-    __device__ __forceinline__ u8 *myring() const { return rings + trc_lane() * TRC_SRING_STRIDE; }
-    // ring address of the unit that starts at stream position p
+    // ring offset of the unit that starts at stream position p
     __device__ __forceinline__ u32 roff16(u32 p) const { return DOWN ? ((0u - (p + 2u)) & (TRC_SRING - 1)) : (p & (TRC_SRING - 1)); }
     __device__ __forceinline__ u32 roff32(u32 p) const { return DOWN ? ((0u - (p + 4u)) & (TRC_SRING - 1)) : (p & (TRC_SRING - 1)); }
     // speculative append: the slot of the next unit is always free, so write unconditionally and
@@ -109,12 +121,12 @@ struct StreamOut {
     __device__ __forceinline__ void put16_if(bool take, u32 v)
     {
 #ifndef TRC_ABL_NOWRITE
-        *(u16 *)(myring() + roff16(wpos)) = (u16)v;
+        *(u16 *)(rings + trc_raddr(trc_lane(), roff16(wpos))) = (u16)v;
 #endif
         wpos += take ? 2u : 0u;
     }
-    __device__ __forceinline__ void put16(u32 v) { *(u16 *)(myring() + roff16(wpos)) = (u16)v; wpos += 2; }
-    __device__ __forceinline__ void put32(u32 v) { *(u32 *)(myring() + roff32(wpos)) = v; wpos += 4; }
+    __device__ __forceinline__ void put16(u32 v) { *(u16 *)(rings + trc_raddr(trc_lane(), roff16(wpos))) = (u16)v; wpos += 2; }
+    __device__ __forceinline__ void put32(u32 v) { *(u32 *)(rings + trc_raddr(trc_lane(), roff32(wpos))) = v; wpos += 4; }
 
     __device__ __forceinline__ u32 pending() const { return wpos - TRC_SEG * nfl; }
     // one lane moving its own oldest segment to the region (bursts only: runs of 0xFFFFFFFF words
@@ -122,10 +134,9 @@ struct StreamOut {
     __device__ __forceinline__ void self_drain()
     {
         const u32 ro = DOWN ? ((0u - TRC_SEG * (nfl + 1u)) & (TRC_SRING - 1)) : ((TRC_SEG * nfl) & (TRC_SRING - 1));
-        const u32 *s = (const u32 *)(myring() + ro);
         u8 *reg = scratch + (size_t)(c0 + trc_lane()) * stride;
         u8 *d = DOWN ? reg + stride - (size_t)TRC_SEG * (nfl + 1u) : reg + (size_t)TRC_SEG * nfl;
-        for (int i = 0; i < 4; i++) ((uint4 *)d)[i] = make_uint4(s[4 * i], s[4 * i + 1], s[4 * i + 2], s[4 * i + 3]);
+        for (u32 i = 0; i < 16; i++) ((u32 *)d)[i] = *(const u32 *)(rings + trc_raddr(trc_lane(), ro + 4u * i));
         nfl++;
     }
     __device__ __forceinline__ void put32_slow(u32 v)
@@ -152,10 +163,11 @@ struct StreamOut {
             const u32 nfl_j = (u32)__shfl((int)nfl, (int)j, 64);
             if (q < cnt && q < 16u) {
                 const u32 ro = DOWN ? ((0u - TRC_SEG * (nfl_j + 1u)) & (TRC_SRING - 1)) : ((TRC_SEG * nfl_j) & (TRC_SRING - 1));
-                const u32 *s = (const u32 *)(rings + j * TRC_SRING_STRIDE + ro + part);
+                const u32 s0 = *(const u32 *)(rings + trc_raddr(j, ro + part)), s1 = *(const u32 *)(rings + trc_raddr(j, ro + part + 4u));
+                const u32 s2 = *(const u32 *)(rings + trc_raddr(j, ro + part + 8u)), s3 = *(const u32 *)(rings + trc_raddr(j, ro + part + 12u));
                 u8 *reg = scratch + (size_t)(c0 + j) * stride;
                 u8 *d = DOWN ? reg + stride - (size_t)TRC_SEG * (nfl_j + 1u) + part : reg + (size_t)TRC_SEG * nfl_j + part;
-                *(uint4 *)d = make_uint4(s[0], s[1], s[2], s[3]);
+                *(uint4 *)d = make_uint4(s0, s1, s2, s3);
             }
             if (pick) { nfl++; ready = final ? (wpos > TRC_SEG * nfl) : pending() >= TRC_SEG; }
             mask = __ballot(ready);
@@ -181,9 +193,8 @@ struct StreamIn {
     // helper side: this lane moves one 16-byte piece of some lane's segment, per register set
     uint4 hvA, hvB; u32 hdA, hdB; bool hokA, hokB;
 
-    __device__ __forceinline__ const u8 *myring() const { return rings + trc_lane() * TRC_SRING_STRIDE; }
-    __device__ __forceinline__ u32 peek16() const { return *(const u16 *)(myring() + (rpos & (TRC_SRING - 1))); }
-    __device__ __forceinline__ u32 peek32() const { return *(const u32 *)(myring() + (rpos & (TRC_SRING - 1))); }
+    __device__ __forceinline__ u32 peek16() const { return *(const u16 *)(rings + trc_raddr(trc_lane(), rpos & (TRC_SRING - 1))); }
+    __device__ __forceinline__ u32 peek32() const { return *(const u32 *)(rings + trc_raddr(trc_lane(), rpos & (TRC_SRING - 1))); }
     __device__ __forceinline__ u32 avail() const { return lbytes - rpos; }
 
     // first fill: every live lane fetches its own first 128 bytes (8 independent loads, one round trip)
@@ -195,20 +206,29 @@ struct StreamIn {
             uint4 v[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) v[i] = trc_ld16_a2(gbase + soff + 16 * i);
-            u32 *d = (u32 *)(rings + trc_lane() * TRC_SRING_STRIDE);
 #pragma unroll
-            for (int i = 0; i < 8; i++) { d[4 * i] = v[i].x; d[4 * i + 1] = v[i].y; d[4 * i + 2] = v[i].z; d[4 * i + 3] = v[i].w; }
+            for (int i = 0; i < 8; i++) {
+                *(u32 *)(rings + trc_raddr(trc_lane(), 16u * i)) = v[i].x;      *(u32 *)(rings + trc_raddr(trc_lane(), 16u * i + 4u)) = v[i].y;
+                *(u32 *)(rings + trc_raddr(trc_lane(), 16u * i + 8u)) = v[i].z; *(u32 *)(rings + trc_raddr(trc_lane(), 16u * i + 12u)) = v[i].w;
+            }
             lbytes = TRC_SRING;
         }
+    }
+    // hd = lane<<8 | ring offset of the 16-byte piece
+    __device__ __forceinline__ void put_piece(u32 hd, uint4 v)
+    {
+        const u32 j = hd >> 8, o = hd & 0xffu;
+        *(u32 *)(rings + trc_raddr(j, o)) = v.x;      *(u32 *)(rings + trc_raddr(j, o + 4u)) = v.y;
+        *(u32 *)(rings + trc_raddr(j, o + 8u)) = v.z; *(u32 *)(rings + trc_raddr(j, o + 12u)) = v.w;
     }
     // land the round that travels in set `par` (requested two periods ago)
     __device__ __forceinline__ void commit(int par)
     {
         if (par == 0) {
-            if (hokA) { u32 *d = (u32 *)(rings + hdA); d[0] = hvA.x; d[1] = hvA.y; d[2] = hvA.z; d[3] = hvA.w; hokA = false; }
+            if (hokA) { put_piece(hdA, hvA); hokA = false; }
             if (mineA) { lbytes += TRC_SEG; infl--; mineA = false; }
         } else {
-            if (hokB) { u32 *d = (u32 *)(rings + hdB); d[0] = hvB.x; d[1] = hvB.y; d[2] = hvB.z; d[3] = hvB.w; hokB = false; }
+            if (hokB) { put_piece(hdB, hvB); hokB = false; }
             if (mineB) { lbytes += TRC_SEG; infl--; mineB = false; }
         }
     }
@@ -232,7 +252,7 @@ struct StreamIn {
         if (q < cnt && q < 16u) {
             const u8 *s = gbase + ((((u64)hi) << 32) | lo) + nx_j + part;
             const uint4 v = trc_ld16_a2(s);
-            const u32 dd = j * TRC_SRING_STRIDE + (nx_j & (TRC_SRING - 1)) + part;
+            const u32 dd = (j << 8) | ((nx_j & (TRC_SRING - 1)) + part);
             if (par == 0) { hvA = v; hdA = dd; hokA = true; } else { hvB = v; hdB = dd; hokB = true; }
         }
         if (pick) { infl++; if (par == 0) mineA = true; else mineB = true; }
