@@ -48,35 +48,53 @@ def make_input(n, rank):
 
 
 def cpu_baseline(d, cdf, cdfnum, sample):
-    """1-thread CPU timing on d[:sample]: reference anscdf4senc (oracle/_ref) when present, decode by
-    the oracle port (the reference has no byte-alphabet static-rANS decoder); plus the
-    literal `turborc -e45` pair rccdfs2enc/rccdfsb2dec for context."""
+    """CPU timing of the same workload on this box's host cores.
+
+    value      all host threads, shard-parallel: the buffer is cut into one shard per thread and every
+               thread runs the whole-buffer reference call on its shard (ctypes releases the GIL)
+    one_thread the reference's own regime (1 thread, whole-buffer call on the first `sample` bytes)
+    encode = reference anscdf4senc (oracle/_ref) when present, else the oracle port; decode = oracle port
+    orc_anscdf4sdec (the reference has no byte-alphabet static-rANS decoder); the literal
+    `turborc -e45` pair rccdfs2enc/rccdfsb2dec (all reference) is listed for context."""
+    import concurrent.futures as cf
     import trc_testlib as T
-    s = np.ascontiguousarray(d[:sample])
-    out = {"cores": 1, "unit": "MB/s"}
     use_ref = T.have_ref()
+    enc = (lambda x: T.ref_enc(T.ANS4S, x, cdf, cdfnum)) if use_ref else (lambda x: T.orc_enc(T.ANS4S, x, cdf, cdfnum))
+    out = {"unit": "MB/s", "kind": "reference" if use_ref else "port"}
+
+    s = np.ascontiguousarray(d[:sample])
     best_e = best_d = 1e9
     for _ in range(2):
-        t0 = time.perf_counter()
-        comp = T.ref_enc(T.ANS4S, s, cdf, cdfnum) if use_ref else T.orc_enc(T.ANS4S, s, cdf, cdfnum)
-        t1 = time.perf_counter()
-        dec = T.orc_dec(T.ANS4S, comp, s.size, cdf, cdfnum)
-        t2 = time.perf_counter()
+        t0 = time.perf_counter(); comp = enc(s); t1 = time.perf_counter()
+        dec = T.orc_dec(T.ANS4S, comp, s.size, cdf, cdfnum); t2 = time.perf_counter()
         best_e, best_d = min(best_e, t1 - t0), min(best_d, t2 - t1)
     assert np.array_equal(dec, s)
-    out["value"] = round(s.size / (best_e + best_d) / 1e6, 2)
-    out["enc_MBps"] = round(s.size / best_e / 1e6, 2)
-    out["dec_MBps"] = round(s.size / best_d / 1e6, 2)
-    out["kind"] = "reference" if use_ref else "port"
-    out["sample"] = ("first %d bytes of the workload, whole-buffer call, min of 2 runs; encode = %s anscdf4senc, "
-                     "decode = oracle port orc_anscdf4sdec (no byte-alphabet decoder exists in the reference)"
-                     % (s.size, "reference" if use_ref else "oracle port"))
+    one = {"cores": 1, "encdec_MBps": round(s.size / (best_e + best_d) / 1e6, 2), "enc_MBps": round(s.size / best_e / 1e6, 2),
+           "dec_MBps": round(s.size / best_d / 1e6, 2), "sample_bytes": int(s.size)}
     if use_ref:
         t0 = time.perf_counter(); c45 = T.ref_enc(T.RCS2, s, cdf, cdfnum); t1 = time.perf_counter()
         d45 = T.ref_dec(T.RCS2, c45, s.size, cdf, cdfnum); t2 = time.perf_counter()
         assert np.array_equal(d45, s)
-        out["e45_reference_MBps"] = {"enc": round(s.size / (t1 - t0) / 1e6, 2), "dec": round(s.size / (t2 - t1) / 1e6, 2),
+        one["e45_reference_MBps"] = {"enc": round(s.size / (t1 - t0) / 1e6, 2), "dec": round(s.size / (t2 - t1) / 1e6, 2),
                                      "encdec": round(s.size / (t2 - t0) / 1e6, 2)}
+    out["one_thread"] = one
+
+    nthr = max(1, os.cpu_count() or 1)
+    n = d.size
+    per = (n + nthr - 1) // nthr
+    shards = [np.ascontiguousarray(d[i:i + per]) for i in range(0, n, per)]
+    with cf.ThreadPoolExecutor(nthr) as ex:
+        list(ex.map(lambda x: x.sum(), shards))                        # spin the pool up
+        t0 = time.perf_counter(); comps = list(ex.map(enc, shards)); t1 = time.perf_counter()
+        decs = list(ex.map(lambda cx: T.orc_dec(T.ANS4S, cx[0], cx[1].size, cdf, cdfnum), zip(comps, shards))); t2 = time.perf_counter()
+    assert all(np.array_equal(a, b) for a, b in zip(decs, shards))
+    out["value"] = round(n / (t2 - t0) / 1e6, 1)
+    out["enc_MBps"] = round(n / (t1 - t0) / 1e6, 1)
+    out["dec_MBps"] = round(n / (t2 - t1) / 1e6, 1)
+    out["cores"] = nthr
+    out["sample"] = ("whole workload (%d B) cut into %d shards, one whole-buffer call per thread on %d host threads; encode = %s "
+                     "anscdf4senc, decode = oracle port orc_anscdf4sdec; one_thread = first %d B, min of 2 runs"
+                     % (n, len(shards), nthr, "reference" if use_ref else "oracle port", s.size))
     return out
 
 

@@ -68,7 +68,9 @@ struct TileIn {
         for (int j = 0; j < 4; j++) {
             u32 row = (u32)j * 16u + (lane >> 2);
             row = row < w.rows ? row : w.rows - 1;
-            r[j] = *(const uint4 *)(base + (size_t)row * w.chunk + segoff + part);
+            // a short last chunk has no bytes in its upper segments: never read past the input's pad
+            const u32 so = segoff < w.len_of(row) ? segoff : 0u;
+            r[j] = *(const uint4 *)(base + (size_t)row * w.chunk + so + part);
         }
     }
     __device__ __forceinline__ void commit()
