@@ -217,7 +217,8 @@ def main():
             except Exception:
                 traffic = None
         res = {
-            "metric": "encode+decode MB/s, order-0 static-CDF rANS, 100 MB bytes",
+            "metric": ("encode+decode MB/s, order-0 static-CDF rANS, 100 MB bytes" if args.codec == "anscdf4s"
+                       else "encode+decode MB/s, %s, %d bytes" % (args.codec, n)),
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",

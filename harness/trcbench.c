@@ -9,7 +9,7 @@
  * device-resident numbers come from bench.py.
  *
  *   trcbench [-e id[,id..]] [-I runs] [-c chunk] (file | --zipf N | --text N | --uniform N)
- * ids: 1 rcs | 42 cdfsb | 43 cdfsv | 45 cdfs2 | 46 cdf | 56 ans | 57 ans(s) | 58 ans(x) | 65 ans4s | 79 memcpy
+ * ids: 1 rcs | 42 cdfsb | 43 cdfsv | 45 cdfs2 | 46 cdf | 47 cdfi | 56 ans | 57 ans(s) | 58 ans(x) | 65 ans4s | 79 memcpy
  */
 #include <math.h>
 #include <stdio.h>
@@ -65,6 +65,7 @@ static int bench(unsigned char *in, size_t n, unsigned char *out, unsigned char 
     case 43: name = "cdfsv (rccdfsenc/rccdfsvbdec)"; e5 = rccdfsenc; d5 = rccdfsvbdec; break;
     case 45: name = "cdfsb interleaved (rccdfs2enc/rccdfsb2dec)"; e5 = rccdfs2enc; d5 = rccdfsb2dec; break;
     case 46: name = "cdf byte adaptive (rccdfenc/rccdfdec)"; e3 = rccdfenc; d3 = rccdfdec; break;
+    case 47: name = "cdfi byte adaptive interleaved (rccdfienc/rccdfidec)"; e3 = rccdfienc; d3 = rccdfidec; break;
     case 56: name = "ans auto (anscdfenc/anscdfdec)"; e3 = anscdfenc; d3 = anscdfdec; break;
     case 57: name = "ans s (anscdfencs/anscdfdecs)"; e3 = anscdfencs; d3 = anscdfdecs; break;
     case 58: name = "ans x (anscdfencx/anscdfdecx)"; e3 = anscdfencx; d3 = anscdfdecx; break;
@@ -103,7 +104,7 @@ static int bench(unsigned char *in, size_t n, unsigned char *out, unsigned char 
 
 int main(int argc, char **argv)
 {
-    const char *ids = "1,42,45,46,56,65,79", *file = 0;
+    const char *ids = "1,42,45,46,47,56,65,79", *file = 0;
     int runs = 3, kind = -1;
     size_t n = 0;
     for (int i = 1; i < argc; i++) {

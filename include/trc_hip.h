@@ -39,7 +39,8 @@ enum trc_codec {
     TRC_RCS2  = 3,  /* rccdfs2enc  / rccdfs*2dec   static-CDF RC, 2 streams       rccdf.c:125-184  (-e45) */
     TRC_RCA   = 4,  /* rccdfenc    / rccdfdec      adaptive-CDF byte RC           rccdf.c:187-211  (-e46) */
     TRC_ANSA  = 5,  /* anscdfenc   / anscdfdec     adaptive-CDF byte rANS, 4 st.  anscdf.c:567-605 (-e56) */
-    TRC_RCB   = 6   /* rcsenc      / rcsdec        bitwise order-0 RC             rc_.c:37-58      (-e1)  */
+    TRC_RCB   = 6,  /* rcsenc      / rcsdec        bitwise order-0 RC             rc_.c:37-58      (-e1)  */
+    TRC_RCAI  = 7   /* rccdfienc   / rccdfidec     adaptive-CDF byte RC, 2 streams rccdf.c:213-249 (-e47) */
 };
 
 #define TRC_MAGIC        0x31435254u   /* "TRC1" */

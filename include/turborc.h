@@ -51,6 +51,11 @@ size_t rccdfsb2dec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *
 size_t rccdfenc(unsigned char *in, size_t inlen, unsigned char *out);
 size_t rccdfdec(unsigned char *in, size_t outlen, unsigned char *out);
 
+/* adaptive-CDF byte range coder, hi nibbles on stream 0 / lo nibbles on stream 1 (reference rccdf.c:213-249,
+ * include/turborc.h:515-516; `turborc -e47`) */
+size_t rccdfienc(unsigned char *in, size_t inlen, unsigned char *out);
+size_t rccdfidec(unsigned char *in, size_t outlen, unsigned char *out);
+
 /* bitwise order-0 range coder, "s" predictor (reference rc_.c:37-58; `turborc -e1`, file codec 1) */
 size_t rcsenc(unsigned char *in, size_t inlen, unsigned char *out);
 size_t rcsdec(unsigned char *in, size_t outlen, unsigned char *out);

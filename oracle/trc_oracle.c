@@ -261,6 +261,48 @@ size_t orc_rccdfdec(const uint8_t *in, size_t outlen, uint8_t *out)
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* rccdfienc / rccdfidec (rccdf.c:213-249; cdf8e2/cdf8d2 rccdf_.h:35-40,64-76), */
+/* `turborc -e47`: hi nibbles -> stream 0, lo nibbles -> stream 1 (base out+4+inlen/2), one model. */
+/* OVERFLOWI after every full group of 4 bytes only; both streams are written into `out` itself   */
+/* exactly as the reference does (out needs inlen + 64 bytes).                                     */
+size_t orc_rccdfienc(const uint8_t *in, size_t inlen, uint8_t *out)
+{
+    nibmodel_t m; nib_reset(&m);
+    uint8_t *base0 = out + 4, *base1 = out + 4 + inlen / 2;
+    rce_t e0, e1; rce_start(&e0, base0); rce_start(&e1, base1);
+    size_t i = 0, groups = inlen & ~(size_t)3;
+    for (; i < inlen; i++) {
+        unsigned h = in[i] >> 4, l = in[i] & 15;
+        rce_sym(&e0, m.hi[h], m.hi[h + 1]);       nib_adapt(m.hi, h);
+        uint16_t *t = m.lo[h];
+        rce_sym(&e1, t[l], t[l + 1]);             nib_adapt(t, l);
+        if (i < groups && (i & 3) == 3)
+            if (rc_overflow((size_t)(e1.op - out), inlen) || e0.op >= base1) { memcpy(out, in, inlen); return inlen; }
+    }
+    rce_finish(&e0);
+    rce_finish(&e1);
+    size_t len0 = (size_t)(e0.op - base0), len1 = (size_t)(e1.op - base1);
+    st32(out, (uint32_t)len0);
+    memmove(e0.op, base1, len1);
+    size_t total = 4 + len0 + len1;
+    if (rc_overflow(total, inlen)) { memcpy(out, in, inlen); return inlen; }
+    return total;
+}
+size_t orc_rccdfidec(const uint8_t *in, size_t outlen, uint8_t *out)
+{
+    nibmodel_t m; nib_reset(&m);
+    rcd_t d0, d1;
+    rcd_start(&d0, in + 4);
+    rcd_start(&d1, in + 4 + ld32(in));
+    for (size_t i = 0; i < outlen; i++) {
+        unsigned h = rcd_nibble(&d0, m.hi);
+        unsigned l = rcd_nibble(&d1, m.lo[h]);
+        out[i] = (uint8_t)(h << 4 | l);
+    }
+    return outlen;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* M6  32-bit rANS core, 16-bit renorm, 15-bit scale (anscdf_.h:33-48,90-94)                   */
 #define ANS_LO (1u << 15)
 static inline void ans_put(uint32_t *st, uint32_t c0, uint32_t f, uint8_t **ep)
@@ -464,6 +506,7 @@ static size_t enc_one(int codec, const uint8_t *in, size_t n, uint8_t *out, cons
     case ORC_RCA:   return orc_rccdfenc(in, n, out);
     case ORC_ANSA:  return orc_anscdfenc(in, n, out);
     case ORC_RCB:   return orc_rcsenc(in, n, out);
+    case ORC_RCAI:  return orc_rccdfienc(in, n, out);
     }
     return 0;
 }
@@ -476,6 +519,7 @@ static void dec_one(int codec, const uint8_t *in, size_t n, uint8_t *out, const 
     case ORC_RCA:   orc_rccdfdec(in, n, out); break;
     case ORC_ANSA:  orc_anscdfdec(in, n, out); break;
     case ORC_RCB:   orc_rcsdec(in, n, out); break;
+    case ORC_RCAI:  orc_rccdfidec(in, n, out); break;
     }
 }
 size_t orc_chunked_enc(int codec, const uint8_t *in, size_t n, size_t chunk,

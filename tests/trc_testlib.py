@@ -18,8 +18,8 @@ ORACLE_SO = os.path.join(ORACLE_DIR, "libtrc_oracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libtrc_ref.so")
 
 # codec ids == include/trc_hip.h == oracle/trc_oracle.h
-ANS4S, RCS1, RCS2, RCA, ANSA, RCB = 1, 2, 3, 4, 5, 6
-CODEC_NAMES = {ANS4S: "anscdf4s", RCS1: "rccdfs", RCS2: "rccdfs2", RCA: "rccdf", ANSA: "anscdf", RCB: "rcs"}
+ANS4S, RCS1, RCS2, RCA, ANSA, RCB, RCAI = 1, 2, 3, 4, 5, 6, 7
+CODEC_NAMES = {ANS4S: "anscdf4s", RCS1: "rccdfs", RCS2: "rccdfs2", RCA: "rccdf", ANSA: "anscdf", RCB: "rcs", RCAI: "rccdfi"}
 STATIC_CODECS = (ANS4S, RCS1, RCS2)
 
 _u8p = C.POINTER(C.c_uint8)
@@ -112,7 +112,7 @@ def oracle():
             f = getattr(lib, name); f.restype = sz; f.argtypes = [_u8p, sz, _u8p, _u16p, C.c_uint]
         lib.orc_anscdf4senc.restype = sz; lib.orc_anscdf4senc.argtypes = [_u8p, sz, _u8p, _u16p]
         lib.orc_anscdf4sdec.restype = sz; lib.orc_anscdf4sdec.argtypes = [_u8p, sz, _u8p, _u16p, C.c_uint]
-        for name in ("orc_rccdfenc", "orc_rccdfdec", "orc_anscdfenc", "orc_anscdfdec", "orc_rcsenc", "orc_rcsdec"):
+        for name in ("orc_rccdfenc", "orc_rccdfdec", "orc_anscdfenc", "orc_anscdfdec", "orc_rcsenc", "orc_rcsdec", "orc_rccdfienc", "orc_rccdfidec"):
             f = getattr(lib, name); f.restype = sz; f.argtypes = [_u8p, sz, _u8p]
         lib.orc_chunked_enc.restype = sz
         lib.orc_chunked_enc.argtypes = [C.c_int, _u8p, sz, sz, _u16p, C.c_uint, _u8p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
@@ -157,6 +157,8 @@ def orc_enc(codec, data, cdf=None, cdfnum=256):
         l = o.orc_anscdfenc(_p8(data), n, _p8(out))
     elif codec == RCB:
         l = o.orc_rcsenc(_p8(data), n, _p8(out))
+    elif codec == RCAI:
+        l = o.orc_rccdfienc(_p8(data), n, _p8(out))
     else:
         raise ValueError(codec)
     return out[:l].copy()
@@ -182,6 +184,8 @@ def orc_dec(codec, comp, n, cdf=None, cdfnum=256):
         o.orc_anscdfdec(_p8(src), n, _p8(out))
     elif codec == RCB:
         o.orc_rcsdec(_p8(src), n, _p8(out))
+    elif codec == RCAI:
+        o.orc_rccdfidec(_p8(src), n, _p8(out))
     else:
         raise ValueError(codec)
     return out[:n].copy()
@@ -229,7 +233,7 @@ def ref():
             f = getattr(lib, name); f.restype = sz; f.argtypes = [_u8p, sz, _u8p, _u16p, C.c_uint]
         for name in ("anscdf4senc", "anscdf4sencs", "anscdf4sencx"):
             f = getattr(lib, name); f.restype = sz; f.argtypes = [_u8p, sz, _u8p, _u16p]
-        for name in ("rccdfenc", "rccdfdec", "anscdfenc", "anscdfdec", "anscdfencs", "anscdfdecs", "anscdfencx", "anscdfdecx", "rcsenc", "rcsdec"):
+        for name in ("rccdfienc", "rccdfidec", "rccdfenc", "rccdfdec", "anscdfenc", "anscdfdec", "anscdfencs", "anscdfdecs", "anscdfencx", "anscdfdecx", "rcsenc", "rcsdec"):
             f = getattr(lib, name); f.restype = sz; f.argtypes = [_u8p, sz, _u8p]
         _ref = lib
     return _ref
@@ -263,6 +267,8 @@ def ref_enc(codec, data, cdf=None, cdfnum=256, variant=""):
         l = getattr(r, "anscdfenc" + variant)(pin, n, pout)
     elif codec == RCB:
         l = r.rcsenc(pin, n, pout)
+    elif codec == RCAI:
+        l = r.rccdfienc(pin, n, pout)
     else:
         raise ValueError(codec)
     return buf[oo:oo + l].copy()
@@ -288,6 +294,8 @@ def ref_dec(codec, comp, n, cdf=None, cdfnum=256, variant="", search="b"):
         getattr(r, "anscdfdec" + variant)(_p8(src), n, _p8(out))
     elif codec == RCB:
         r.rcsdec(_p8(src), n, _p8(out))
+    elif codec == RCAI:
+        r.rccdfidec(_p8(src), n, _p8(out))
     return out[:n].copy()
 
 

@@ -63,10 +63,10 @@ extern "C" int trc_set_chunk(uint32_t chunk)
 #define TRC_INKERNEL_SCAN_MAX 8192u
 static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline bool is_static(int codec) { return codec == TRC_ANS4S || codec == TRC_RCS1 || codec == TRC_RCS2; }
-static inline bool codec_ok(int codec) { return codec == TRC_ANS4S || codec == TRC_RCS1 || codec == TRC_RCS2 || codec == TRC_RCB || codec == TRC_RCA || codec == TRC_ANSA; }
-static inline int nregions(int codec) { return codec == TRC_RCS2 ? 2 : 1; }
+static inline bool codec_ok(int codec) { return codec == TRC_ANS4S || codec == TRC_RCS1 || codec == TRC_RCS2 || codec == TRC_RCB || codec == TRC_RCA || codec == TRC_ANSA || codec == TRC_RCAI; }
+static inline int nregions(int codec) { return (codec == TRC_RCS2 || codec == TRC_RCAI) ? 2 : 1; }
 // second scratch array: RCS2 stream 1 (same stride) or ANSA's record stack (8 B per input byte + one segment)
-static inline size_t scratch2_stride(int codec, uint32_t chunk) { return codec == TRC_RCS2 ? chunk + 128 : codec == TRC_ANSA ? 8 * (size_t)chunk : 0; }
+static inline size_t scratch2_stride(int codec, uint32_t chunk) { return (codec == TRC_RCS2 || codec == TRC_RCAI) ? chunk + 128 : codec == TRC_ANSA ? 8 * (size_t)chunk : 0; }
 
 static uint32_t scratch_stride(int codec, uint32_t chunk)
 {
@@ -198,7 +198,8 @@ extern "C" int trc_encode_dev(int codec, const void *d_in, size_t n, uint32_t ch
     case TRC_RCS1:  trc_launch_rcs_enc(1, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 0; break;
     case TRC_RCS2:  trc_launch_rcs_enc(2, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 2; break;
     case TRC_RCB:   trc_launch_rcb_enc((const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 0; break;
-    case TRC_RCA:   trc_launch_rca_enc((const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 0; break;
+    case TRC_RCA:   trc_launch_rca_enc(1, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 0; break;
+    case TRC_RCAI:  trc_launch_rca_enc(2, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 2; break;
     case TRC_ANSA:  trc_launch_ansa_enc((const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 1; break;
     }
     tm_end(0, tmi, s);
@@ -229,7 +230,8 @@ extern "C" int trc_decode_dev(int codec, const uint32_t *d_clen, const void *d_p
     case TRC_RCS1:  trc_launch_rcs_dec(1, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     case TRC_RCS2:  trc_launch_rcs_dec(2, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     case TRC_RCB:   trc_launch_rcb_dec((const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
-    case TRC_RCA:   trc_launch_rca_dec((const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
+    case TRC_RCA:   trc_launch_rca_dec(1, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
+    case TRC_RCAI:  trc_launch_rca_dec(2, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     case TRC_ANSA:  trc_launch_ansa_dec((const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     }
     tm_end(1, tmi, s);
@@ -243,7 +245,7 @@ extern "C" const char *trc_kernel_name(int codec, int decode)
     case TRC_ANS4S: return decode ? "trc_ans4s_dec_kernel" : "trc_ans4s_enc_kernel";
     case TRC_RCS1: case TRC_RCS2: return decode ? "trc_rcs_dec_kernel" : "trc_rcs_enc_kernel";
     case TRC_RCB: return decode ? "trc_rcb_dec_kernel" : "trc_rcb_enc_kernel";
-    case TRC_RCA: return decode ? "trc_rca_dec_kernel" : "trc_rca_enc_kernel";
+    case TRC_RCA: case TRC_RCAI: return decode ? "trc_rca_dec_kernel" : "trc_rca_enc_kernel";
     case TRC_ANSA: return decode ? "trc_ansa_dec_kernel" : "trc_ansa_code_kernel";
     }
     return "";
@@ -419,6 +421,10 @@ size_t rcsdec(unsigned char *in, size_t outlen, unsigned char *out) { return hos
 // adaptive-CDF byte range coder (reference rccdf.c:187-211; turborc -e46)
 size_t rccdfenc(unsigned char *in, size_t inlen, unsigned char *out) { return host_encode(TRC_RCA, in, inlen, out, nullptr, 0); }
 size_t rccdfdec(unsigned char *in, size_t outlen, unsigned char *out) { return host_decode(TRC_RCA, in, outlen, out, nullptr, 0); }
+
+// interleaved adaptive-CDF byte range coder (reference rccdf.c:213-249; turborc -e47) -- SURVEY 8f rank 1
+size_t rccdfienc(unsigned char *in, size_t inlen, unsigned char *out) { return host_encode(TRC_RCAI, in, inlen, out, nullptr, 0); }
+size_t rccdfidec(unsigned char *in, size_t outlen, unsigned char *out) { return host_decode(TRC_RCAI, in, outlen, out, nullptr, 0); }
 
 // adaptive-CDF byte rANS (reference anscdf.c:567-605, dispatch :816-817; turborc -e56 / -e57 / -e58)
 #define TRC_EXPORT_ANSA(sfx) \

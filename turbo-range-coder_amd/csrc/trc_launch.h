@@ -52,9 +52,9 @@ void trc_launch_rcb_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const Trc
 void trc_launch_rcb_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                         const TrcWork &w, uint8_t *d_out, hipStream_t s);
 
-// RCA: adaptive-CDF byte range coder (rccdfenc / rccdfdec)
-void trc_launch_rca_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s);
-void trc_launch_rca_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
+// RCA / RCAI: adaptive-CDF byte range coder, 1 stream (rccdfenc / rccdfdec) or hi/lo nibbles on 2 streams (rccdfienc / rccdfidec)
+void trc_launch_rca_enc(int nstreams, const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s);
+void trc_launch_rca_dec(int nstreams, const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                         const TrcWork &w, uint8_t *d_out, hipStream_t s);
 
 // ANSA: adaptive-CDF byte rANS (anscdfenc / anscdfdec); scratch2 holds the 8 B/byte record stack
