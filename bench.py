@@ -104,8 +104,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=100 * 1000 * 1000, help="bytes per GPU")
-    ap.add_argument("--chunk", type=int, default=int(os.environ.get("TRC_BENCH_CHUNK", "1024")),
-                    help="chunk bytes (parallel unit); 1024 fills the 1024 SIMDs at 100 MB, ratio cost vs 4096: +0.7 %% (DESIGN.md)")
+    ap.add_argument("--chunk", type=int, default=int(os.environ.get("TRC_BENCH_CHUNK", "512")),
+                    help="chunk bytes (parallel unit); 512 = 12 resident waves per CU at 100 MB; payload ratio cost vs 4096: +1.6 %% (DESIGN.md)")
     ap.add_argument("--codec", default="anscdf4s")
     ap.add_argument("--cpu-sample", type=int, default=32 * 1000 * 1000)
     ap.add_argument("--no-cpu", action="store_true")

@@ -17,6 +17,9 @@
 #include "trc_io.h"
 #include "trc_launch.h"
 
+#define ENC_WAVE_LDS (TRC_SRING_BYTES + TRC_SEL_BYTES)       // input arrives through an in-register quad transpose
+#define DEC_WAVE_LDS (TRC_SRING_BYTES + TRC_SEL_BYTES)       // 8.3 KiB: 12 waves + 34 KiB of tables fit one CU
+
 // ------------------------------------------------------------------------------------- encode ---
 // one rANS step (ece, anscdf_.h:90-94): renorm-emit, then st = (st/f)<<15 + st%f + c0.
 //   e = { m, (2^15-f) | sh<<24, f<<16, c0' }:  q = umulhi(st, m) >> sh == st / f  for st < 2^31
@@ -39,7 +42,7 @@ __global__ __launch_bounds__(BLOCK) void trc_ans4s_enc_kernel(
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     uint4 *etab = (uint4 *)smem;                                                     // 4096 B
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    u8 *wbase = smem + 4096 + wv * (TRC_TILE_BYTES + TRC_SRING_BYTES + TRC_SEL_BYTES);
+    u8 *wbase = smem + 4096 + wv * ENC_WAVE_LDS;
     for (u32 i = tid; i < 256; i += BLOCK) etab[i] = etab_g[i];
     __syncthreads();
 
@@ -52,9 +55,9 @@ __global__ __launch_bounds__(BLOCK) void trc_ans4s_enc_kernel(
     const bool alive = lane < wc.rows;
     const u32 c = wc.c0 + lane;
     const u32 len = alive ? wc.len_of(lane) : 0u;
-    TileIn tin; tin.tile = wbase; tin.base = in + (u64)wc.c0 * chunk;
+    QuadIn tin; tin.base = in + (u64)wc.c0 * chunk;
     StreamOut<true> so;
-    so.rings = wbase + TRC_TILE_BYTES; so.sel = wbase + TRC_TILE_BYTES + TRC_SRING_BYTES;
+    so.rings = wbase; so.sel = wbase + TRC_SRING_BYTES;
     so.scratch = scratch; so.stride = stride; so.c0 = wc.c0; so.wpos = 0; so.nfl = 0;
 
     const u32 S = chunk / TRC_SEG;
@@ -70,11 +73,11 @@ __global__ __launch_bounds__(BLOCK) void trc_ans4s_enc_kernel(
         bool act = alive && s <= top && !ovf;
         const bool ragged = act && s == top && toplen != TRC_SEG;
         if (ragged) {                                           // last chunk only: byte by byte
-            const u8 *row = tin.tile + lane * TRC_TILE_STRIDE;
             const u32 body = len & ~3u;
+            const u8 *mine = in + (u64)c * chunk;               // (one lane in the whole grid: plain byte loads)
             for (u32 pos = len; pos > TRC_SEG * top;) {
                 pos--;
-                const uint4 e = etab[row[pos & 63u]];
+                const uint4 e = etab[mine[pos]];
                 if (pos >= body || !(pos & 1u)) ans_put(st0, e, so); else ans_put(st1, e, so);
             }
             act = false;
@@ -133,7 +136,7 @@ __device__ __forceinline__ u32 ans_get(u32 &st, const u8 *lut, const uint2 *dtab
     return x;
 }
 
-__global__ __launch_bounds__(512) void trc_ans4s_dec_kernel(
+__global__ __launch_bounds__(768) void trc_ans4s_dec_kernel(
     const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
     u64 n, u32 chunk, u32 nchunks,
     const u8 *__restrict__ lut_g, const u32 *__restrict__ dtab_g, u8 *__restrict__ out)
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(512) void trc_ans4s_dec_kernel(
     u8 *lut = smem;                                   // 32768
     uint2 *dtab = (uint2 *)(smem + 32768);            // 256 x 8
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, BLOCK = blockDim.x;
-    u8 *wbase = smem + 32768 + 2048 + wv * (TRC_TILE_BYTES + TRC_SRING_BYTES + TRC_SEL_BYTES);
+    u8 *wbase = smem + 32768 + 2048 + wv * DEC_WAVE_LDS;
     for (u32 i = tid; i < 2048; i += BLOCK) ((uint4 *)lut)[i] = ((const uint4 *)lut_g)[i];
     for (u32 i = tid; i < 256; i += BLOCK) { const u32 d = dtab_g[i]; dtab[i] = make_uint2(d >> 16, 0u - (d & 0xffffu)); }
     __syncthreads();
@@ -161,9 +164,9 @@ __global__ __launch_bounds__(512) void trc_ans4s_dec_kernel(
     const u64 off = trc_group_base(goff, gsum, wc.c0 >> 6) + ex;
     const bool coded = alive && cl != len;
 
-    TileOut tout; tout.tile = wbase; tout.base = out + (u64)wc.c0 * chunk;
+    QuadOut tout; tout.base = out + (u64)wc.c0 * chunk;        // output leaves through an in-register quad transpose
     StreamIn si;
-    si.rings = wbase + TRC_TILE_BYTES; si.sel = wbase + TRC_TILE_BYTES + TRC_SRING_BYTES;
+    si.rings = wbase; si.sel = wbase + TRC_SRING_BYTES;
     si.gbase = payload; si.soff = off + 8;                    // words follow the two states
     u32 sa = 0, sb = 0;
     if (coded) { sa = trc_ld32_a2(payload + off); sb = trc_ld32_a2(payload + off + 4); }   // sa = enc state 1, sb = enc state 0
@@ -206,16 +209,20 @@ __global__ __launch_bounds__(512) void trc_ans4s_dec_kernel(
 }
 
 // ------------------------------------------------------------------------------------- launch ---
-#define ENC_WAVE_LDS (TRC_TILE_BYTES + TRC_SRING_BYTES + TRC_SEL_BYTES)
-
 void trc_launch_ans4s_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w,
                           uint32_t *d_clen, hipStream_t s)
 {
     const uint4 *etab = (const uint4 *)(w.tables + TRC_TAB_ENC);
     const u32 nwaves = w.ngroups;
-    const size_t sm = 4096 + ENC_WAVE_LDS;                      // one wave per workgroup: 17.4 KiB -> 9 waves/CU
-    hipLaunchKernelGGL(trc_ans4s_enc_kernel<64>, dim3(nwaves), dim3(64), sm, s,
-                       d_in, (u64)n, chunk, w.nchunks, etab, w.scratch, w.stride, d_clen, w.gsum);
+    if (nwaves >= 2048) {        // 4 waves share one 4 KiB symbol table: 37 KiB per workgroup -> 16 waves per CU
+        const size_t sm = 4096 + 4 * ENC_WAVE_LDS;
+        hipLaunchKernelGGL(trc_ans4s_enc_kernel<256>, dim3((nwaves + 3) / 4), dim3(256), sm, s,
+                           d_in, (u64)n, chunk, w.nchunks, etab, w.scratch, w.stride, d_clen, w.gsum);
+    } else {                     // few waves: one per workgroup so they spread over all CUs (12.4 KiB -> 12 per CU)
+        const size_t sm = 4096 + ENC_WAVE_LDS;
+        hipLaunchKernelGGL(trc_ans4s_enc_kernel<64>, dim3(nwaves), dim3(64), sm, s,
+                           d_in, (u64)n, chunk, w.nchunks, etab, w.scratch, w.stride, d_clen, w.gsum);
+    }
 }
 
 void trc_launch_ans4s_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
@@ -227,15 +234,15 @@ void trc_launch_ans4s_dec(const uint8_t *d_payload, const uint32_t *d_clen, size
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)trc_ans4s_dec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  32768 + 2048 + 8 * ENC_WAVE_LDS);
+                                  32768 + 2048 + 12 * DEC_WAVE_LDS);
         attr_set = true;
     }
     // the 34 KiB of tables are per workgroup, so waves share a workgroup -- but no more than it takes to
-    // give every one of the 256 CUs a workgroup (1526 waves: 6 per workgroup -> 255 workgroups)
+    // give every one of the 256 CUs a workgroup (1526 waves: 6 per workgroup -> 255 workgroups); up to 12 fit
     u32 wpb = (nwaves + 255u) / 256u;
-    wpb = wpb < 1u ? 1u : wpb > 8u ? 8u : wpb;
-    if (const char *e = getenv("TRC_DEC_WPB")) { const u32 v = (u32)atoi(e); if (v >= 1 && v <= 8) wpb = v; }   // tuning aid
-    const size_t sm = 32768 + 2048 + wpb * ENC_WAVE_LDS;
+    wpb = wpb < 1u ? 1u : wpb > 12u ? 12u : wpb;
+    if (const char *e = getenv("TRC_DEC_WPB")) { const u32 v = (u32)atoi(e); if (v >= 1 && v <= 12) wpb = v; }   // tuning aid
+    const size_t sm = 32768 + 2048 + wpb * DEC_WAVE_LDS;
     hipLaunchKernelGGL(trc_ans4s_dec_kernel, dim3((nwaves + wpb - 1) / wpb), dim3(64 * wpb), sm, s,
                        d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, lut, dtab, d_out);
 }

@@ -77,6 +77,8 @@ __device__ __forceinline__ void trc_wave_copy(u8 *dst, const u8 *src, u32 len)
 
 // Payload offset of group g (64 chunks): goff[g] when the caller ran the scan kernel, otherwise the sum
 // of the per-group byte counts below g, computed by the calling wave (all 64 lanes must call).
+// (A variant with atomically accumulated per-64-group super-sums was measured and dropped: the atomics
+// cost more than these loads -- group_sums went from 4 to 18 us.)
 __device__ __forceinline__ u64 trc_group_base(const u64 *goff, const u32 *gsum, u32 g)
 {
     if (goff) return goff[g];

@@ -102,6 +102,86 @@ struct TileOut {
     }
 };
 
+// ----------------------------------------------------------------------------------- QuadOut ---
+// TileOut without the LDS tile: every lane keeps its chunk's 64 output bytes in 4 x uint4 registers and
+// the 4 lanes of a quad transpose their 4x4 blocks in registers (two DPP butterfly stages, quad_perm
+// xor-1 then xor-2, ~1 VALU per byte), after which lane i of quad q holds piece i of the chunks
+// 4q..4q+3 and every store instruction again writes whole 64-byte segments.  Frees 5 KiB of LDS per
+// wave -- what it takes to keep 12 decoder waves per CU resident next to the 34 KiB symbol tables.
+__device__ __forceinline__ u32 trc_quad_xor1(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false); }
+__device__ __forceinline__ u32 trc_quad_xor2(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false); }
+// 4x4 transpose of uint4 blocks inside every quad of lanes: afterwards m[j] of lane i is what m[i] of lane
+// (quad base + j) held (an involution, used in both directions).
+__device__ __forceinline__ void trc_quad_transpose(u32 (&m)[4][4])
+{
+    const u32 lane = trc_lane();
+    const bool b0 = lane & 1u, b1 = lane & 2u;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+#pragma unroll
+        for (int k = 0; k < 4; k += 2) {                       // swap bit 0 of (lane, piece) with lane^1
+            const u32 r = trc_quad_xor1(b0 ? m[k][c] : m[k + 1][c]);
+            const u32 n0 = b0 ? r : m[k][c], n1 = b0 ? m[k + 1][c] : r;
+            m[k][c] = n0; m[k + 1][c] = n1;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {                          // swap bit 1 with lane^2
+            const u32 r = trc_quad_xor2(b1 ? m[k][c] : m[k + 2][c]);
+            const u32 n0 = b1 ? r : m[k][c], n1 = b1 ? m[k + 2][c] : r;
+            m[k][c] = n0; m[k + 2][c] = n1;
+        }
+    }
+}
+
+// QuadIn: TileIn without the LDS tile (same quad-coalesced 64-byte loads, transposed in registers).
+struct QuadIn {
+    const u8 *base;      // global address of chunk c0
+    uint4 r[4];          // segment in flight: r[j] = piece (lane&3) of the chunk of lane (lane&~3)+j
+    uint4 p[4];          // current segment: p[k] = piece k of this lane's chunk
+    __device__ __forceinline__ void issue(const WaveChunks &w, u32 segoff)
+    {
+        const u32 lane = trc_lane(), part = (lane & 3u) << 4;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            u32 row = (lane & ~3u) + (u32)j;
+            row = row < w.rows ? row : w.rows - 1;
+            const u32 so = segoff < w.len_of(row) ? segoff : 0u;     // never read past the input's pad
+            r[j] = *(const uint4 *)(base + (size_t)row * w.chunk + so + part);
+        }
+    }
+    __device__ __forceinline__ void commit()
+    {
+        u32 m[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { m[j][0] = r[j].x; m[j][1] = r[j].y; m[j][2] = r[j].z; m[j][3] = r[j].w; }
+        trc_quad_transpose(m);
+#pragma unroll
+        for (int k = 0; k < 4; k++) p[k] = make_uint4(m[k][0], m[k][1], m[k][2], m[k][3]);
+    }
+    __device__ __forceinline__ uint4 read(u32 k) const { return p[k]; }           // k is a literal after unrolling
+};
+
+struct QuadOut {
+    u8 *base;            // global address of chunk c0 in the output
+    uint4 p[4];
+    __device__ __forceinline__ void put(u32 k, uint4 v) { p[k] = v; }
+    __device__ __forceinline__ void flush(const WaveChunks &w, u32 segoff)
+    {
+        const u32 lane = trc_lane();
+        u32 m[4][4];                                           // m[k][c]: dword c of piece k
+#pragma unroll
+        for (int k = 0; k < 4; k++) { m[k][0] = p[k].x; m[k][1] = p[k].y; m[k][2] = p[k].z; m[k][3] = p[k].w; }
+        trc_quad_transpose(m);
+        const u32 part = (lane & 3u) << 4;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {                          // m[j] = piece (lane&3) of the chunk of lane (lane&~3)+j
+            const u32 row = (lane & ~3u) + (u32)j;
+            if (row < w.rows && segoff + part + 16u <= w.len_of(row))
+                *(uint4 *)(base + (size_t)row * w.chunk + segoff + part) = make_uint4(m[j][0], m[j][1], m[j][2], m[j][3]);
+        }
+    }
+};
+
 // --------------------------------------------------------------------------------- StreamOut ---
 // DOWN = true : units are appended downward from the END of the chunk's scratch region (rANS)
 // DOWN = false: upward from the START of the region (range coders)
