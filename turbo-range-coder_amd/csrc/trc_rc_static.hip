@@ -14,7 +14,7 @@
 #include "trc_rc.h"
 #include "trc_launch.h"
 
-#define RCS_WAVE_LDS(NS) (TRC_TILE_BYTES + (NS) * TRC_SRING_BYTES + TRC_SEL_BYTES)
+#define RCS_WAVE_LDS(NS) ((NS) * TRC_SRING_BYTES + TRC_SEL_BYTES)     // chunk bytes travel through in-register quad transposes
 
 template <int NS>
 __global__ __launch_bounds__(64) void trc_rcs_enc_kernel(
@@ -38,9 +38,9 @@ __global__ __launch_bounds__(64) void trc_rcs_enc_kernel(
     const u32 len = alive ? wc.len_of(lane) : 0u;
     const int lim = trc_rc_limit(len);
 
-    TileIn tin; tin.tile = wbase; tin.base = in + (u64)wc.c0 * chunk;
+    QuadIn tin; tin.base = in + (u64)wc.c0 * chunk;
     StreamOut<false> so0, so1;
-    so0.rings = wbase + TRC_TILE_BYTES; so0.sel = wbase + TRC_TILE_BYTES + NS * TRC_SRING_BYTES;
+    so0.rings = wbase; so0.sel = wbase + NS * TRC_SRING_BYTES;
     so0.scratch = scrA; so0.stride = strideA; so0.c0 = wc.c0; so0.wpos = (NS == 2) ? 4u : 0u; so0.nfl = 0;
     so1 = so0;
     if (NS == 2) { so1.rings = so0.rings + TRC_SRING_BYTES; so1.scratch = scrB; so1.stride = strideB; so1.wpos = 0; }
@@ -73,9 +73,9 @@ __global__ __launch_bounds__(64) void trc_rcs_enc_kernel(
                     }
                 }
             } else if (act) {                                   // last chunk's final partial piece
-                const u8 *row = tin.tile + lane * TRC_TILE_STRIDE;
+                const u8 *mine = in + (u64)c * chunk;               // (one lane in the whole grid: plain byte loads)
                 for (u32 pos = p0; pos < len; pos++) {
-                    const u32 t = tab[row[pos & 63u]];
+                    const u32 t = tab[mine[pos]];
                     if (NS == 2 && pos < pairs && (pos & 1u)) {
                         e1.sym(so1, t & 0xffffu, t >> 16);          // pair complete: OVERFLOWI (never after the odd tail byte)
                         ovf = ovf || ((int)(off1 + 4u * e1.nwords) >= lim) || (4u + 4u * e0.nwords >= off1);
@@ -111,15 +111,15 @@ __global__ __launch_bounds__(64) void trc_rcs_enc_kernel(
     if (lane == 0) gsum[wc.c0 >> 6] = gs;
 }
 
-template <int NS, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void trc_rcs_dec_kernel(
+template <int NS>
+__global__ __launch_bounds__(768) void trc_rcs_dec_kernel(
     const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
     u64 n, u32 chunk, u32 nchunks, const u8 *__restrict__ lut_g, const u32 *__restrict__ tab_g, u8 *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     u8 *lut = smem;                                            // 32768
     u32 *tab = (u32 *)(smem + 32768);                          // 256 x {f<<16 | c0}
-    const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, BLOCK = blockDim.x;
     u8 *wbase = smem + 32768 + 1024 + wv * RCS_WAVE_LDS(NS);
     for (u32 i = tid; i < 2048; i += BLOCK) ((uint4 *)lut)[i] = ((const uint4 *)lut_g)[i];
     for (u32 i = tid; i < 256; i += BLOCK) tab[i] = tab_g[i];
@@ -138,9 +138,9 @@ __global__ __launch_bounds__(BLOCK) void trc_rcs_dec_kernel(
     const u64 off = trc_group_base(goff, gsum, wc.c0 >> 6) + ex;
     const bool coded = alive && cl != len;
 
-    TileOut tout; tout.tile = wbase; tout.base = out + (u64)wc.c0 * chunk;
+    QuadOut tout; tout.base = out + (u64)wc.c0 * chunk;
     StreamIn s0, s1;
-    s0.rings = wbase + TRC_TILE_BYTES; s0.sel = wbase + TRC_TILE_BYTES + NS * TRC_SRING_BYTES;
+    s0.rings = wbase; s0.sel = wbase + NS * TRC_SRING_BYTES;
     s0.gbase = payload; s0.soff = off + (NS == 2 ? 4u : 0u);
     s1 = s0;
     if (NS == 2) {
@@ -211,22 +211,23 @@ void trc_launch_rcs_enc(int nstreams, const uint8_t *d_in, size_t n, uint32_t ch
                            d_in, (u64)n, chunk, w.nchunks, tab, w.scratch, w.stride, w.scratch2, w.stride2, d_clen, w.gsum);
 }
 
-template <int NS, int BLOCK>
+template <int NS>
 static void launch_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                        const TrcWork &w, uint8_t *d_out, hipStream_t s)
 {
-    const size_t sm = 32768 + 1024 + (BLOCK / 64) * RCS_WAVE_LDS(NS);
+    const u32 maxw = NS == 1 ? 12u : 7u;                       // 34 KiB tables + waves x (NS rings) must fit 160 KiB
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)trc_rcs_dec_kernel<NS, BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr = true; }
-    const u32 wpb = BLOCK / 64;
-    hipLaunchKernelGGL((trc_rcs_dec_kernel<NS, BLOCK>), dim3((w.ngroups + wpb - 1) / wpb), dim3(BLOCK), sm, s,
+    if (!attr) { (void)hipFuncSetAttribute((const void *)trc_rcs_dec_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(32768 + 1024 + maxw * RCS_WAVE_LDS(NS))); attr = true; }
+    u32 wpb = (w.ngroups + 255u) / 256u;                       // just enough waves per workgroup to give every CU one
+    wpb = wpb < 1u ? 1u : wpb > maxw ? maxw : wpb;
+    const size_t sm = 32768 + 1024 + wpb * RCS_WAVE_LDS(NS);
+    hipLaunchKernelGGL((trc_rcs_dec_kernel<NS>), dim3((w.ngroups + wpb - 1) / wpb), dim3(64 * wpb), sm, s,
                        d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, w.tables + TRC_TAB_LUT,
                        (const u32 *)(w.tables + TRC_TAB_DEC), d_out);
 }
 void trc_launch_rcs_dec(int nstreams, const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                         const TrcWork &w, uint8_t *d_out, hipStream_t s)
 {
-    const bool many = w.ngroups > 768;
-    if (nstreams == 1) { if (many) launch_dec<1, 512>(d_payload, d_clen, n, chunk, w, d_out, s); else launch_dec<1, 64>(d_payload, d_clen, n, chunk, w, d_out, s); }
-    else               { if (many) launch_dec<2, 256>(d_payload, d_clen, n, chunk, w, d_out, s); else launch_dec<2, 64>(d_payload, d_clen, n, chunk, w, d_out, s); }
+    if (nstreams == 1) launch_dec<1>(d_payload, d_clen, n, chunk, w, d_out, s);
+    else               launch_dec<2>(d_payload, d_clen, n, chunk, w, d_out, s);
 }
