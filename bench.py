@@ -213,7 +213,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("%s_%s_chunk%d" % (args.codec, dom, chunk))
+                if n == 100 * 1000 * 1000:                          # the PMC passes were taken on the default workload
+                    traffic = json.load(open(tpath)).get("%s_%s_chunk%d" % (args.codec, dom, chunk))
             except Exception:
                 traffic = None
         res = {

@@ -92,7 +92,8 @@ static int carve(int codec, size_t n, uint32_t chunk, void *d_work, size_t work_
     uint8_t *p = (uint8_t *)d_work;
     w.tables = p;               p += up256(TRC_TAB_BYTES);
     w.gsum = (uint32_t *)p;     p += up256(4 * ngroups);
-    w.goff = ngroups > TRC_INKERNEL_SCAN_MAX ? (uint64_t *)p : nullptr;     p += up256(8 * (ngroups + 1));
+    static const uint32_t scan_max = getenv("TRC_SCAN_MAX") ? (uint32_t)atoi(getenv("TRC_SCAN_MAX")) : TRC_INKERNEL_SCAN_MAX;   // tuning aid
+    w.goff = ngroups > scan_max ? (uint64_t *)p : nullptr;     p += up256(8 * (ngroups + 1));
     w.scratch = p;
     w.stride = scratch_stride(codec, chunk);
     w.stride2 = (uint32_t)scratch2_stride(codec, chunk);
