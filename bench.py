@@ -7,7 +7,7 @@
 A "step" = one encode pass + one decode pass of the hot path over this rank's 100 MB shard, inputs
 already resident in HBM (weak scaling: every rank codes its own 100 MB of independent chunks; for
 N > 1 the per-rank compressed payloads are gathered to rank 0 with RCCL inside the timed region --
-the path's only exchange step).  value = bytes all ranks processed / max-over-ranks wall time, with
+the path's only exchange step -- on a side stream, overlapped with the local decode).  value = bytes all ranks processed / max-over-ranks wall time, with
 MB = 10^6 (reference include_/time_.h:113,233), i.e. N / (t_enc + t_dec) per SURVEY 8d.
 
 Workload (configs[1]): "text100m" -- 100 000 000 i.i.d. bytes from an English-like order-0 table,
@@ -165,11 +165,21 @@ def main():
         point-to-point transfer per peer -- over xGMI each rides its own direct link."""
         shard.gather_to_root(dist, rank, world, dc.total[:1], dc.clen[:nch], dc.payload, recv_clen, recv_payload)
 
+    side = torch.cuda.Stream(device=dev) if use_dist else None
+
     def step():
         dc.encode(d_in, n)
         if use_dist:
-            exchange()
-        dc.decode(d_out, n)
+            # the gather of the compressed results rides a side stream, concurrently with the local decode
+            # (the transfer needs one xGMI link per peer for ~C/150 GB/s; the decode is LDS-bound)
+            main = torch.cuda.current_stream(dev)
+            side.wait_stream(main)                             # side stream: starts once the encode is done
+            dc.decode(d_out, n)                                # main stream: local decode, enqueued first ...
+            with torch.cuda.stream(side):
+                exchange()                                     # ... so the host-side size sync in here overlaps it
+            main.wait_stream(side)
+        else:
+            dc.decode(d_out, n)
 
     for _ in range(args.warmup):
         step()
