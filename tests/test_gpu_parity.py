@@ -197,6 +197,25 @@ def test_many_groups_uses_scan_kernel(torch_cuda, codec):
         assert clen[c] == exp.size and np.array_equal(payload[off[c]:off[c + 1]], exp), "chunk %d" % c
 
 
+@pytest.mark.parametrize("codec", trc.AVAILABLE, ids=lambda c: trc.CODEC_NAMES[c])
+def test_max_rate_bursts(torch_cuda, codec):
+    """chunks that stay compressible overall but contain long bursts of the rarest symbols (frequency 1 in the
+    static CDF): inside a burst every symbol renormalises, i.e. the coded stream is consumed/produced at the
+    maximum rate the ring + look-ahead logic is sized for (32 bytes per 16-symbol period)"""
+    rng = np.random.default_rng(7)
+    n, chunk = 1 << 20, 4096
+    d = np.zeros(n, dtype=np.uint8)
+    d[rng.integers(0, n, n // 50)] = 1                         # two common symbols
+    rare = np.arange(40, 250, dtype=np.uint8)
+    for start in range(1000, n - 2000, 4096):                  # one burst per chunk, different lengths / phases
+        ln = int(rng.integers(60, 700))
+        d[start:start + ln] = rng.choice(rare, ln)
+    _, cdf, cdfnum = T.orc_cdfini(d)
+    clen, _ = device_roundtrip(torch_cuda, codec, d, chunk, cdf, cdfnum)
+    assert (clen < chunk).mean() > 0.9                         # the chunks are coded, not stored raw
+    clen2, _ = device_roundtrip(torch_cuda, codec, d, 512, cdf, cdfnum)
+
+
 def test_device_layer_rejects_bad_arguments(torch_cuda):
     torch = torch_cuda
     l = trc.lib()

@@ -90,11 +90,7 @@ __global__ __launch_bounds__(BLOCK) void trc_ans4s_enc_kernel(
 #pragma unroll
                 for (int d = 3; d >= 0; d--) {
                     // table entries depend only on the input bytes: fetch all four before the chains
-#ifdef TRC_ABL_NOCONFLICT
-                    const uint4 e3 = etab[lane & 15u], e2 = etab[(lane + 1u) & 15u], e1 = etab[(lane + 2u) & 15u], e0 = etab[(lane + 3u) & 15u];
-#else
                     const uint4 e3 = etab[w[d] >> 24], e2 = etab[(w[d] >> 16) & 255u], e1 = etab[(w[d] >> 8) & 255u], e0 = etab[w[d] & 255u];
-#endif
                     ans_put(st1, e3, so); ans_put(st0, e2, so);
                     ans_put(st1, e1, so); ans_put(st0, e0, so);
                 }

@@ -1,0 +1,56 @@
+// trc_carry.h -- the append-only carry scheme of the range-coder encoder, free of any HIP dependency so that
+// the very same code is unit-tested on the host (tests/test_carry_host.py) against the reference's
+// behaviour: write every word at once and, on a carry, walk back adding 1 (turborc_.h:103 `_rccarry_`).
+//
+// The encoder logically emits a sequence of events (cy, W): "a carry reaches the words emitted so far"
+// (cy) followed by "append the 32-bit word W".  Because output leaves the chip append-only, the last word
+// is held back (`cache`) together with a count of 0xFFFFFFFF words behind it (`npend`): a carry turns
+// cache, FF.. into cache+1, 00..; words are released to the sink only when no later carry can reach them.
+// A word receives at most one carry in its lifetime (what is still to be added to the code value is
+// always smaller than the range at the time the word was emitted), so after a carry everything held is final.
+#pragma once
+#include <stdint.h>
+#ifndef TRC_HD
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define TRC_HD __host__ __device__ __forceinline__
+#else
+#define TRC_HD inline
+#endif
+#endif
+
+struct TrcCarry {
+    uint32_t cache, npend, nwords;   // nwords counts like the reference's output pointer (held-back words included)
+    bool have;
+    TRC_HD void start() { cache = 0; npend = 0; nwords = 0; have = false; }
+    // SINK needs put32(uint32_t) and put32_slow(uint32_t) (the latter may be called in long runs)
+    template <class SINK>
+    TRC_HD void emit(SINK &so, bool cy, uint32_t W)
+    {
+        nwords++;
+        if (have && !cy && npend == 0 && W != 0xffffffffu) {           // the common case
+            so.put32(cache); cache = W;
+            return;
+        }
+        if (cy) {                                                       // cache+1, then zeros: all final
+            so.put32(cache + 1u);
+            for (; npend; npend--) so.put32_slow(0u);
+            have = false;
+        }
+        if (!have) { cache = W; have = true; }
+        else if (W == 0xffffffffu) npend++;
+        else {
+            so.put32(cache);
+            for (; npend; npend--) so.put32_slow(0xffffffffu);
+            cache = W;
+        }
+    }
+    template <class SINK>
+    TRC_HD void release(SINK &so)                                      // end of stream: nothing can carry any more
+    {
+        if (have) {
+            so.put32(cache);
+            for (; npend; npend--) so.put32_slow(0xffffffffu);
+            have = false;
+        }
+    }
+};

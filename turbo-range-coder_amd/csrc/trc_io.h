@@ -202,9 +202,7 @@ struct StreamOut {
     // only advance when `take` (no exec-mask branch in the symbol loop)
     __device__ __forceinline__ void put16_if(bool take, u32 v)
     {
-#ifndef TRC_ABL_NOWRITE
         *(u16 *)(rings + trc_raddr(trc_lane(), roff16(wpos))) = (u16)v;
-#endif
         wpos += take ? 2u : 0u;
     }
     __device__ __forceinline__ void put16(u32 v) { *(u16 *)(rings + trc_raddr(trc_lane(), roff16(wpos))) = (u16)v; wpos += 2; }

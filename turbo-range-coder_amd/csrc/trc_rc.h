@@ -15,6 +15,7 @@
 // (held-back words included): the incompressibility test (OVERFLOW, rcutil_.h:130) uses it.
 #pragma once
 #include "trc_io.h"
+#include "trc_carry.h"
 
 #define TRC_TOP32 ((u64)1 << 32)
 
@@ -23,33 +24,13 @@ __device__ __forceinline__ int trc_rc_limit(u32 len) { return (int)((len * 255u)
 
 struct RcEnc {
     u64 range, low, mark;
-    u32 cache, npend, nwords;
-    bool have;
+    TrcCarry cw;                                                        // held-back words (trc_carry.h)
 
-    __device__ __forceinline__ void start() { range = ~(u64)0; low = mark = 0; cache = 0; npend = 0; nwords = 0; have = false; }
+    __device__ __forceinline__ void start() { range = ~(u64)0; low = mark = 0; cw.start(); }
 
     // logical append of word W with carry flag cy (cy refers to the words BEFORE W)
     template <class SO>
-    __device__ __forceinline__ void emit(SO &so, bool cy, u32 W)
-    {
-        nwords++;
-        if (have && !cy && npend == 0 && W != 0xffffffffu) {           // the common case
-            so.put32(cache); cache = W;
-            return;
-        }
-        if (cy) {                                                       // cache+1, then zeros: all final
-            so.put32(cache + 1u);
-            for (; npend; npend--) so.put32_slow(0u);
-            have = false;
-        }
-        if (!have) { cache = W; have = true; }
-        else if (W == 0xffffffffu) npend++;
-        else {
-            so.put32(cache);
-            for (; npend; npend--) so.put32_slow(0xffffffffu);
-            cache = W;
-        }
-    }
+    __device__ __forceinline__ void emit(SO &so, bool cy, u32 W) { cw.emit(so, cy, W); }
     template <class SO>
     __device__ __forceinline__ void renorm(SO &so)                      // single `if`: RC_IO = 32
     {
@@ -86,11 +67,7 @@ struct RcEnc {
             emit(so, mark > low, (u32)(low >> 32));
             emit(so, false, (u32)low);
         }
-        if (have) {
-            so.put32(cache);
-            for (; npend; npend--) so.put32_slow(0xffffffffu);
-            have = false;
-        }
+        cw.release(so);
     }
 };
 

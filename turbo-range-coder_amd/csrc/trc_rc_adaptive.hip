@@ -75,8 +75,8 @@ __global__ __launch_bounds__(64) void trc_rca_enc_kernel(
                         else         put_nibble(e1, so1, m.table(1u + (x >> 4)), x & 15u);
                     }
                     // OVERFLOW after every byte (NS=1) / OVERFLOWI after every FULL group of 4 (NS=2): both monotone
-                    if (NS == 1) ovf = (int)(4u * e.nwords) >= lim;
-                    else if (nb == 4u) ovf = ((int)(off1 + 4u * e1.nwords) >= lim) || (4u + 4u * e.nwords >= off1);
+                    if (NS == 1) ovf = (int)(4u * e.cw.nwords) >= lim;
+                    else if (nb == 4u) ovf = ((int)(off1 + 4u * e1.cw.nwords) >= lim) || (4u + 4u * e.cw.nwords >= off1);
                 }
                 so.drain(false, alive);
                 if (NS == 2) so1.drain(false, alive);

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(64) void trc_rcb_enc_kernel(
                     for (u32 i = 0; i < nb; i++) put_byte((w[d] >> (8 * i)) & 255u);
                 }
                 so.drain(false, alive);
-                ovf = ovf || (alive && (int)(4u * e.nwords) >= lim);
+                ovf = ovf || (alive && (int)(4u * e.cw.nwords) >= lim);
             }
         }
     }

@@ -78,15 +78,15 @@ __global__ __launch_bounds__(64) void trc_rcs_enc_kernel(
                     const u32 t = tab[mine[pos]];
                     if (NS == 2 && pos < pairs && (pos & 1u)) {
                         e1.sym(so1, t & 0xffffu, t >> 16);          // pair complete: OVERFLOWI (never after the odd tail byte)
-                        ovf = ovf || ((int)(off1 + 4u * e1.nwords) >= lim) || (4u + 4u * e0.nwords >= off1);
+                        ovf = ovf || ((int)(off1 + 4u * e1.cw.nwords) >= lim) || (4u + 4u * e0.cw.nwords >= off1);
                     } else e0.sym(so0, t & 0xffffu, t >> 16);
                 }
             }
             so0.drain(false, alive);
             if (NS == 2) so1.drain(false, alive);
             // monotone overflow tests (position = last byte coded so far is < pairs for every full piece)
-            if (NS == 1) ovf = ovf || (alive && (int)(4u * e0.nwords) >= lim);
-            else if (act && p0 + 16u <= len) ovf = ovf || ((int)(off1 + 4u * e1.nwords) >= lim) || (4u + 4u * e0.nwords >= off1);
+            if (NS == 1) ovf = ovf || (alive && (int)(4u * e0.cw.nwords) >= lim);
+            else if (act && p0 + 16u <= len) ovf = ovf || ((int)(off1 + 4u * e1.cw.nwords) >= lim) || (4u + 4u * e0.cw.nwords >= off1);
         }
     }
     u32 out_len = 0;
