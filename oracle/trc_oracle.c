@@ -450,6 +450,156 @@ size_t orc_anscdfdec(const uint8_t *in, size_t outlen, uint8_t *out)
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* the nibble coders (`turborc -n`, input values 0..15; harness gate m<16,     */
+/* turborc.c:499-501,514-520).  One CDF16 table; values above 15 are outside the contract (the   */
+/* reference indexes past its table), we code their low nibble.                                  */
+
+/* rccdf4enc / rccdf4dec (rccdf.c:250-275; cdf4e/cdf4d rccdf_.h:28,48), `turborc -n -e46` */
+size_t orc_rccdf4enc(const uint8_t *in, size_t inlen, uint8_t *out)
+{
+    nibmodel_t m; nib_reset(&m);
+    rce_t e; rce_start(&e, out);
+    for (size_t i = 0; i < inlen; i++) {
+        unsigned x = in[i] & 15;
+        rce_sym(&e, m.hi[x], m.hi[x + 1]);       nib_adapt(m.hi, x);
+        if (rc_overflow((size_t)(e.op - out), inlen)) { memcpy(out, in, inlen); return inlen; }
+    }
+    rce_finish(&e);
+    return (size_t)(e.op - out);
+}
+size_t orc_rccdf4dec(const uint8_t *in, size_t outlen, uint8_t *out)
+{
+    nibmodel_t m; nib_reset(&m);
+    rcd_t d; rcd_start(&d, in);
+    for (size_t i = 0; i < outlen; i++) out[i] = (uint8_t)rcd_nibble(&d, m.hi);
+    return outlen;
+}
+
+/* rccdf4ienc / rccdf4idec (rccdf.c:277-323), `turborc -n -e47`: even positions -> stream 0, odd positions ->
+ * stream 1 (base out+4+inlen/2), odd tail on stream 0.  BOTH symbols of a pair are coded with the table as it
+ * was before the pair, then the table adapts to x0 and to x1 (rccdf.c:311-314).
+ * Deviations from the reference, both where the reference itself does not round-trip:
+ *  - its in-loop OVERFLOW is handed op1 but the function returns op0-out (rccdf.c:314,322), i.e. a
+ *    meaningless length over a raw copy (small / incompressible inputs; it then crashes in the decoder);
+ *  - it never tests stream 0 running into stream 1's region (short inputs: the two flushes alone can need
+ *    more than inlen/2 bytes).
+ *  In both cases we return inlen with a raw copy, the convention of include/turborc.h:46-59. */
+size_t orc_rccdf4ienc(const uint8_t *in, size_t inlen, uint8_t *out)
+{
+    nibmodel_t m; nib_reset(&m);
+    size_t off1 = 4 + inlen / 2, pairs = inlen & ~(size_t)1, i;
+    uint8_t *s0 = (uint8_t *)malloc(2 * inlen + 32), *s1 = (uint8_t *)malloc(2 * inlen + 32);
+    rce_t e0, e1;
+    if (!s0 || !s1) { free(s0); free(s1); return 0; }
+    rce_start(&e0, s0); rce_start(&e1, s1);
+    for (i = 0; i < pairs; i += 2) {
+        unsigned x0 = in[i] & 15, x1 = in[i + 1] & 15;
+        rce_sym(&e0, m.hi[x0], m.hi[x0 + 1]);
+        rce_sym(&e1, m.hi[x1], m.hi[x1 + 1]);
+        nib_adapt(m.hi, x0);
+        nib_adapt(m.hi, x1);
+        if (rc_overflow(off1 + (size_t)(e1.op - s1), inlen)) goto raw;
+    }
+    if (i < inlen) { unsigned x = in[i] & 15; rce_sym(&e0, m.hi[x], m.hi[x + 1]); nib_adapt(m.hi, x); }
+    rce_finish(&e0);
+    rce_finish(&e1);
+    {
+        size_t len0 = (size_t)(e0.op - s0), len1 = (size_t)(e1.op - s1), total = 4 + len0 + len1;
+        if (4 + len0 > off1 || rc_overflow(total, inlen)) goto raw;
+        st32(out, (uint32_t)len0);
+        memcpy(out + 4, s0, len0);
+        memcpy(out + 4 + len0, s1, len1);
+        free(s0); free(s1);
+        return total;
+    }
+raw:
+    free(s0); free(s1);
+    memcpy(out, in, inlen);
+    return inlen;
+}
+size_t orc_rccdf4idec(const uint8_t *in, size_t outlen, uint8_t *out)
+{
+    nibmodel_t m; nib_reset(&m);
+    rcd_t d0, d1;
+    size_t pairs = outlen & ~(size_t)1, i;
+    rcd_start(&d0, in + 4);
+    rcd_start(&d1, in + 4 + ld32(in));
+    for (i = 0; i < pairs; i += 2) {
+        unsigned x0 = 0, x1 = 0;
+        d0.range >>= PROB_BITS; d1.range >>= PROB_BITS;
+        while (x0 < 15 && (uint64_t)m.hi[x0 + 1] * d0.range <= d0.code) x0++;
+        while (x1 < 15 && (uint64_t)m.hi[x1 + 1] * d1.range <= d1.code) x1++;
+        rcd_consume(&d0, m.hi[x0], m.hi[x0 + 1]);
+        rcd_consume(&d1, m.hi[x1], m.hi[x1 + 1]);
+        nib_adapt(m.hi, x0);
+        nib_adapt(m.hi, x1);
+        out[i] = (uint8_t)x0; out[i + 1] = (uint8_t)x1;
+    }
+    if (i < outlen) out[i] = (uint8_t)rcd_nibble(&d0, m.hi);
+    return outlen;
+}
+
+/* anscdf4enc / anscdf4dec (anscdf.c:87-133; mnenc4/mnflush/mndec4 anscdf_.h:106,128-141), `turborc -n -e56`:
+ * adaptive nibble rANS, 2 states, 4 MiB blocks.  Groups of 4: positions 0,2 -> state 1, positions 1,3 -> state 0;
+ * the n%4 tail -> state 0.  The decoder here reads the tail from the state the ENCODER used; the reference
+ * decoder takes its st[0] (= encoder state 1, mnfill reverses the order), so the reference does not round-trip
+ * when the block length is not a multiple of 4 -- same defect as anscdf4sdec (see orc_anscdf4sdec). */
+size_t orc_anscdf4enc(const uint8_t *in, size_t inlen, uint8_t *out)
+{
+    size_t blk = inlen < ANS_BLOCK ? inlen : ANS_BLOCK;
+    uint32_t *stack = (uint32_t *)malloc((blk + 1) * sizeof(uint32_t) + 64);
+    uint8_t *op = out, *oend = out + inlen;
+    size_t pos = 0;
+    if (!stack) return 0;
+    while (pos < inlen) {
+        size_t len = inlen - pos < blk ? inlen - pos : blk, body = len & ~(size_t)3, k, ns = 0;
+        nibmodel_t m; nib_reset(&m);
+        for (k = 0; k < len; k++) {
+            unsigned x = in[pos + k] & 15, sid = (k < body) ? 1u - (unsigned)(k & 1) : 0u;
+            stack[ns++] = sid << 30 | (uint32_t)m.hi[x] << 15 | (uint32_t)(m.hi[x + 1] - m.hi[x]);
+            nib_adapt(m.hi, x);
+        }
+        uint32_t st[2] = { ANS_LO, ANS_LO };
+        uint8_t *ep = oend;
+        while (ns) {
+            uint32_t r = stack[--ns];
+            if (ep <= op + 2 + 8) goto raw;
+            ans_put(&st[r >> 30], (r >> 15) & 0x7fff, r & 0x7fff, &ep);
+        }
+        for (k = 0; k < 2; k++) { ep -= 4; st32(ep, st[k]); }
+        if (ep <= op) goto raw;
+        size_t l = (size_t)(oend - ep);
+        if (op + l >= oend) goto raw;
+        memmove(op, ep, l); op += l;
+        pos += len;
+    }
+    free(stack);
+    return (size_t)(op - out);
+raw:
+    free(stack);
+    memcpy(out, in, inlen);                            /* whole input from its true start (cf. orc_anscdfenc) */
+    return inlen;
+}
+size_t orc_anscdf4dec(const uint8_t *in, size_t outlen, uint8_t *out)
+{
+    size_t blk = outlen < ANS_BLOCK ? outlen : ANS_BLOCK, pos = 0;
+    const uint8_t *ip = in;
+    while (pos < outlen) {
+        size_t len = outlen - pos < blk ? outlen - pos : blk, body = len & ~(size_t)3, k;
+        nibmodel_t m; nib_reset(&m);
+        uint32_t sa = ld32(ip), sb = ld32(ip + 4);     /* sa = encoder state 1, sb = encoder state 0 */
+        ip += 8;
+        for (k = 0; k < len; k++) {
+            uint32_t *s = (k < body && !(k & 1)) ? &sa : &sb;
+            out[pos + k] = (uint8_t)ansd_nibble(s, m.hi);
+            ansd_renorm(s, &ip);
+        }
+        pos += len;
+    }
+    return outlen;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* M9  rcsenc / rcsdec  (rc_.c:37-58, mb_o0.h:27-41,89-112, turborc_.h:417-452, mbc_s.h:53-55)  */
 static inline uint16_t bit_adapt(uint32_t p, uint32_t bit)
 {
@@ -507,6 +657,9 @@ static size_t enc_one(int codec, const uint8_t *in, size_t n, uint8_t *out, cons
     case ORC_ANSA:  return orc_anscdfenc(in, n, out);
     case ORC_RCB:   return orc_rcsenc(in, n, out);
     case ORC_RCAI:  return orc_rccdfienc(in, n, out);
+    case ORC_RCA4:  return orc_rccdf4enc(in, n, out);
+    case ORC_RCAI4: return orc_rccdf4ienc(in, n, out);
+    case ORC_ANSA4: return orc_anscdf4enc(in, n, out);
     }
     return 0;
 }
@@ -520,6 +673,9 @@ static void dec_one(int codec, const uint8_t *in, size_t n, uint8_t *out, const 
     case ORC_ANSA:  orc_anscdfdec(in, n, out); break;
     case ORC_RCB:   orc_rcsdec(in, n, out); break;
     case ORC_RCAI:  orc_rccdfidec(in, n, out); break;
+    case ORC_RCA4:  orc_rccdf4dec(in, n, out); break;
+    case ORC_RCAI4: orc_rccdf4idec(in, n, out); break;
+    case ORC_ANSA4: orc_anscdf4dec(in, n, out); break;
     }
 }
 size_t orc_chunked_enc(int codec, const uint8_t *in, size_t n, size_t chunk,

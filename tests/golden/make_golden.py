@@ -46,6 +46,38 @@ MID = [(k, n) for k in ("zipf", "runs") for n in (16384, 65536)] + [("text", 655
 LARGE = [("zipf", 10**6, 1), ("text", 10**6, 7), ("runs", 10**6, 3), ("uniform", 10**6, 1),
          ("zipf", (1 << 22) + 1, 5), ("runs", 9 * (1 << 20) + 3, 5)]
 CODECS = [T.ANS4S, T.RCS1, T.RCS2, T.RCA, T.ANSA, T.RCB, T.RCAI]
+# `turborc -n` coders: own fixture file so that vectors.npz stays byte-stable
+NIB_SIZES = [1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 16, 17, 33, 63, 64, 65, 66, 67, 100, 255, 256, 257, 1000, 1001, 1002, 1003,
+             4096, 4097, 4098, 4099, 16384, 65535]
+NIB_RCAI4_MIN = 64          # below this the reference's rccdf4ienc returns meaningless lengths / crashes (see oracle)
+
+
+def main_nibble():
+    arrays, index = {}, []
+    ci = 0
+    for kind in ("geo", "runs", "uniform"):
+        for n in NIB_SIZES:
+            seed = 3000 + ci
+            d = T.nibble_bytes(n, seed, kind)
+            arrays["in_%d" % ci] = d
+            ent = dict(case=ci, kind=kind, n=n, seed=seed, out={})
+            for codec in T.NIBBLE_CODECS:
+                if codec == T.RCAI4 and n < NIB_RCAI4_MIN:
+                    continue
+                o = T.ref_enc(codec, d, variant="s" if codec == T.ANSA4 else "")
+                if codec == T.ANSA4:
+                    assert np.array_equal(o, T.ref_enc(codec, d, variant="x")), "s/x builds differ"
+                if o.size != n and not (codec == T.ANSA4 and n % 4):    # reference anscdf4dec mis-decodes n%4 tails
+                    assert np.array_equal(T.ref_dec(codec, o, n, variant="s" if codec == T.ANSA4 else ""), d)
+                name = T.CODEC_NAMES[codec]
+                ent["out"][name] = int(o.size)
+                if o.size != n:
+                    arrays["out_%d_%s" % (ci, name)] = o
+            index.append(ent)
+            ci += 1
+    arrays["index"] = np.frombuffer(json.dumps(index).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "nibble_vectors.npz"), **arrays)
+    print("wrote", len(index), "nibble cases")
 
 
 def main():
@@ -102,4 +134,6 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--nibble-only" not in sys.argv:
+        main()
+    main_nibble()

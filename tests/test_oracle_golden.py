@@ -75,3 +75,29 @@ def test_large_cases_hash():
                 assert payload.size == ent["chunk4096"][name]["total"]
                 assert hashlib.sha256(payload.tobytes()).hexdigest() == ent["chunk4096"][name]["sha256"]
                 assert np.array_equal(T.orc_chunked_dec(codec, payload, clen, d.size, 4096, cdf, cdfnum), d)
+
+
+# ---------------------------------------------------------------- `turborc -n` coders ---
+@pytest.fixture(scope="module")
+def nibble_vectors():
+    z = np.load(os.path.join(GOLD, "nibble_vectors.npz"))
+    return z, json.loads(bytes(z["index"]).decode())
+
+
+@pytest.mark.parametrize("codec", T.NIBBLE_CODECS, ids=lambda c: T.CODEC_NAMES[c])
+def test_nibble_encode_matches_golden_and_roundtrips(nibble_vectors, codec):
+    z, index = nibble_vectors
+    name = T.CODEC_NAMES[codec]
+    seen = 0
+    for ent in index:
+        d = z["in_%d" % ent["case"]]
+        assert np.array_equal(T.nibble_bytes(ent["n"], ent["seed"], ent["kind"]), d)
+        o = T.orc_enc(codec, d)
+        assert np.array_equal(T.orc_dec(codec, o, ent["n"]), d), (ent["kind"], ent["n"], name)
+        if name not in ent["out"]:
+            continue                                         # reference undefined there (rccdf4ienc, n < 64)
+        assert o.size == ent["out"][name], (ent["kind"], ent["n"], name)
+        exp = d if o.size == ent["n"] else z["out_%d_%s" % (ent["case"], name)]
+        assert np.array_equal(o, exp), (ent["kind"], ent["n"], name)
+        seen += 1
+    assert seen >= 45

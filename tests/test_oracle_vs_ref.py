@@ -45,3 +45,31 @@ def test_multiblock_adaptive_rans():
         a = T.orc_enc(T.ANSA, d)
         assert np.array_equal(a, T.ref_enc(T.ANSA, d))
         assert np.array_equal(T.orc_dec(T.ANSA, a, n), d)
+
+
+@pytest.mark.parametrize("kind", ["geo", "runs", "uniform"])
+def test_nibble_coders_against_reference(kind):
+    """`turborc -n` coders.  rccdf4ienc is compared from 64 bytes up (below, the reference returns meaningless
+    lengths and crashes: oracle/trc_oracle.c); anscdf4dec of the reference only where n % 4 == 0 (tail defect)."""
+    rng = np.random.default_rng(777)
+    sizes = list(range(1, 72)) + [255, 256, 257, 4095, 4096, 4097, 4098] + [int(x) for x in rng.integers(72, 90000, 10)]
+    for n in sizes:
+        d = T.nibble_bytes(n, 9000 + n, kind)
+        for codec in T.NIBBLE_CODECS:
+            a = T.orc_enc(codec, d)
+            assert np.array_equal(T.orc_dec(codec, a, n), d), (kind, n, T.CODEC_NAMES[codec])
+            if codec == T.RCAI4 and n < 64:
+                continue
+            for v in ("s", "x") if codec == T.ANSA4 else ("",):
+                assert np.array_equal(a, T.ref_enc(codec, d, variant=v)), (kind, n, T.CODEC_NAMES[codec], v)
+                if a.size != n and not (codec == T.ANSA4 and n % 4):
+                    assert np.array_equal(T.ref_dec(codec, a, n, variant=v), d)
+
+
+def test_multiblock_nibble_rans():
+    n = (1 << 22) + 4
+    d = T.nibble_bytes(n, 11, "geo")
+    a = T.orc_enc(T.ANSA4, d)
+    assert np.array_equal(a, T.ref_enc(T.ANSA4, d, variant="x"))
+    assert np.array_equal(T.orc_dec(T.ANSA4, a, n), d)
+    assert np.array_equal(T.ref_dec(T.ANSA4, a, n, variant="s"), d)

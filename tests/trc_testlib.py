@@ -18,8 +18,14 @@ ORACLE_SO = os.path.join(ORACLE_DIR, "libtrc_oracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libtrc_ref.so")
 
 # codec ids == include/trc_hip.h == oracle/trc_oracle.h
-ANS4S, RCS1, RCS2, RCA, ANSA, RCB, RCAI = 1, 2, 3, 4, 5, 6, 7
-CODEC_NAMES = {ANS4S: "anscdf4s", RCS1: "rccdfs", RCS2: "rccdfs2", RCA: "rccdf", ANSA: "anscdf", RCB: "rcs", RCAI: "rccdfi"}
+ANS4S, RCS1, RCS2, RCA, ANSA, RCB, RCAI, RCA4, RCAI4, ANSA4 = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+CODEC_NAMES = {ANS4S: "anscdf4s", RCS1: "rccdfs", RCS2: "rccdfs2", RCA: "rccdf", ANSA: "anscdf", RCB: "rcs", RCAI: "rccdfi",
+               RCA4: "rccdf4", RCAI4: "rccdf4i", ANSA4: "anscdf4"}
+NIBBLE_CODECS = (RCA4, RCAI4, ANSA4)          # `turborc -n` coders: input values 0..15
+# adaptive coders: (oracle encoder, oracle decoder, reference encoder, reference decoder); ANS ones take a variant suffix
+_ADAPTIVE = {RCA: ("rccdfenc", "rccdfdec"), ANSA: ("anscdfenc", "anscdfdec"), RCB: ("rcsenc", "rcsdec"),
+             RCAI: ("rccdfienc", "rccdfidec"), RCA4: ("rccdf4enc", "rccdf4dec"), RCAI4: ("rccdf4ienc", "rccdf4idec"),
+             ANSA4: ("anscdf4enc", "anscdf4dec")}
 STATIC_CODECS = (ANS4S, RCS1, RCS2)
 
 _u8p = C.POINTER(C.c_uint8)
@@ -83,6 +89,20 @@ def runs_bytes(n, seed=3, mean_run=6.0, alpha=1.2):
     return out[:n].copy()
 
 
+def nibble_bytes(n, seed=5, kind="geo"):
+    """`turborc -n` style input: values 0..15.  geo: skewed (geometric); runs: run-heavy; uniform: incompressible-ish."""
+    u = (splitmix64(n, seed) >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+    if kind == "uniform":
+        return (u * 16).astype(np.uint8)
+    v = np.minimum(np.floor(np.log1p(-u) / np.log(0.62)), 15).astype(np.uint8)
+    if kind == "runs":
+        rl = (splitmix64(n, seed + 7) % np.uint64(9)).astype(np.int64) + 1
+        v = np.repeat(v[:n // 4 + 4], rl[:n // 4 + 4])
+        while v.size < n:
+            v = np.concatenate([v, v])
+    return v[:n].copy()
+
+
 def fnv1a64(b):
     """FNV-1a-64 of a bytes-like (for large-case fixtures)."""
     h = 0xCBF29CE484222325
@@ -112,8 +132,9 @@ def oracle():
             f = getattr(lib, name); f.restype = sz; f.argtypes = [_u8p, sz, _u8p, _u16p, C.c_uint]
         lib.orc_anscdf4senc.restype = sz; lib.orc_anscdf4senc.argtypes = [_u8p, sz, _u8p, _u16p]
         lib.orc_anscdf4sdec.restype = sz; lib.orc_anscdf4sdec.argtypes = [_u8p, sz, _u8p, _u16p, C.c_uint]
-        for name in ("orc_rccdfenc", "orc_rccdfdec", "orc_anscdfenc", "orc_anscdfdec", "orc_rcsenc", "orc_rcsdec", "orc_rccdfienc", "orc_rccdfidec"):
-            f = getattr(lib, name); f.restype = sz; f.argtypes = [_u8p, sz, _u8p]
+        for pair in _ADAPTIVE.values():
+            for name in pair:
+                f = getattr(lib, "orc_" + name); f.restype = sz; f.argtypes = [_u8p, sz, _u8p]
         lib.orc_chunked_enc.restype = sz
         lib.orc_chunked_enc.argtypes = [C.c_int, _u8p, sz, sz, _u16p, C.c_uint, _u8p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
         lib.orc_chunked_dec.restype = sz
@@ -151,14 +172,8 @@ def orc_enc(codec, data, cdf=None, cdfnum=256):
         l = o.orc_rccdfsenc(_p8(data), n, _p8(out), _p16(cdf), cdfnum)
     elif codec == RCS2:
         l = o.orc_rccdfs2enc(_p8(data), n, _p8(out), _p16(cdf), cdfnum)
-    elif codec == RCA:
-        l = o.orc_rccdfenc(_p8(data), n, _p8(out))
-    elif codec == ANSA:
-        l = o.orc_anscdfenc(_p8(data), n, _p8(out))
-    elif codec == RCB:
-        l = o.orc_rcsenc(_p8(data), n, _p8(out))
-    elif codec == RCAI:
-        l = o.orc_rccdfienc(_p8(data), n, _p8(out))
+    elif codec in _ADAPTIVE:
+        l = getattr(o, "orc_" + _ADAPTIVE[codec][0])(_p8(data), n, _p8(out))
     else:
         raise ValueError(codec)
     return out[:l].copy()
@@ -178,14 +193,8 @@ def orc_dec(codec, comp, n, cdf=None, cdfnum=256):
         o.orc_rccdfsdec(_p8(src), n, _p8(out), _p16(cdf), cdfnum)
     elif codec == RCS2:
         o.orc_rccdfs2dec(_p8(src), n, _p8(out), _p16(cdf), cdfnum)
-    elif codec == RCA:
-        o.orc_rccdfdec(_p8(src), n, _p8(out))
-    elif codec == ANSA:
-        o.orc_anscdfdec(_p8(src), n, _p8(out))
-    elif codec == RCB:
-        o.orc_rcsdec(_p8(src), n, _p8(out))
-    elif codec == RCAI:
-        o.orc_rccdfidec(_p8(src), n, _p8(out))
+    elif codec in _ADAPTIVE:
+        getattr(o, "orc_" + _ADAPTIVE[codec][1])(_p8(src), n, _p8(out))
     else:
         raise ValueError(codec)
     return out[:n].copy()
@@ -233,7 +242,9 @@ def ref():
             f = getattr(lib, name); f.restype = sz; f.argtypes = [_u8p, sz, _u8p, _u16p, C.c_uint]
         for name in ("anscdf4senc", "anscdf4sencs", "anscdf4sencx"):
             f = getattr(lib, name); f.restype = sz; f.argtypes = [_u8p, sz, _u8p, _u16p]
-        for name in ("rccdfienc", "rccdfidec", "rccdfenc", "rccdfdec", "anscdfenc", "anscdfdec", "anscdfencs", "anscdfdecs", "anscdfencx", "anscdfdecx", "rcsenc", "rcsdec"):
+        names = [n for pair in _ADAPTIVE.values() for n in pair]
+        names += [n + v for n in ("anscdfenc", "anscdfdec", "anscdf4enc", "anscdf4dec") for v in ("s", "x")]
+        for name in names:
             f = getattr(lib, name); f.restype = sz; f.argtypes = [_u8p, sz, _u8p]
         _ref = lib
     return _ref
@@ -261,14 +272,8 @@ def ref_enc(codec, data, cdf=None, cdfnum=256, variant=""):
         l = r.rccdfsenc(pin, n, pout, _p16(cdf), cdfnum)
     elif codec == RCS2:
         l = r.rccdfs2enc(pin, n, pout, _p16(cdf), cdfnum)
-    elif codec == RCA:
-        l = r.rccdfenc(pin, n, pout)
-    elif codec == ANSA:
-        l = getattr(r, "anscdfenc" + variant)(pin, n, pout)
-    elif codec == RCB:
-        l = r.rcsenc(pin, n, pout)
-    elif codec == RCAI:
-        l = r.rccdfienc(pin, n, pout)
+    elif codec in _ADAPTIVE:
+        l = getattr(r, _ADAPTIVE[codec][0] + (variant if codec in (ANSA, ANSA4) else ""))(pin, n, pout)
     else:
         raise ValueError(codec)
     return buf[oo:oo + l].copy()
@@ -288,14 +293,8 @@ def ref_dec(codec, comp, n, cdf=None, cdfnum=256, variant="", search="b"):
         getattr(r, "rccdfs%sdec" % search)(_p8(src), n, _p8(out), _p16(cdf), cdfnum)
     elif codec == RCS2:
         r.rccdfsb2dec(_p8(src), n, _p8(out), _p16(cdf), cdfnum)
-    elif codec == RCA:
-        r.rccdfdec(_p8(src), n, _p8(out))
-    elif codec == ANSA:
-        getattr(r, "anscdfdec" + variant)(_p8(src), n, _p8(out))
-    elif codec == RCB:
-        r.rcsdec(_p8(src), n, _p8(out))
-    elif codec == RCAI:
-        r.rccdfidec(_p8(src), n, _p8(out))
+    elif codec in _ADAPTIVE:
+        getattr(r, _ADAPTIVE[codec][1] + (variant if codec in (ANSA, ANSA4) else ""))(_p8(src), n, _p8(out))
     return out[:n].copy()
 
 
