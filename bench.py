@@ -37,41 +37,64 @@ for p in (os.path.join(ROOT, "turbo-range-coder_amd"), os.path.join(ROOT, "tests
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def make_input(n, rank):
+# what each coder is, and the SURVEY 8d workload it is measured on (text100m: order-0 English-like bytes, cfg 2/4;
+# bwt100m: run-heavy source, cfg 3; nib100m: run-heavy values 0..15 for the `turborc -n` coders)
+CODEC_INFO = {
+    "anscdf4s": ("static-CDF rANS, 2 states (anscdf4senc/anscdf4sdec per chunk), tables in LDS", "text"),
+    "rccdfs":   ("static-CDF range coder (rccdfsenc/rccdfs*dec per chunk), tables in LDS", "text"),
+    "rccdfs2":  ("static-CDF range coder, 2 interleaved streams (rccdfs2enc/rccdfs*2dec per chunk, `-e45`), tables in LDS", "text"),
+    "rcs":      ("bitwise order-0 range coder (rcsenc/rcsdec per chunk), 512 B bit model per lane in LDS", "text"),
+    "rccdf":    ("adaptive-CDF byte range coder (rccdfenc/rccdfdec per chunk), 544 B CDF16 model per lane in LDS", "bwt"),
+    "rccdfi":   ("adaptive-CDF byte range coder, 2 streams (rccdfienc/rccdfidec per chunk), 544 B CDF16 model per lane in LDS", "bwt"),
+    "anscdf":   ("adaptive-CDF byte rANS, 4 states (anscdfenc/anscdfdec per chunk), 544 B CDF16 model per lane in LDS", "bwt"),
+    "rccdf4":   ("adaptive-CDF nibble range coder (rccdf4enc/rccdf4dec per chunk), one CDF16 table per lane in LDS", "nib"),
+    "rccdf4i":  ("adaptive-CDF nibble range coder, 2 streams (rccdf4ienc/rccdf4idec per chunk), one CDF16 table per lane in LDS", "nib"),
+    "anscdf4":  ("adaptive-CDF nibble rANS, 2 states (anscdf4enc/anscdf4dec per chunk), one CDF16 table per lane in LDS", "nib"),
+}
+
+
+def make_input(n, rank, kind="text"):
     import trc_testlib as T
     path = os.environ.get("ENWIK8")
-    if path and os.path.exists(path):
+    if kind == "text" and path and os.path.exists(path):
         d = np.fromfile(path, dtype=np.uint8)
         reps = (n + d.size - 1) // d.size
         return np.tile(d, reps)[:n].copy(), "enwik8"
-    return T.text_bytes(n, 7 + rank), "text100m"
+    if kind == "bwt":
+        return T.runs_bytes(n, 3 + rank), "bwt%dm" % (n // 1000000)
+    if kind == "nib":
+        return T.nibble_bytes(n, 5 + rank, "runs"), "nib%dm" % (n // 1000000)
+    return T.text_bytes(n, 7 + rank), "text%dm" % (n // 1000000)
 
 
-def cpu_baseline(d, cdf, cdfnum, sample):
+def cpu_baseline(codec, d, cdf, cdfnum, sample):
     """CPU timing of the same workload on this box's host cores.
 
     value      all host threads, shard-parallel: the buffer is cut into one shard per thread and every
                thread runs the whole-buffer reference call on its shard (ctypes releases the GIL)
     one_thread the reference's own regime (1 thread, whole-buffer call on the first `sample` bytes)
-    encode = reference anscdf4senc (oracle/_ref) when present, else the oracle port; decode = oracle port
-    orc_anscdf4sdec (the reference has no byte-alphabet static-rANS decoder); the literal
+    encode / decode = the reference functions (oracle/_ref) when present, else the oracle port.  Two decoders are
+    always the oracle port because the reference has none that round-trips: static rANS on a byte alphabet
+     and the nibble rANS when the length is not a multiple of 4.  For the headline coder the literal
     `turborc -e45` pair rccdfs2enc/rccdfsb2dec (all reference) is listed for context."""
     import concurrent.futures as cf
     import trc_testlib as T
     use_ref = T.have_ref()
-    enc = (lambda x: T.ref_enc(T.ANS4S, x, cdf, cdfnum)) if use_ref else (lambda x: T.orc_enc(T.ANS4S, x, cdf, cdfnum))
+    enc = (lambda x: T.ref_enc(codec, x, cdf, cdfnum)) if use_ref else (lambda x: T.orc_enc(codec, x, cdf, cdfnum))
+    ref_dec_ok = use_ref and codec not in (T.ANS4S, T.ANSA4)
+    dec_fn = (lambda c, n_: T.ref_dec(codec, c, n_, cdf, cdfnum)) if ref_dec_ok else (lambda c, n_: T.orc_dec(codec, c, n_, cdf, cdfnum))
     out = {"unit": "MB/s", "kind": "reference" if use_ref else "port"}
 
     s = np.ascontiguousarray(d[:sample])
     best_e = best_d = 1e9
     for _ in range(2):
         t0 = time.perf_counter(); comp = enc(s); t1 = time.perf_counter()
-        dec = T.orc_dec(T.ANS4S, comp, s.size, cdf, cdfnum); t2 = time.perf_counter()
+        dec = dec_fn(comp, s.size); t2 = time.perf_counter()
         best_e, best_d = min(best_e, t1 - t0), min(best_d, t2 - t1)
     assert np.array_equal(dec, s)
     one = {"cores": 1, "encdec_MBps": round(s.size / (best_e + best_d) / 1e6, 2), "enc_MBps": round(s.size / best_e / 1e6, 2),
            "dec_MBps": round(s.size / best_d / 1e6, 2), "sample_bytes": int(s.size)}
-    if use_ref:
+    if use_ref and codec == T.ANS4S:
         t0 = time.perf_counter(); c45 = T.ref_enc(T.RCS2, s, cdf, cdfnum); t1 = time.perf_counter()
         d45 = T.ref_dec(T.RCS2, c45, s.size, cdf, cdfnum); t2 = time.perf_counter()
         assert np.array_equal(d45, s)
@@ -86,15 +109,17 @@ def cpu_baseline(d, cdf, cdfnum, sample):
     with cf.ThreadPoolExecutor(nthr) as ex:
         list(ex.map(lambda x: x.sum(), shards))                        # spin the pool up
         t0 = time.perf_counter(); comps = list(ex.map(enc, shards)); t1 = time.perf_counter()
-        decs = list(ex.map(lambda cx: T.orc_dec(T.ANS4S, cx[0], cx[1].size, cdf, cdfnum), zip(comps, shards))); t2 = time.perf_counter()
+        decs = list(ex.map(lambda cx: dec_fn(cx[0], cx[1].size), zip(comps, shards))); t2 = time.perf_counter()
     assert all(np.array_equal(a, b) for a, b in zip(decs, shards))
     out["value"] = round(n / (t2 - t0) / 1e6, 1)
     out["enc_MBps"] = round(n / (t1 - t0) / 1e6, 1)
     out["dec_MBps"] = round(n / (t2 - t1) / 1e6, 1)
     out["cores"] = nthr
+    name = T.CODEC_NAMES[codec]
     out["sample"] = ("whole workload (%d B) cut into %d shards, one whole-buffer call per thread on %d host threads; encode = %s "
-                     "anscdf4senc, decode = oracle port orc_anscdf4sdec; one_thread = first %d B, min of 2 runs"
-                     % (n, len(shards), nthr, "reference" if use_ref else "oracle port", s.size))
+                     "%senc, decode = %s %sdec; one_thread = first %d B, min of 2 runs"
+                     % (n, len(shards), nthr, "reference" if use_ref else "oracle port", name,
+                        "reference" if ref_dec_ok else "oracle port", name, s.size))
     return out
 
 
@@ -137,7 +162,7 @@ def main():
 
     codec = {v: k for k, v in trc.CODEC_NAMES.items()}[args.codec]
     n, chunk = args.size, args.chunk
-    d, wname = make_input(n, rank)
+    d, wname = make_input(n, rank, CODEC_INFO[args.codec][1])
     d_in = torch.from_numpy(np.concatenate([d, np.zeros(512, np.uint8)])).to(dev)
     dc = trc.DeviceCoder(codec, n, chunk, dev)
     cdfnum = 256
@@ -233,8 +258,8 @@ def main():
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "%s: %d B/GPU, static-CDF rANS (anscdf4senc/anscdf4sdec per chunk), chunk %d B, "
-                                   "1 lane = 1 chunk (2 rANS states), 64 chunks/wave, tables in LDS" % (wname, n, chunk),
+            "config": {"workload": "%s: %d B/GPU, %s, chunk %d B, 1 lane = 1 chunk, 64 chunks/wave"
+                                   % (wname, n, CODEC_INFO[args.codec][0], chunk),
                        "codec": args.codec, "chunk": chunk, "bytes_per_gpu": n, "compressed_bytes_per_gpu": total_c,
                        "ratio": round(total_c / n, 5), "exchange": "rccl gather of payloads to rank 0" if world > 1 else "none"},
             "enc_MBps": round(n / (enc_avg * 1e-3) / 1e6, 1) if enc_avg else None,
@@ -248,7 +273,7 @@ def main():
         if world == 1 and not args.no_cpu:
             cdf = dc.cdf[:cdfnum + 1].cpu().numpy().view(np.uint16).copy()
             cdf_full = np.zeros(257, dtype=np.uint16); cdf_full[:cdfnum + 1] = cdf
-            res["cpu_baseline"] = cpu_baseline(d, cdf_full, cdfnum, min(args.cpu_sample, n))
+            res["cpu_baseline"] = cpu_baseline(codec, d, cdf_full, cdfnum, min(args.cpu_sample, n))
         print(json.dumps(res))
     if use_dist:
         dist.destroy_process_group()

@@ -46,11 +46,23 @@ LIBAPI size_t anscdfdecs(unsigned char *in, size_t outlen, unsigned char *out);
 LIBAPI size_t anscdfencx(unsigned char *in, size_t inlen, unsigned char *out);
 LIBAPI size_t anscdfdecx(unsigned char *in, size_t outlen, unsigned char *out);
 
+/* adaptive-CDF nibble rANS on values 0..15, 2 states (reference include/anscdf.h:44-45,70-75; anscdf.c:87-133;
+ * `turborc -n -e56/57/58`).  The decoder takes the n%4 tail from the state the encoder used (the reference's
+ * decoder does not round-trip such lengths). */
+LIBAPI size_t anscdf4enc(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdf4dec(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdf4enc0(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdf4dec0(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdf4encs(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdf4decs(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdf4encx(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdf4decx(unsigned char *in, size_t outlen, unsigned char *out);
+
 #ifdef __cplusplus
 }
 #endif
 
-/* dispatch globals of the reference (include/anscdf.h:27-33); both point at the functions above */
+/* dispatch globals of the reference (include/anscdf.h:27-35); they point at the functions above */
 typedef LIBAPI size_t (*fanscdfenc)(unsigned char *in, size_t inlen, unsigned char *out);
 typedef LIBAPI size_t (*fanscdfdec)(unsigned char *in, size_t inlen, unsigned char *out);
 #ifdef __cplusplus
@@ -58,6 +70,8 @@ extern "C" {
 #endif
 extern fanscdfenc _anscdfenc;
 extern fanscdfdec _anscdfdec;
+extern fanscdfenc _anscdf4enc;
+extern fanscdfdec _anscdf4dec;
 #ifdef __cplusplus
 }
 #endif

@@ -40,7 +40,11 @@ enum trc_codec {
     TRC_RCA   = 4,  /* rccdfenc    / rccdfdec      adaptive-CDF byte RC           rccdf.c:187-211  (-e46) */
     TRC_ANSA  = 5,  /* anscdfenc   / anscdfdec     adaptive-CDF byte rANS, 4 st.  anscdf.c:567-605 (-e56) */
     TRC_RCB   = 6,  /* rcsenc      / rcsdec        bitwise order-0 RC             rc_.c:37-58      (-e1)  */
-    TRC_RCAI  = 7   /* rccdfienc   / rccdfidec     adaptive-CDF byte RC, 2 streams rccdf.c:213-249 (-e47) */
+    TRC_RCAI  = 7,  /* rccdfienc   / rccdfidec     adaptive-CDF byte RC, 2 streams rccdf.c:213-249 (-e47) */
+    /* the `turborc -n` coders: input values 0..15, one CDF16 table (harness gate m<16, turborc.c:499-520) */
+    TRC_RCA4  = 8,  /* rccdf4enc   / rccdf4dec     adaptive-CDF nibble RC         rccdf.c:250-275  (-n -e46) */
+    TRC_RCAI4 = 9,  /* rccdf4ienc  / rccdf4idec    ... on 2 interleaved streams   rccdf.c:277-323  (-n -e47) */
+    TRC_ANSA4 = 10  /* anscdf4enc  / anscdf4dec    adaptive-CDF nibble rANS, 2 st. anscdf.c:87-133 (-n -e56) */
 };
 
 #define TRC_MAGIC        0x31435254u   /* "TRC1" */

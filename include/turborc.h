@@ -56,6 +56,14 @@ size_t rccdfdec(unsigned char *in, size_t outlen, unsigned char *out);
 size_t rccdfienc(unsigned char *in, size_t inlen, unsigned char *out);
 size_t rccdfidec(unsigned char *in, size_t outlen, unsigned char *out);
 
+/* the `turborc -n` coders: adaptive-CDF range coder on values 0..15, one CDF16 table (reference rccdf.c:250-275 and,
+ * two interleaved streams, rccdf.c:277-323; include/turborc.h:517-519,528-529; harness ids 46/47 when the data is
+ * nibble-valued, turborc.c:499-501).  Values above 15 are outside the reference's contract; their low nibble is coded. */
+size_t rccdf4enc(unsigned char *in, size_t inlen, unsigned char *out);
+size_t rccdf4dec(unsigned char *in, size_t outlen, unsigned char *out);
+size_t rccdf4ienc(unsigned char *in, size_t inlen, unsigned char *out);
+size_t rccdf4idec(unsigned char *in, size_t outlen, unsigned char *out);
+
 /* bitwise order-0 range coder, "s" predictor (reference rc_.c:37-58; `turborc -e1`, file codec 1) */
 size_t rcsenc(unsigned char *in, size_t inlen, unsigned char *out);
 size_t rcsdec(unsigned char *in, size_t outlen, unsigned char *out);

@@ -7,7 +7,12 @@
 #include <vector>
 #include "../turbo-range-coder_amd/csrc/trc_carry.h"
 
-struct Sink { std::vector<uint32_t> w; void put32(uint32_t v) { w.push_back(v); } void put32_slow(uint32_t v) { w.push_back(v); } };
+struct Sink {
+    std::vector<uint32_t> w;
+    void put32(uint32_t v) { w.push_back(v); }
+    void put32_slow(uint32_t v) { w.push_back(v); }
+    void put32_if(bool take, uint32_t v) { if (take) w.push_back(v); }
+};
 
 static uint64_t rng_state = 88172645463325252ull;
 static uint32_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (uint32_t)(rng_state >> 16); }
@@ -40,7 +45,9 @@ int main()
                 if (j + 1 < ref.size()) carries_into_ff++;
             }
             ref.push_back(W); carried.push_back(false);
-            c.emit(s, cy, W);
+            // odd trials go through the predicated entry point, mixed with events that are switched off
+            if (trial & 1) { if (rnd() % 3 == 0) c.emit_if(s, false, rnd() & 1, rnd()); c.emit_if(s, true, cy, W); }
+            else c.emit(s, cy, W);
             if (W == 0xffffffffu) ffruns++;
             if (c.nwords != ref.size()) { printf("nwords mismatch\n"); return 1; }
         }

@@ -28,6 +28,11 @@ def torch_cuda():
     return torch
 
 
+def fit(codec, d):
+    """the `turborc -n` coders take values 0..15 (harness gate m<16): fold any test input into that range"""
+    return (d & 15).astype(np.uint8) if codec in trc.NIBBLE_CODECS else d
+
+
 def to_dev(torch, a):
     return torch.from_numpy(np.concatenate([a, np.zeros(512, np.uint8)])).to("cuda:0")
 
@@ -57,7 +62,7 @@ def device_roundtrip(torch, codec, d, chunk, cdf, cdfnum):
 def test_device_layer_matches_oracle(torch_cuda, codec, kind):
     for n, chunk in [(1, 256), (5, 256), (255, 256), (256, 256), (257, 256), (4096, 4096), (4097, 4096), (70001, 1024),
                      (300007, 4096), (1 << 20, 65536), (999999, 2048)]:
-        d = gen(kind, n, 4000 + n)
+        d = fit(codec, gen(kind, n, 4000 + n))
         _, cdf, cdfnum = T.orc_cdfini(d)
         device_roundtrip(torch_cuda, codec, d, chunk, cdf, cdfnum)
 
@@ -66,9 +71,11 @@ def test_device_layer_matches_oracle(torch_cuda, codec, kind):
 def test_mixed_raw_and_coded_chunks(torch_cuda, codec):
     """incompressible slices inside compressible data: per-chunk raw fallback + raw copy at decode"""
     parts = [gen("zipf", 8192, 1), gen("uniform", 4096, 2), gen("const", 4096, 3), gen("uniform", 8192, 4), gen("text", 5000, 5)]
-    d = np.concatenate(parts)
+    d = fit(codec, np.concatenate(parts))
     _, cdf, cdfnum = T.orc_cdfini(d)
     clen, _ = device_roundtrip(torch_cuda, codec, d, 4096, cdf, cdfnum)
+    if codec in trc.NIBBLE_CODECS:
+        return                                                        # 4-bit values always compress: nothing is stored raw
     assert clen[2] == 4096 and clen[4] == 4096 and clen[5] == 4096      # the uniform slices are stored raw
     assert clen[3] < 4096                                             # the constant slice is coded
 
@@ -76,7 +83,8 @@ def test_mixed_raw_and_coded_chunks(torch_cuda, codec):
 @pytest.mark.parametrize("codec", trc.AVAILABLE, ids=lambda c: trc.CODEC_NAMES[c])
 def test_golden_vectors_single_chunk(torch_cuda, codec):
     """n <= 65536 with chunk >= n: the one payload must equal the reference's whole-buffer output"""
-    z = np.load(os.path.join(GOLD, "vectors.npz"))
+    nib = codec in trc.NIBBLE_CODECS
+    z = np.load(os.path.join(GOLD, "nibble_vectors.npz" if nib else "vectors.npz"))
     index = json.loads(bytes(z["index"]).decode())
     name = trc.CODEC_NAMES[codec]
     done = 0
@@ -86,7 +94,9 @@ def test_golden_vectors_single_chunk(torch_cuda, codec):
         d = z["in_%d" % ent["case"]]
         n = ent["n"]
         chunk = min(65536, max(256, (n + 63) // 64 * 64))
-        cdf = np.zeros(257, dtype=np.uint16); cdf[:ent["cdfnum"] + 1] = z["cdf_%d" % ent["case"]]
+        cdf = np.zeros(257, dtype=np.uint16)
+        if not nib:
+            cdf[:ent["cdfnum"] + 1] = z["cdf_%d" % ent["case"]]
         dc = trc.DeviceCoder(codec, n, chunk, "cuda:0")
         if codec in trc.STATIC:
             dc.set_cdf(cdf, ent["cdfnum"])
@@ -96,7 +106,7 @@ def test_golden_vectors_single_chunk(torch_cuda, codec):
         exp = d if ent["out"][name] == n else z["out_%d_%s" % (ent["case"], name)]
         assert np.array_equal(payload, exp), (ent["kind"], n)
         done += 1
-    assert done > 100
+    assert done > (45 if nib else 100)
 
 
 def test_cdfini_on_device(torch_cuda):
@@ -119,7 +129,7 @@ def test_host_pointer_layer(torch_cuda, codec):
     assert trc.lib().trc_set_chunk(chunk) == 0
     try:
         for kind, n in [("zipf", 100000), ("text", 70001), ("runs", 4096)]:
-            d = gen(kind, n, 31)
+            d = fit(codec, gen(kind, n, 31))
             _, cdf, cdfnum = T.orc_cdfini(d)
             comp = trc.host_encode(codec, d, cdf, cdfnum)
             assert comp.size < n
@@ -129,11 +139,12 @@ def test_host_pointer_layer(torch_cuda, codec):
             assert np.array_equal(clen, exp_clen) and np.array_equal(payload, exp_payload)
             assert comp.size == 32 + 4 * clen.size + payload.size
             assert np.array_equal(trc.host_decode(codec, comp, n, cdf, cdfnum), d)
-        d = gen("uniform", 100000, 9)                      # incompressible: returns n, out == in
-        _, cdf, cdfnum = T.orc_cdfini(d)
-        comp = trc.host_encode(codec, d, cdf, cdfnum)
-        assert comp.size == d.size and np.array_equal(comp, d)
-        d = gen("zipf", 40, 9)                             # tiny: container overhead >= n -> raw
+        if codec not in trc.NIBBLE_CODECS:
+            d = gen("uniform", 100000, 9)                  # incompressible: returns n, out == in
+            _, cdf, cdfnum = T.orc_cdfini(d)
+            comp = trc.host_encode(codec, d, cdf, cdfnum)
+            assert comp.size == d.size and np.array_equal(comp, d)
+        d = fit(codec, gen("zipf", 40, 9))                            # tiny: container overhead >= n -> raw
         _, cdf, cdfnum = T.orc_cdfini(d)
         assert trc.host_encode(codec, d, cdf, cdfnum).size == 40
     finally:
@@ -146,7 +157,7 @@ def test_baseline_size_properties(torch_cuda, codec):
     torch = torch_cuda
     n, chunk = 100 * 1000 * 1000, 4096
     kind = "runs" if codec in (trc.RCA, trc.ANSA) else "text"
-    d = gen(kind, n, 7)
+    d = T.nibble_bytes(n, 7, "runs") if codec in trc.NIBBLE_CODECS else gen(kind, n, 7)
     _, cdf, cdfnum = T.orc_cdfini(d)
     dc = trc.DeviceCoder(codec, n, chunk, "cuda:0")
     if codec in trc.STATIC:
@@ -210,6 +221,7 @@ def test_max_rate_bursts(torch_cuda, codec):
     for start in range(1000, n - 2000, 4096):                  # one burst per chunk, different lengths / phases
         ln = int(rng.integers(60, 700))
         d[start:start + ln] = rng.choice(rare, ln)
+    d = fit(codec, d)
     _, cdf, cdfnum = T.orc_cdfini(d)
     clen, _ = device_roundtrip(torch_cuda, codec, d, chunk, cdf, cdfnum)
     assert (clen < chunk).mean() > 0.9                         # the chunks are coded, not stored raw

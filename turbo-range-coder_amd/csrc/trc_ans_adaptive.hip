@@ -1,81 +1,98 @@
-// trc_ans_adaptive.hip -- adaptive-CDF byte rANS, 4 interleaved states (codec TRC_ANSA; `turborc -e56/57/58`).
-//
-// Per chunk the payload is exactly what anscdfenc returns for that slice (a chunk is far below the
-// reference's 4 MiB block, so it is one block): reference anscdf.c:567-586 (encoder), :588-605
-// (decoder); mnenc8x2/mnflush/mndec8x2 anscdf_.h:114-119,128-138,152-162; model trc_nibmodel.h.
-//     [u32 st3][u32 st2][u32 st1][u32 st0][u16 renorm words in decode order]        (raw if it does not fit)
+// trc_ans_adaptive.hip -- the adaptive-CDF rANS coders (CDF16 model, trc_nibmodel.h):
+//   TRC_ANSA   anscdfenc / anscdfdec    anscdf.c:567-605  `turborc -e56/57/58`     bytes, 4 interleaved states
+//   TRC_ANSA4  anscdf4enc / anscdf4dec  anscdf.c:87-133   `turborc -n -e56/57/58`  nibbles (values 0..15), 2 states
+// Per chunk the payload is exactly what the reference function returns for that slice (a chunk is far below the
+// reference's 4 MiB block, so it is one block); mnenc4/mnenc8x2/mnflush/mndec4/mndec8x2 anscdf_.h:106-162.
+//     ANSA   [u32 st3][u32 st2][u32 st1][u32 st0][u16 renorm words in decode order]     (raw if it does not fit)
+//     ANSA4  [u32 st1][u32 st0][u16 renorm words in decode order]
 //
 // The encoder is inherently two-pass (the model adapts forward, rANS codes backward):
 //   pass 1  trc_ansa_model_kernel : walk the chunk forward through the adaptive model and record
-//           {cdf_lo << 15 | freq} per nibble -- 4 records per byte pair in the reference's push
-//           order (x0.hi -> state 3, x0.lo -> 2, x1.hi -> 1, x1.lo -> 0; an odd tail byte pairs
-//           with a CODED dummy 0).  Records stream to HBM scratch as uniform 64-byte segments
-//           (8 B per input byte: the reference keeps the same stack on the heap, anscdf.c:570).
-//   pass 2  trc_ansa_code_kernel  : pop the records in reverse, one rANS step each on state
-//           3-(r&3); words grow downward from the end of the chunk's scratch region.  The divisor
-//           changes every symbol, so st/f is an f32 estimate plus exact correction (st < 2^31).
-//   Raw rule (mnflush): before EVERY record the reference tests ep <= op + 2 + 16; the test is
-//   monotone, so "true before the last record" decides, which is what pass 2 evaluates.
+//           {cdf_lo << 15 | freq} per nibble.  ANSA: 4 records per byte pair in the reference's push order
+//           (x0.hi -> state 3, x0.lo -> 2, x1.hi -> 1, x1.lo -> 0; an odd tail byte pairs with a CODED dummy 0).
+//           ANSA4: one record per input value; groups of 4 alternate states 1,0,1,0, the n%4 tail uses state 0.
+//           Records stream to HBM scratch as uniform 64-byte segments (8 resp. 4 B per input byte: the reference
+//           keeps the same stack on the heap, anscdf.c:112,570).  Model-bound: the model is the only thing in LDS
+//           (bytes and records move through in-register quad transposes), four waves per CU.
+//   pass 2  trc_ansa_code_kernel  : pop the records in reverse, one rANS step each; words grow downward from the
+//           end of the chunk's scratch region.  The divisor changes every symbol, so st/f is an f32 estimate plus
+//           exact correction (st < 2^31).
+//   Raw rule (mnflush): before EVERY record the reference tests ep <= op + 2 + 4*states; the test is monotone.
+// The decoders read the stream through a 16-byte register window per lane (trc_lane_io.h).  ANSA4's decoder takes
+// the n%4 tail from the state the ENCODER used (the reference decoder's tail reads the other state and does not
+// round-trip: see oracle/trc_oracle.c orc_anscdf4dec).
 #include "trc_io.h"
+#include "trc_lane_io.h"
 #include "trc_nibmodel.h"
 #include "trc_launch.h"
 
-#define ANSA_MODEL_LDS (TRC_NIB_BYTES + 2u * TRC_TILE_BYTES)
-#define ANSA_CODE_LDS  (TRC_TILE_BYTES + TRC_SRING_BYTES + TRC_SEL_BYTES)
-#define ANSA_DEC_LDS   (TRC_NIB_BYTES + TRC_TILE_BYTES + TRC_SRING_BYTES + TRC_SEL_BYTES)
+#define ANSA_MODEL_LDS(NIB) ((NIB) ? TRC_NIB1_BYTES : TRC_NIB_BYTES)
+#define ANSA_CODE_LDS       (TRC_TILE_BYTES + TRC_SRING_BYTES + TRC_SEL_BYTES)
+
+// geometry of the record space of one wave's chunks (record bytes per input byte: 8 / 4)
+template <bool NIB>
+__device__ __forceinline__ WaveChunks ansa_record_space(const WaveChunks &wc)
+{
+    WaveChunks wr = wc;
+    wr.chunk = (NIB ? 4u : 8u) * wc.chunk;
+    wr.lastlen = NIB ? ((4u * wc.lastlen + 15u) & ~15u) : 8u * (wc.lastlen + (wc.lastlen & 1u));
+    return wr;
+}
 
 // ------------------------------------------------------------------------------ encode, pass 1 ---
+template <bool NIB>
 __global__ __launch_bounds__(64) void trc_ansa_model_kernel(
-    const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ recs /* 8*chunk bytes per chunk */)
+    const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ recs)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const u32 lane = threadIdx.x;
-    NibModel m; m.row = smem + lane * TRC_NIB_ROW; m.reset();
+    NibModel<!NIB> m; m.init(smem);
 
     WaveChunks wc;
     wc.c0 = blockIdx.x * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
     wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
     wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
-    WaveChunks wr = wc;                                        // the same chunks in record space
-    wr.chunk = 8u * chunk; wr.lastlen = 8u * (wc.lastlen + (wc.lastlen & 1u));
+    const WaveChunks wr = ansa_record_space<NIB>(wc);
     const bool alive = lane < wc.rows;
     const u32 len = alive ? wc.len_of(lane) : 0u;
-    const u32 plen = len + (len & 1u);                         // bytes coded, dummy included
 
-    TileIn tin; tin.tile = smem + TRC_NIB_BYTES; tin.base = in + (u64)wc.c0 * chunk;
-    TileOut tout; tout.tile = smem + TRC_NIB_BYTES + TRC_TILE_BYTES; tout.base = recs + (u64)wc.c0 * wr.chunk;
-
-    auto rec_nibble = [&](u8 *tb, u32 x) -> u32 {
-        u32 c0, c1; m.bounds(tb, x, c0, c1);
-        NibTable T = m.load(tb); trc_nib_adapt(T, c0); m.store(tb, T);
-        return (c0 << 15) | (c1 - c0);
-    };
+    QuadIn qin; qin.base = in + (u64)wc.c0 * chunk;
+    QuadOut qout; qout.base = recs + (u64)wc.c0 * wr.chunk;
 
     const u32 S = chunk / TRC_SEG;
-    tin.issue(wc, 0);
+    qin.issue(wc, 0);
     for (u32 s = 0; s < S; s++) {
-        tin.commit();
-        if (s + 1 < S) tin.issue(wc, (s + 1) * TRC_SEG);
+        qin.commit();
+        if (s + 1 < S) qin.issue(wc, (s + 1) * TRC_SEG);
+        uint4 pc0 = qin.read(0), pc1 = qin.read(1), pc2 = qin.read(2), pc3 = qin.read(3);
+#pragma nounroll
         for (u32 k = 0; k < 4; k++) {
-            const uint4 v = tin.read(k);
+            const uint4 v = pc0; pc0 = pc1; pc1 = pc2; pc2 = pc3;
+            const u32 p0 = s * TRC_SEG + k * 16u;
+            if (!__ballot(alive && p0 < len)) continue;
             const u32 w[4] = { v.x, v.y, v.z, v.w };
+            if (!NIB) {
 #pragma unroll
-            for (int h = 0; h < 2; h++) {                      // 8 input bytes -> 16 records = one 64-byte record segment
-                const u32 q0 = s * TRC_SEG + k * 16u + (u32)h * 8u;
-                u32 r[16];
+                for (int h = 0; h < 2; h++) {                  // 8 input bytes -> 16 records = one 64-byte record segment
+                    u32 r[16];
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    u32 x = (w[2 * h + (i >> 2)] >> (8 * (i & 3))) & 255u;
-                    const u32 pos = q0 + (u32)i;
-                    if (pos >= len) x = 0;                     // the dummy (and never-used padding)
-                    if (alive && pos < plen) {
-                        r[2 * i] = rec_nibble(m.table(0), x >> 4);
-                        r[2 * i + 1] = rec_nibble(m.table(1u + (x >> 4)), x & 15u);
-                    } else r[2 * i] = r[2 * i + 1] = 0;
+                    for (int i = 0; i < 8; i++) {
+                        u32 x = (w[2 * h + (i >> 2)] >> (8 * (i & 3))) & 255u;
+                        if (p0 + 8u * (u32)h + (u32)i >= len) x = 0;      // the coded dummy of an odd tail (and unused padding)
+                        r[2 * i] = m.record(m.table(0), x >> 4);
+                        r[2 * i + 1] = m.record(m.table(1u + (x >> 4)), x & 15u);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) qout.put((u32)j, make_uint4(r[4 * j], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]));
+                    qout.flush(wr, (p0 + 8u * (u32)h) * 8u);
                 }
+            } else {
+                u32 r[16];                                     // 16 input values -> 16 records
 #pragma unroll
-                for (int j = 0; j < 4; j++) tout.put((u32)j, make_uint4(r[4 * j], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]));
-                tout.flush(wr, q0 * 8u);
+                for (int i = 0; i < 16; i++) r[i] = m.record(m.table(0), (w[i >> 2] >> (8 * (i & 3))) & 15u);
+#pragma unroll
+                for (int j = 0; j < 4; j++) qout.put((u32)j, make_uint4(r[4 * j], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]));
+                qout.flush(wr, p0 * 4u);
             }
         }
     }
@@ -95,6 +112,7 @@ __device__ __forceinline__ void ansa_put(u32 &st, u32 rec, StreamOut<true> &so)
     st = (q << TRC_PROB_BITS) + r + c0;
 }
 
+template <bool NIB>
 __global__ __launch_bounds__(64) void trc_ansa_code_kernel(
     const u8 *__restrict__ recs, u64 n, u32 chunk, u32 nchunks,
     u8 *__restrict__ scratch, u32 stride, u32 *__restrict__ clen, u32 *__restrict__ gsum)
@@ -105,11 +123,13 @@ __global__ __launch_bounds__(64) void trc_ansa_code_kernel(
     wc.c0 = blockIdx.x * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
     wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
     wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
-    WaveChunks wr = wc; wr.chunk = 8u * chunk; wr.lastlen = 8u * (wc.lastlen + (wc.lastlen & 1u));
+    const WaveChunks wr = ansa_record_space<NIB>(wc);
     const bool alive = lane < wc.rows;
     const u32 c = wc.c0 + lane;
     const u32 len = alive ? wc.len_of(lane) : 0u;
-    const u32 nrec = 2u * (len + (len & 1u));                  // 4 per byte pair
+    const u32 nrec = NIB ? len : 2u * (len + (len & 1u));      // ANSA: 4 per byte pair
+    const u32 body = len & ~3u;                                // ANSA4: records below this alternate states 1,0,1,0
+    const u32 room = 2u + 4u * (NIB ? 2u : 4u);                // mnflush: ep <= op + sizeof(io_t) + states * 4  ->  raw
 
     TileIn tin; tin.tile = smem; tin.base = recs + (u64)wc.c0 * wr.chunk;
     StreamOut<true> so;
@@ -117,9 +137,8 @@ __global__ __launch_bounds__(64) void trc_ansa_code_kernel(
     so.scratch = scratch; so.stride = stride; so.c0 = wc.c0; so.wpos = 0; so.nfl = 0;
     u32 st[4] = { TRC_ANS_LOW, TRC_ANS_LOW, TRC_ANS_LOW, TRC_ANS_LOW };
     bool ovf = false;
-    u32 wpos_last = 0;                                         // words position just before the LAST record (record 0)
 
-    const u32 S = (8u * chunk) / TRC_SEG;                      // record segments (16 records each) in a full chunk
+    const u32 S = wr.chunk / TRC_SEG;                          // record segments (16 records each) in a full chunk
     const u32 top = alive ? (nrec - 1u) / 16u : 0u;
     tin.issue(wr, (S - 1u) * TRC_SEG);
     for (u32 s = S - 1u;; s--) {
@@ -134,10 +153,14 @@ __global__ __launch_bounds__(64) void trc_ansa_code_kernel(
 #pragma unroll
             for (int i = 15; i >= 0; i--) {
                 if ((u32)i < hi && !ovf) {
-                    if (so.wpos + 18u >= len) ovf = true;      // mnflush: ep <= op + 2 + 16  ->  goto ovr (raw)
-                    else {
-                        if (s == 0 && i == 0) wpos_last = so.wpos;
-                        ansa_put(st[3 - (i & 3)], rr[i], so);  // record index 16*s + i, 16*s is a multiple of 4
+                    if (so.wpos + room >= len) ovf = true;
+                    else if (!NIB) ansa_put(st[3 - (i & 3)], rr[i], so);      // record index 16*s + i, 16*s is a multiple of 4
+                    else if (i & 1) ansa_put(st[0], rr[i], so);
+                    else {                                     // even position: state 1 inside the body, state 0 in the tail
+                        const bool one = 16u * s + (u32)i < body;
+                        u32 cur = one ? st[1] : st[0];
+                        ansa_put(cur, rr[i], so);
+                        st[1] = one ? cur : st[1]; st[0] = one ? st[0] : cur;
                     }
                 }
             }
@@ -145,11 +168,10 @@ __global__ __launch_bounds__(64) void trc_ansa_code_kernel(
         so.drain(false, alive);                                // <= 32 new bytes (16 records) per lane
         if (s == 0) break;
     }
-    (void)wpos_last;
     u32 out_len = 0;
     if (alive) {
         if (!ovf) {
-            for (int k = 0; k < 4; k++) { so.put16(st[k] >> 16); so.put16(st[k]); }
+            for (int k = 0; k < (NIB ? 2 : 4); k++) { so.put16(st[k] >> 16); so.put16(st[k]); }
             if (so.wpos >= len) ovf = true;
         }
         out_len = ovf ? len : so.wpos;
@@ -161,14 +183,14 @@ __global__ __launch_bounds__(64) void trc_ansa_code_kernel(
 }
 
 // ------------------------------------------------------------------------------------- decode ---
+template <bool NIB>
 __global__ __launch_bounds__(64) void trc_ansa_dec_kernel(
     const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
     u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const u32 lane = threadIdx.x;
-    NibModel m; m.row = smem + lane * TRC_NIB_ROW; m.reset();
-    u8 *wbase = smem + TRC_NIB_BYTES;
+    NibModel<!NIB> m; m.init(smem);
 
     WaveChunks wc;
     wc.c0 = blockIdx.x * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
@@ -181,62 +203,77 @@ __global__ __launch_bounds__(64) void trc_ansa_dec_kernel(
     const u32 ex = trc_wave_incl_scan(cl) - cl;
     const u64 off = trc_group_base(goff, gsum, wc.c0 >> 6) + ex;
     const bool coded = alive && cl != len;
+    const u32 body = len & ~3u;
 
-    TileOut tout; tout.tile = wbase; tout.base = out + (u64)wc.c0 * chunk;
-    StreamIn si;
-    si.rings = wbase + TRC_TILE_BYTES; si.sel = wbase + TRC_TILE_BYTES + TRC_SRING_BYTES;
-    si.gbase = payload; si.soff = off + 16;                    // words follow the four states
-    u32 st[4] = { 0, 0, 0, 0 };
-    if (coded) for (int k = 0; k < 4; k++) st[k] = trc_ld32_a2(payload + off + 4 * k);   // decoder st[i] = encoder st[3-i] (mnfill)
-    si.prime(coded);
+    constexpr u32 NST = NIB ? 2u : 4u;
+    u32 st[4] = { TRC_ANS_LOW, TRC_ANS_LOW, TRC_ANS_LOW, TRC_ANS_LOW };
+    if (coded) for (u32 k = 0; k < NST; k++) st[k] = trc_ld32_a2(payload + off + 4u * k);   // decoder st[i] = encoder st[NST-1-i] (mnfill)
+    LaneIn<2> si; si.prime(payload + off + 4u * NST, coded);   // words follow the states
 
-    // cdf16ansdec: search + state update + model update; the renorm comes later (order matters)
-    auto get_nibble = [&](u32 &s, u8 *tb) -> u32 {
+    // cdf16ansdec: search + state update + model update; the renorm comes separately (its order is the word order)
+    auto get_nibble = [&](u32 &s, u8 *tb, bool act) -> u32 {
         const u32 slot = s & (TRC_PROB_ONE - 1);
         NibTable T = m.load(tb);
-        const u32 x = 15u - trc_nib_count_gt(T, slot);
-        u32 c0, c1; m.bounds(tb, x, c0, c1);
-        s = __umul24(c1 - c0, s >> TRC_PROB_BITS) + slot - c0;
-        trc_nib_adapt(T, slot); m.store(tb, T);
+        u32 c0, c1;
+        const u32 x = trc_nib_find(T, slot, c0, c1);
+        s = act ? __umul24(c1 - c0, s >> TRC_PROB_BITS) + slot - c0 : s;
+        m.adapt(T, x); m.store(tb, T);
         return x;
     };
-    auto renorm = [&](u32 &s) {
+    auto renorm = [&](u32 &s, bool act) {
         const u32 w = si.peek16();
-        const bool rn = s < TRC_ANS_LOW;
+        const bool rn = act && s < TRC_ANS_LOW;
         s = rn ? (s << 16) | w : s;
-        si.rpos += rn ? 2u : 0u;
-    };
-    auto get_pair = [&]() -> u32 {                             // mndec8x2: two bytes, then four renorms in order st0..st3
-        const u32 h0 = get_nibble(st[0], m.table(0)), l0 = get_nibble(st[1], m.table(1u + h0));
-        const u32 h1 = get_nibble(st[2], m.table(0)), l1 = get_nibble(st[3], m.table(1u + h1));
-        renorm(st[0]); renorm(st[1]); renorm(st[2]); renorm(st[3]);
-        return (h0 << 4 | l0) | (h1 << 4 | l1) << 8;
+        si.skip_if(rn);
     };
 
-    const u32 S = chunk / TRC_SEG;
+    QuadOut qout; qout.base = out + (u64)wc.c0 * chunk;
     u8 *dst = out + (u64)c * chunk;
+    const u32 S = chunk / TRC_SEG;
     for (u32 s = 0; s < S; s++) {
+        uint4 pc0 = make_uint4(0, 0, 0, 0), pc1 = pc0, pc2 = pc0, pc3 = pc0;
+#pragma nounroll
         for (u32 k = 0; k < 4; k++) {
             const u32 p0 = s * TRC_SEG + k * 16u;
-            u32 w[4] = { 0, 0, 0, 0 };
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (__ballot(coded && p0 < len)) {
+#pragma nounroll
+                for (u32 d = 0; d < 4; d++) {
+                    const u32 q0 = p0 + d * 4u;
+                    u32 w = 0;
+                    if (!NIB) {
 #pragma unroll
-            for (int hh = 0; hh < 2; hh++) {                   // period = 8 bytes = 4 pairs: <= 16 renorm words = 32 B
-                const u32 q0 = p0 + (u32)hh * 8u;
-                si.period(coded && q0 < len, hh);
+                        for (int j = 0; j < 2; j++) {          // mndec8x2: two bytes, then four renorms in order st0..st3
+                            const bool act = coded && q0 + 2u * (u32)j < len;     // the second byte of an odd tail is the dummy
+                            const u32 h0 = get_nibble(st[0], m.table(0), act), l0 = get_nibble(st[1], m.table(1u + h0), act);
+                            const u32 h1 = get_nibble(st[2], m.table(0), act), l1 = get_nibble(st[3], m.table(1u + h1), act);
+                            renorm(st[0], act); renorm(st[1], act); renorm(st[2], act); renorm(st[3], act);
+                            w |= ((h0 << 4 | l0) | (h1 << 4 | l1) << 8) << (16 * j);
+                        }
+                    } else {
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const u32 pos = q0 + 2u * (u32)j;
-                    if (coded && pos < len) {
-                        const u32 two = get_pair();
-                        w[2 * hh + (j >> 1)] |= two << (16 * (j & 1));
+                        for (int i = 0; i < 4; i++) {          // mndec4: positions 0,2 of a group <- st[0], 1,3 <- st[1]; tail <- st[1]
+                            const u32 pos = q0 + (u32)i;
+                            const bool act = coded && pos < len;
+                            const bool first = !(i & 1) && pos < body;
+                            u32 cur = first ? st[0] : st[1];
+                            const u32 x = get_nibble(cur, m.table(0), act);
+                            renorm(cur, act);
+                            st[0] = first ? cur : st[0]; st[1] = first ? st[1] : cur;
+                            w |= x << (8 * i);
+                        }
                     }
+                    v.x = v.y; v.y = v.z; v.z = v.w; v.w = w;
+                }
+                if (coded && p0 < len && p0 + 16u > len) {      // ragged end of the last chunk: byte stores
+                    const u32 ww[4] = { v.x, v.y, v.z, v.w };
+                    for (u32 pos = p0; pos < len; pos++) dst[pos] = (u8)(ww[(pos - p0) >> 2] >> (8 * ((pos - p0) & 3u)));
                 }
             }
-            if (coded && p0 + 16u <= len) tout.put(k, make_uint4(w[0], w[1], w[2], w[3]));
-            else if (coded && p0 < len)
-                for (u32 pos = p0; pos < len; pos++) dst[pos] = (u8)(w[(pos - p0) >> 2] >> (8 * ((pos - p0) & 3u)));
+            pc0 = pc1; pc1 = pc2; pc2 = pc3; pc3 = v;
         }
-        tout.flush(wc, s * TRC_SEG);
+        qout.put(0, pc0); qout.put(1, pc1); qout.put(2, pc2); qout.put(3, pc3);
+        qout.flush(wc, s * TRC_SEG);
     }
     u64 rawmask = __ballot(alive && cl == len && len != 0);
     while (rawmask) {
@@ -249,22 +286,26 @@ __global__ __launch_bounds__(64) void trc_ansa_dec_kernel(
 }
 
 // ------------------------------------------------------------------------------------- launch ---
-void trc_launch_ansa_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
+template <bool NIB>
+static void launch_ansa_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
 {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)trc_ansa_model_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ANSA_MODEL_LDS);
-        attr = true;
-    }
-    hipLaunchKernelGGL(trc_ansa_model_kernel, dim3(w.ngroups), dim3(64), ANSA_MODEL_LDS, s, d_in, (u64)n, chunk, w.nchunks, w.scratch2);
-    hipLaunchKernelGGL(trc_ansa_code_kernel, dim3(w.ngroups), dim3(64), ANSA_CODE_LDS, s,
+    hipLaunchKernelGGL((trc_ansa_model_kernel<NIB>), dim3(w.ngroups), dim3(64), ANSA_MODEL_LDS(NIB), s, d_in, (u64)n, chunk, w.nchunks, w.scratch2);
+    hipLaunchKernelGGL((trc_ansa_code_kernel<NIB>), dim3(w.ngroups), dim3(64), ANSA_CODE_LDS, s,
                        (const u8 *)w.scratch2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
 }
-void trc_launch_ansa_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
+template <bool NIB>
+static void launch_ansa_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
+                            const TrcWork &w, uint8_t *d_out, hipStream_t s)
+{
+    hipLaunchKernelGGL((trc_ansa_dec_kernel<NIB>), dim3(w.ngroups), dim3(64), ANSA_MODEL_LDS(NIB), s,
+                       d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, d_out);
+}
+void trc_launch_ansa_enc(int nibble, const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
+{
+    if (nibble) launch_ansa_enc<true>(d_in, n, chunk, w, d_clen, s); else launch_ansa_enc<false>(d_in, n, chunk, w, d_clen, s);
+}
+void trc_launch_ansa_dec(int nibble, const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                          const TrcWork &w, uint8_t *d_out, hipStream_t s)
 {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)trc_ansa_dec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ANSA_DEC_LDS); attr = true; }
-    hipLaunchKernelGGL(trc_ansa_dec_kernel, dim3(w.ngroups), dim3(64), ANSA_DEC_LDS, s,
-                       d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, d_out);
+    if (nibble) launch_ansa_dec<true>(d_payload, d_clen, n, chunk, w, d_out, s); else launch_ansa_dec<false>(d_payload, d_clen, n, chunk, w, d_out, s);
 }

@@ -63,10 +63,13 @@ extern "C" int trc_set_chunk(uint32_t chunk)
 #define TRC_INKERNEL_SCAN_MAX 8192u
 static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline bool is_static(int codec) { return codec == TRC_ANS4S || codec == TRC_RCS1 || codec == TRC_RCS2; }
-static inline bool codec_ok(int codec) { return codec == TRC_ANS4S || codec == TRC_RCS1 || codec == TRC_RCS2 || codec == TRC_RCB || codec == TRC_RCA || codec == TRC_ANSA || codec == TRC_RCAI; }
-static inline int nregions(int codec) { return (codec == TRC_RCS2 || codec == TRC_RCAI) ? 2 : 1; }
+static inline bool codec_ok(int codec) { return codec >= TRC_ANS4S && codec <= TRC_ANSA4; }
+static inline bool two_streams(int codec) { return codec == TRC_RCS2 || codec == TRC_RCAI || codec == TRC_RCAI4; }
 // second scratch array: RCS2 stream 1 (same stride) or ANSA's record stack (8 B per input byte + one segment)
-static inline size_t scratch2_stride(int codec, uint32_t chunk) { return (codec == TRC_RCS2 || codec == TRC_RCAI) ? chunk + 128 : codec == TRC_ANSA ? 8 * (size_t)chunk : 0; }
+static inline size_t scratch2_stride(int codec, uint32_t chunk)
+{
+    return two_streams(codec) ? chunk + 128 : codec == TRC_ANSA ? 8 * (size_t)chunk : codec == TRC_ANSA4 ? 4 * (size_t)chunk : 0;
+}
 
 static uint32_t scratch_stride(int codec, uint32_t chunk)
 {
@@ -199,9 +202,12 @@ extern "C" int trc_encode_dev(int codec, const void *d_in, size_t n, uint32_t ch
     case TRC_RCS1:  trc_launch_rcs_enc(1, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 0; break;
     case TRC_RCS2:  trc_launch_rcs_enc(2, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 2; break;
     case TRC_RCB:   trc_launch_rcb_enc((const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 0; break;
-    case TRC_RCA:   trc_launch_rca_enc(1, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 0; break;
-    case TRC_RCAI:  trc_launch_rca_enc(2, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 2; break;
-    case TRC_ANSA:  trc_launch_ansa_enc((const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 1; break;
+    case TRC_RCA:   trc_launch_rca_enc(1, 0, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 0; break;
+    case TRC_RCAI:  trc_launch_rca_enc(2, 0, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 2; break;
+    case TRC_RCA4:  trc_launch_rca_enc(1, 1, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 0; break;
+    case TRC_RCAI4: trc_launch_rca_enc(2, 1, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 2; break;
+    case TRC_ANSA:  trc_launch_ansa_enc(0, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 1; break;
+    case TRC_ANSA4: trc_launch_ansa_enc(1, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 1; break;
     }
     tm_end(0, tmi, s);
     if (w.goff) trc_launch_scan_groups(w.gsum, w.ngroups, w.goff, d_total, s);
@@ -231,9 +237,12 @@ extern "C" int trc_decode_dev(int codec, const uint32_t *d_clen, const void *d_p
     case TRC_RCS1:  trc_launch_rcs_dec(1, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     case TRC_RCS2:  trc_launch_rcs_dec(2, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     case TRC_RCB:   trc_launch_rcb_dec((const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
-    case TRC_RCA:   trc_launch_rca_dec(1, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
-    case TRC_RCAI:  trc_launch_rca_dec(2, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
-    case TRC_ANSA:  trc_launch_ansa_dec((const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
+    case TRC_RCA:   trc_launch_rca_dec(1, 0, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
+    case TRC_RCAI:  trc_launch_rca_dec(2, 0, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
+    case TRC_RCA4:  trc_launch_rca_dec(1, 1, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
+    case TRC_RCAI4: trc_launch_rca_dec(2, 1, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
+    case TRC_ANSA:  trc_launch_ansa_dec(0, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
+    case TRC_ANSA4: trc_launch_ansa_dec(1, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     }
     tm_end(1, tmi, s);
     HIPCHK(hipGetLastError());
@@ -246,8 +255,8 @@ extern "C" const char *trc_kernel_name(int codec, int decode)
     case TRC_ANS4S: return decode ? "trc_ans4s_dec_kernel" : "trc_ans4s_enc_kernel";
     case TRC_RCS1: case TRC_RCS2: return decode ? "trc_rcs_dec_kernel" : "trc_rcs_enc_kernel";
     case TRC_RCB: return decode ? "trc_rcb_dec_kernel" : "trc_rcb_enc_kernel";
-    case TRC_RCA: case TRC_RCAI: return decode ? "trc_rca_dec_kernel" : "trc_rca_enc_kernel";
-    case TRC_ANSA: return decode ? "trc_ansa_dec_kernel" : "trc_ansa_code_kernel";
+    case TRC_RCA: case TRC_RCAI: case TRC_RCA4: case TRC_RCAI4: return decode ? "trc_rca_dec_kernel" : "trc_rca_enc_kernel";
+    case TRC_ANSA: case TRC_ANSA4: return decode ? "trc_ansa_dec_kernel" : "trc_ansa_model_kernel";
     }
     return "";
 }
@@ -435,9 +444,26 @@ TRC_EXPORT_ANSA()
 TRC_EXPORT_ANSA(0)
 TRC_EXPORT_ANSA(s)
 TRC_EXPORT_ANSA(x)
+// the `turborc -n` coders on values 0..15 -- SURVEY 8f rank 1
+// adaptive-CDF nibble range coder, one stream (reference rccdf.c:250-275) and interleaved (rccdf.c:277-323)
+size_t rccdf4enc(unsigned char *in, size_t inlen, unsigned char *out) { return host_encode(TRC_RCA4, in, inlen, out, nullptr, 0); }
+size_t rccdf4dec(unsigned char *in, size_t outlen, unsigned char *out) { return host_decode(TRC_RCA4, in, outlen, out, nullptr, 0); }
+size_t rccdf4ienc(unsigned char *in, size_t inlen, unsigned char *out) { return host_encode(TRC_RCAI4, in, inlen, out, nullptr, 0); }
+size_t rccdf4idec(unsigned char *in, size_t outlen, unsigned char *out) { return host_decode(TRC_RCAI4, in, outlen, out, nullptr, 0); }
+// adaptive-CDF nibble rANS (reference anscdf.c:87-133, dispatch :814-815)
+#define TRC_EXPORT_ANSA4(sfx) \
+    size_t anscdf4enc##sfx(unsigned char *in, size_t inlen, unsigned char *out) { return host_encode(TRC_ANSA4, in, inlen, out, nullptr, 0); } \
+    size_t anscdf4dec##sfx(unsigned char *in, size_t outlen, unsigned char *out) { return host_decode(TRC_ANSA4, in, outlen, out, nullptr, 0); }
+TRC_EXPORT_ANSA4()
+TRC_EXPORT_ANSA4(0)
+TRC_EXPORT_ANSA4(s)
+TRC_EXPORT_ANSA4(x)
+
 typedef size_t (*fanscdfenc)(unsigned char *in, size_t inlen, unsigned char *out);
 typedef size_t (*fanscdfdec)(unsigned char *in, size_t inlen, unsigned char *out);
-fanscdfenc _anscdfenc = anscdfenc;      // the reference's dispatch globals (include/anscdf.h:32-33)
+fanscdfenc _anscdfenc = anscdfenc;      // the reference's dispatch globals (include/anscdf.h:32-35)
 fanscdfdec _anscdfdec = anscdfdec;
+fanscdfenc _anscdf4enc = anscdf4enc;
+fanscdfdec _anscdf4dec = anscdf4dec;
 
 }  // extern "C"

@@ -44,6 +44,17 @@ struct TrcCarry {
             cache = W;
         }
     }
+    // Predicated form for branch-free symbol loops: the event happens only where `on`.  SINK additionally needs
+    // put32_if(bool, uint32_t).  The common case costs no branch; everything else takes the general path.
+    template <class SINK>
+    TRC_HD void emit_if(SINK &so, bool on, bool cy, uint32_t W)
+    {
+        const bool fast = on && have && !cy && npend == 0 && W != 0xffffffffu;
+        so.put32_if(fast, cache);
+        cache = fast ? W : cache;
+        nwords += fast ? 1u : 0u;
+        if (on && !fast) emit(so, cy, W);
+    }
     template <class SINK>
     TRC_HD void release(SINK &so)                                      // end of stream: nothing can carry any more
     {

@@ -1,0 +1,71 @@
+// trc_lane_io.h -- per-lane register-window stream I/O for the MODEL-BOUND coders (adaptive CDF16 coders).
+//
+// The static coders move their variable-rate streams through per-lane LDS rings and leave the CU in whole
+// 64-byte segments (trc_io.h), because they run at more than 1 TB/s and every scattered 16-byte lane access
+// costs ~5 TA cycles.  The adaptive coders are two orders of magnitude below that rate (their time goes into
+// the 16-entry table update of every nibble) and their occupancy is set by LDS: the byte model is 544 B per
+// lane, 35 KiB per wave.  For them a stream is a 16-byte register window per lane:
+//   LaneOut32  appends 32-bit words; every fourth word the lane stores its 16 bytes itself;
+//   LaneIn     keeps the current and the next 16 bytes of the lane's stream in registers; the next window is
+//              requested when the current one is used up, i.e. 16 bytes (>= 4 renormalisations) ahead.
+// No LDS at all, so four model-carrying waves fit a CU (one per SIMD).  At <= 1 scattered access per ~40
+// coded nibbles the TA cost is noise (profiles/r01_notes.md).
+#pragma once
+#include "trc_dev.h"
+
+struct __attribute__((packed, aligned(4))) trc_u128_a4 { u32 x, y, z, w; };
+
+struct LaneOut32 {
+    u8 *dst;             // this lane's region (4-byte aligned)
+    u32 wpos;            // bytes appended
+    u32 h0, h1, h2;      // the last three words, h2 newest (what is not stored yet lives here)
+
+    __device__ __forceinline__ void start(u8 *d) { dst = d; wpos = 0; h0 = h1 = h2 = 0; }
+    __device__ __forceinline__ void put32_if(bool take, u32 v)
+    {
+        if (take && (wpos & 12u) == 12u) {
+            trc_u128_a4 q; q.x = h0; q.y = h1; q.z = h2; q.w = v;
+            *(trc_u128_a4 *)(dst + wpos - 12u) = q;
+        }
+        h0 = take ? h1 : h0; h1 = take ? h2 : h1; h2 = take ? v : h2;
+        wpos += take ? 4u : 0u;
+    }
+    __device__ __forceinline__ void put32(u32 v) { put32_if(true, v); }
+    __device__ __forceinline__ void put32_slow(u32 v) { put32_if(true, v); }
+    // store the words still held (0..3)
+    __device__ __forceinline__ void finish(bool ok)
+    {
+        const u32 cnt = (wpos >> 2) & 3u;
+        if (ok && cnt >= 3u) *(u32 *)(dst + wpos - 12u) = h0;
+        if (ok && cnt >= 2u) *(u32 *)(dst + wpos - 8u) = h1;
+        if (ok && cnt >= 1u) *(u32 *)(dst + wpos - 4u) = h2;
+    }
+};
+
+// UNIT = bytes per consumed unit (4: range coders, 2: rANS)
+template <int UNIT>
+struct LaneIn {
+    const u8 *src;       // this lane's stream (2-byte aligned; the payload buffer carries TRC_PAD bytes of slack)
+    u32 rpos;            // bytes consumed
+    uint4 cur, nxt;      // stream bytes [16*(rpos/16), +16) and the 16 after them
+
+    __device__ __forceinline__ void prime(const u8 *s, bool alive)
+    {
+        src = s; rpos = 0;
+        cur = nxt = make_uint4(0, 0, 0, 0);
+        if (alive) { cur = trc_ld16_a2(src); nxt = trc_ld16_a2(src + 16); }
+    }
+    __device__ __forceinline__ u32 word() const
+    {
+        const bool b0 = rpos & 4u, b1 = rpos & 8u;
+        const u32 lo = b0 ? cur.y : cur.x, hi = b0 ? cur.w : cur.z;
+        return b1 ? hi : lo;
+    }
+    __device__ __forceinline__ u32 peek32() const { return word(); }
+    __device__ __forceinline__ u32 peek16() const { const u32 w = word(); return (rpos & 2u) ? w >> 16 : w & 0xffffu; }
+    __device__ __forceinline__ void skip_if(bool take)
+    {
+        rpos += take ? (u32)UNIT : 0u;
+        if (take && (rpos & 15u) == 0u) { cur = nxt; nxt = trc_ld16_a2(src + rpos + 16u); }
+    }
+};

@@ -52,14 +52,16 @@ void trc_launch_rcb_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const Trc
 void trc_launch_rcb_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                         const TrcWork &w, uint8_t *d_out, hipStream_t s);
 
-// RCA / RCAI: adaptive-CDF byte range coder, 1 stream (rccdfenc / rccdfdec) or hi/lo nibbles on 2 streams (rccdfienc / rccdfidec)
-void trc_launch_rca_enc(int nstreams, const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s);
-void trc_launch_rca_dec(int nstreams, const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
+// RCA / RCAI: adaptive-CDF byte range coder, 1 stream (rccdfenc / rccdfdec) or hi/lo nibbles on 2 streams (rccdfienc / rccdfidec);
+// nibble != 0: the `turborc -n` coders on values 0..15 (rccdf4enc/dec, rccdf4ienc/idec)
+void trc_launch_rca_enc(int nstreams, int nibble, const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s);
+void trc_launch_rca_dec(int nstreams, int nibble, const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                         const TrcWork &w, uint8_t *d_out, hipStream_t s);
 
 // ANSA: adaptive-CDF byte rANS (anscdfenc / anscdfdec); scratch2 holds the 8 B/byte record stack
-void trc_launch_ansa_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s);
-void trc_launch_ansa_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
+// nibble != 0: anscdf4enc / anscdf4dec on values 0..15 (2 states, 4 B/byte record stack)
+void trc_launch_ansa_enc(int nibble, const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s);
+void trc_launch_ansa_dec(int nibble, const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                          const TrcWork &w, uint8_t *d_out, hipStream_t s);
 
 // cdfini on device

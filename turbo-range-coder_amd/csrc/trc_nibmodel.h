@@ -1,23 +1,32 @@
-// trc_nibmodel.h -- the adaptive 16-symbol CDF model ("CDF16", rate 7) of the reference, per lane,
-// in LDS.  Reference: init CDF16DEC0/1 cdf_.h:26-27,40-41 (cdf[j] = j<<11); update cdf16upd
-// cdf_.h:46-50 (AVX2) == :87-97 (SSE) -- the SIMD rule is normative, the scalar fallback of
-// cdf_.h:112-117 is a different formula.  After coding symbol x whose lower bound was
-// c = t[x] (read BEFORE the update), in int16 lanes with arithmetic shift:
+// trc_nibmodel.h -- the adaptive 16-symbol CDF model ("CDF16", rate 7) of the reference, per lane, in LDS.
+// Reference: init CDF16DEC0/1 cdf_.h:26-27,40-41 (cdf[j] = j<<11); update cdf16upd cdf_.h:46-50 (AVX2) ==
+// :87-97 (SSE) -- the SIMD rule is normative, the scalar fallback of cdf_.h:112-117 is a different formula
+// (SURVEY F7).  After coding symbol x whose lower bound was c = t[x] (read BEFORE the update), in int16 lanes
+// with arithmetic shift:
 //        t[i] += ((10*i - t[i]) + (t[i] > c ? 32736 : 0)) >> 7          i = 0..15
-// A byte model is one "hi" table plus 16 "lo" tables selected by the hi nibble (rccdf.c:202,
-// anscdf.c:574-575): 17 x 16 x u16 = 544 B per lane.  Entry 16 (= 32768) is never stored.
+// A byte model is one "hi" table plus 16 "lo" tables selected by the hi nibble (rccdf.c:202, anscdf.c:574-575):
+// 17 x 16 x u16 = 544 B per lane; the nibble coders (`turborc -n`) use a single table.  Entry 16 (= 32768) is
+// never stored.
 //
-// gfx950 mapping: a table is 32 B = 8 dwords of packed int16 pairs; the update is 7 packed-16
-// VALU ops per dword (v_pk_sub_i16 / v_pk_ashrrev_i16 / v_and / v_pk_add_i16), tables are moved
-// with two ds_read_b128 + two ds_write_b128.  Lane rows are 560 B apart (140 dwords: 16
-// consecutive lanes x 4 banks tile all 64 banks, so equal-offset b128 accesses are conflict free).
+// gfx950 mapping.  A table is 32 B = 8 dwords of packed int16 pairs, moved with two ds_read_b128 / two
+// ds_write_b128.  The tables are strictly increasing (the update keeps t[i+1] - t[i] >= 1: both targets are
+// 10 apart and the step is 1/128 of the distance, floor), so "t[i] > t[x]" is "i > x" and the update is
+//        t[i] += (K[x][i] - t[i]) >> 7,        K[x][i] = 10*i + (i > x ? 32736 : 0)   (mod 2^16)
+// with K a 16 x 16 constant table (512 B per wave in LDS): three packed-16 VALU ops per dword
+// (v_pk_sub_i16, v_pk_ashrrev_i16, v_pk_add_i16) instead of seven.  Decoders find the symbol by a binary
+// search over the register copy of the table (10 v_cndmask), which also yields both bounds.
+// Lane rows: 560 B apart for the byte model (140 dwords), 48 B for the single table (12 dwords): in both cases
+// 16 consecutive lanes x 4 banks tile all 64 banks, so equal-offset b128 accesses are conflict free.
 #pragma once
 #include "trc_dev.h"
 
 typedef short trc_s2 __attribute__((ext_vector_type(2)));
 
-#define TRC_NIB_ROW    560u                       // bytes per lane
-#define TRC_NIB_BYTES  (64u * TRC_NIB_ROW)        // 35840 per wave
+#define TRC_NIBK_BYTES  512u                      // K table, per wave
+#define TRC_NIB_ROW     560u                      // bytes per lane, byte model (17 tables)
+#define TRC_NIB1_ROW    48u                       // bytes per lane, single table
+#define TRC_NIB_BYTES   (TRC_NIBK_BYTES + 64u * TRC_NIB_ROW)      // 36352 per wave
+#define TRC_NIB1_BYTES  (TRC_NIBK_BYTES + 64u * TRC_NIB1_ROW)     // 3584 per wave
 
 struct NibTable { u32 d[8]; };                    // 16 x u16, entry 2k in the low half of d[k]
 
@@ -25,13 +34,26 @@ __device__ __forceinline__ u32 trc_pk(u32 lo, u32 hi) { return (lo & 0xffffu) | 
 __device__ __forceinline__ trc_s2 trc_as_s2(u32 v) { return __builtin_bit_cast(trc_s2, v); }
 __device__ __forceinline__ u32 trc_as_u32(trc_s2 v) { return __builtin_bit_cast(u32, v); }
 
+template <bool BYTE>
 struct NibModel {
-    u8 *row;                                      // this lane's 544 bytes in LDS
-    __device__ __forceinline__ void reset()
+    u8 *kb;                                       // this wave's K table
+    u8 *row;                                      // this lane's tables
+    // smem = this wave's model area (TRC_NIB_BYTES / TRC_NIB1_BYTES); every lane of the wave must call
+    __device__ __forceinline__ void init(u8 *smem)
     {
-        for (u32 t = 0; t < 17; t++)
+        const u32 lane = trc_lane();
+        kb = smem;
+        row = smem + TRC_NIBK_BYTES + lane * (BYTE ? TRC_NIB_ROW : TRC_NIB1_ROW);
+#pragma unroll
+        for (u32 j = 0; j < 2; j++) {             // 128 dwords of K, two per lane
+            const u32 idx = lane * 2u + j, x = idx >> 3, k = idx & 7u;
+            const u32 e0 = 2u * k, e1 = 2u * k + 1u;
+            ((u32 *)kb)[idx] = trc_pk(10u * e0 + (e0 > x ? 32736u : 0u), 10u * e1 + (e1 > x ? 32736u : 0u));
+        }
+        for (u32 t = 0; t < (BYTE ? 17u : 1u); t++)
 #pragma unroll
             for (u32 k = 0; k < 8; k++) ((u32 *)(row + t * 32u))[k] = trc_pk((2 * k) << 11, (2 * k + 1) << 11);
+        __syncthreads();                          // one wave per workgroup: orders the K writes before other lanes' reads
     }
     __device__ __forceinline__ u8 *table(u32 t) const { return row + t * 32u; }      // t = 0: hi, 1 + h: lo[h]
     __device__ __forceinline__ NibTable load(const u8 *tb) const
@@ -46,38 +68,47 @@ struct NibModel {
         *(uint4 *)tb = make_uint4(T.d[0], T.d[1], T.d[2], T.d[3]);
         *(uint4 *)(tb + 16) = make_uint4(T.d[4], T.d[5], T.d[6], T.d[7]);
     }
-    // bounds of symbol x straight from LDS (entry 16 is the constant 32768)
+    // bounds of symbol x straight from LDS (entry 16 is the constant 32768; the u16 after a table is in-row padding or
+    // the next table, never out of the row)
     __device__ __forceinline__ void bounds(const u8 *tb, u32 x, u32 &c0, u32 &c1) const
     {
         c0 = ((const u16 *)tb)[x];
-        const u32 n = ((const u16 *)tb)[(x + 1u) & 15u];
+        const u32 n = ((const u16 *)tb)[x + 1u];
         c1 = x == 15u ? TRC_PROB_ONE : n;
+    }
+    // cdf16upd for coded symbol x
+    __device__ __forceinline__ void adapt(NibTable &T, u32 x) const
+    {
+        const NibTable K = load(kb + x * 32u);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const trc_s2 v = trc_as_s2(T.d[k]);
+            T.d[k] = trc_as_u32(v + ((trc_as_s2(K.d[k]) - v) >> (trc_s2)7));
+        }
+    }
+    // encoder side: {c0 << 15 | freq} of symbol x under table tb, then the table adapts
+    __device__ __forceinline__ u32 record(u8 *tb, u32 x) const
+    {
+        u32 c0, c1; bounds(tb, x, c0, c1);
+        NibTable T = load(tb); adapt(T, x); store(tb, T);
+        return (c0 << TRC_PROB_BITS) | (c1 - c0);
     }
 };
 
-// cdf16upd: every entry moves 1/128 of the way to 10*i (entries <= thr) or 10*i + 32736 (entries > thr).
-// thr may be the coded symbol's lower bound c (encoders) or the decoded slot/quotient q with
-// c <= q < next bound (decoders, as cdf16ansdec does): the tables are strictly increasing, so both
-// select exactly the entries above the coded symbol.
-__device__ __forceinline__ void trc_nib_adapt(NibTable &T, u32 thr)
+// decoder side: the symbol x whose interval holds q (t[x] <= q < t[x+1], 0 <= q < 32768) and its bounds, by binary
+// search over the register copy (entry 16 = 32768 appended)
+__device__ __forceinline__ u32 trc_nib_find(const NibTable &T, u32 q, u32 &c0, u32 &c1)
 {
-    const trc_s2 tt = trc_as_s2(trc_pk(thr, thr));
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const trc_s2 v = trc_as_s2(T.d[k]);
-        const trc_s2 gt = (tt - v) >> (trc_s2)15;                                   // -1 where v > thr
-        const u32 bonus = trc_as_u32(gt) & 0x7fe07fe0u;                             // 32736 in those lanes
-        trc_s2 d = trc_as_s2(trc_pk(20 * k, 20 * k + 10)) - v;
-        d = (d + trc_as_s2(bonus)) >> (trc_s2)7;
-        T.d[k] = trc_as_u32(v + d);
-    }
-}
-// number of entries > q  (entry 0 is always 0, so this is 15 - x for the symbol x that contains q)
-__device__ __forceinline__ u32 trc_nib_count_gt(const NibTable &T, u32 q)
-{
-    const trc_s2 qq = trc_as_s2(trc_pk(q, q));
-    u32 acc = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) acc += (trc_as_u32(qq - trc_as_s2(T.d[k])) >> 15) & 0x00010001u;   // sign bits
-    return (acc & 0xffu) + (acc >> 16);
+    const bool b3 = q >= (T.d[4] & 0xffffu);
+    const u32 e0 = b3 ? T.d[4] : T.d[0], e1 = b3 ? T.d[5] : T.d[1], e2 = b3 ? T.d[6] : T.d[2],
+              e3 = b3 ? T.d[7] : T.d[3], e4 = b3 ? TRC_PROB_ONE : T.d[4];
+    const bool b2 = q >= (e2 & 0xffffu);
+    const u32 f0 = b2 ? e2 : e0, f1 = b2 ? e3 : e1, f2 = b2 ? e4 : e2;
+    const bool b1 = q >= (f1 & 0xffffu);
+    const u32 g0 = b1 ? f1 : f0, g1 = b1 ? f2 : f1;
+    const u32 gh = g0 >> 16;
+    const bool b0 = q >= gh;
+    c0 = b0 ? gh : (g0 & 0xffffu);
+    c1 = b0 ? (g1 & 0xffffu) : gh;
+    return (b3 ? 8u : 0u) + (b2 ? 4u : 0u) + (b1 ? 2u : 0u) + (b0 ? 1u : 0u);
 }

@@ -47,6 +47,19 @@ struct RcEnc {
         range *= f;
         renorm(so);
     }
+    // predicated, branch-free in the common case: where !act nothing changes (model-bound coders, trc_rc_adaptive.hip)
+    template <class SO>
+    __device__ __forceinline__ void sym_if(SO &so, bool act, u32 c0, u32 f)
+    {
+        const u64 r = range >> TRC_PROB_BITS;
+        const u64 low2 = low + r * (act ? c0 : 0u);
+        const u64 range2 = r * f;
+        const bool rn = act && range2 < TRC_TOP32;
+        cw.emit_if(so, rn, mark > low2, (u32)(low2 >> 32));
+        low = rn ? low2 << 32 : low2;
+        range = act ? (rn ? range2 << 32 : range2) : range;
+        mark = rn ? low : mark;
+    }
     template <class SO>
     __device__ __forceinline__ void bit(SO &so, u32 p, u32 b)           // rcbe_: p = P(bit==1) * 2^15
     {
@@ -74,6 +87,37 @@ struct RcEnc {
 struct RcDec {
     u64 range, code;
     __device__ __forceinline__ void start(u32 w0, u32 w1) { range = ~(u64)0; code = ((u64)w0 << 32) | w1; }
+    // t = code / r for r = range >> 15 (the caller has NOT shifted range), branch-free: the f32 estimate is within
+    // +-1 of the exact quotient (relative errors: operand truncation 2^-23, cvt 2^-24, v_rcp_f32 1 ulp, product 2^-24,
+    // times t < 2^15 => < 0.02 absolute), so one correction step each way is exact for every valid stream.
+    __device__ __forceinline__ u32 quotient15() const
+    {
+        const u64 r = range >> TRC_PROB_BITS;                             // 2^17 <= r < 2^49
+        const int bl = 64 - __clzll((long long)r);
+        const int sh = bl > 24 ? bl - 24 : 0;
+        const float rf = (float)(u32)(r >> sh);
+        const u64 cs = code >> sh;                                       // < 2^39
+        const float cf = (float)(u32)(cs >> 16) * 65536.0f + (float)(u32)(cs & 0xffffu);
+        u32 t = (u32)(cf * __builtin_amdgcn_rcpf(rf));
+        t = t > TRC_PROB_ONE - 1 ? TRC_PROB_ONE - 1 : t;
+        const u64 p = r * t;
+        const bool dn = p > code, up = !dn && code - p >= r;
+        t = dn ? t - 1u : up ? t + 1u : t;
+        return t > TRC_PROB_ONE - 1 ? TRC_PROB_ONE - 1 : t;              // corrupt input: stay inside the table
+    }
+    // _rccdfupdate + renorm where act, nothing where !act (range is still the unshifted one)
+    template <class SI>
+    __device__ __forceinline__ void consume_if(SI &si, bool act, u32 c0, u32 c1)
+    {
+        const u64 r = range >> TRC_PROB_BITS;
+        const u64 rp = r * c0;
+        const u64 range2 = r * c1 - rp, code2 = code - rp;
+        const bool rn = act && range2 < TRC_TOP32;
+        const u32 w = si.peek32();
+        range = act ? (rn ? range2 << 32 : range2) : range;
+        code = act ? (rn ? (code2 << 32) | w : code2) : code;
+        si.skip_if(rn);
+    }
     __device__ __forceinline__ void renorm(StreamIn &si)
     {
         const bool rn = range < TRC_TOP32;

@@ -1,24 +1,34 @@
-// trc_rc_adaptive.hip -- adaptive-CDF byte range coder: one stream (TRC_RCA, `turborc -e46`) and the
-// interleaved variant (TRC_RCAI, `turborc -e47`: hi nibbles on stream 0, lo nibbles on stream 1, one model;
-// rccdfienc/rccdfidec rccdf.c:213-249, payload [u32 len0][stream 0][stream 1], OVERFLOWI after each full
-// group of 4 bytes -- SURVEY 8f rank 1).
+// trc_rc_adaptive.hip -- the adaptive-CDF range coders (CDF16 model, trc_nibmodel.h):
+//   TRC_RCA    rccdfenc / rccdfdec      rccdf.c:187-211   `turborc -e46`     bytes, one stream
+//   TRC_RCAI   rccdfienc / rccdfidec    rccdf.c:213-249   `turborc -e47`     bytes, hi nibbles on stream 0, lo nibbles on stream 1
+//   TRC_RCA4   rccdf4enc / rccdf4dec    rccdf.c:250-275   `turborc -n -e46`  nibbles (values 0..15), one table, one stream
+//   TRC_RCAI4  rccdf4ienc / rccdf4idec  rccdf.c:277-323   `turborc -n -e47`  nibbles, even positions on stream 0, odd on stream 1
+// Per chunk the payload is exactly what the reference function returns for that slice.  Byte coders (cdf8e/cdf4e
+// rccdf_.h:28-40; decoders cdf8d/cdf4d :48-76 with the 16-way search cdflget16 turborc_.h:259-304): the hi nibble
+// is coded with the "hi" table, which then adapts; the lo nibble with the "lo" table selected by the hi nibble,
+// which then adapts.  Two-stream payloads are [u32 len0][stream 0][stream 1].  Incompressibility rules:
+//   RCA / RCA4  OVERFLOW (rcutil_.h:130) after every symbol group (monotone: evaluated once per period);
+//   RCAI        OVERFLOWI (rccdf.c:46) after every FULL group of 4 bytes, OVERFLOW on the total at the end;
+//   RCAI4       OVERFLOW on stream 1 after every pair, on the total at the end.  The reference returns a meaningless
+//               length from the in-loop test (it hands op1 to the macro and returns op0-out, rccdf.c:314,322) and never
+//               tests stream 0 against stream 1's base out+4+n/2; in both cases this coder stores the chunk raw.
+//               BOTH symbols of a pair are coded against the table as it was before the pair (rccdf.c:311-314).
+// Range coder core, carry scheme, exact code/range quotient: trc_rc.h.
 //
-// Per chunk the payload is exactly what rccdfenc returns for that slice (reference rccdf.c:201-211,
-// cdf8e/cdf4e rccdf_.h:28-34; decoder rccdf.c:187-200, cdf8d/cdf4d rccdf_.h:48-54 with the 16-way
-// search cdflget16 turborc_.h:259-304): per byte the hi nibble is coded with the "hi" CDF16 table,
-// then that table adapts; the lo nibble is coded with the "lo" table selected by the hi nibble,
-// then that table adapts (model: trc_nibmodel.h); OVERFLOW (rcutil_.h:130) after every byte.
-// Range coder core, carry scheme and the exact code/range quotient: trc_rc.h.
-//
-// One lane = one chunk; the lane's 544-byte model sits in LDS (35 KiB per wave), which caps
-// occupancy at 3 waves per CU -- the coder is VALU-bound on the 56-op packed table update anyway.
+// One lane = one chunk.  These coders are bound by the per-nibble table update, and their occupancy by the model
+// (544 B per lane in LDS): the kernels are written so that the model is the ONLY thing in LDS -- input/output bytes
+// move in quad-transposed 64-byte segments in registers (QuadIn/QuadOut, trc_io.h), coded streams through 16-byte
+// register windows (trc_lane_io.h) -- which lets four waves (one per SIMD) share a CU.  A period is 4 input bytes:
+// first the model walks them and leaves {cdf_lo, freq} records in registers (pure packed-16 VALU + LDS, no
+// dependence on the coder state), then the range coder consumes the records with predicated, branch-free steps.
 #include "trc_rc.h"
+#include "trc_lane_io.h"
 #include "trc_nibmodel.h"
 #include "trc_launch.h"
 
-#define RCA_WAVE_LDS(NS) (TRC_NIB_BYTES + TRC_TILE_BYTES + (NS) * TRC_SRING_BYTES + TRC_SEL_BYTES)
+#define RCA_WAVE_LDS(NIB) ((NIB) ? TRC_NIB1_BYTES : TRC_NIB_BYTES)
 
-template <int NS>
+template <int NS, bool NIB>
 __global__ __launch_bounds__(64) void trc_rca_enc_kernel(
     const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks,
     u8 *__restrict__ scratch, u32 stride, u8 *__restrict__ scratch2, u32 stride2,
@@ -26,8 +36,7 @@ __global__ __launch_bounds__(64) void trc_rca_enc_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const u32 lane = threadIdx.x;
-    NibModel m; m.row = smem + lane * TRC_NIB_ROW; m.reset();
-    u8 *wbase = smem + TRC_NIB_BYTES;
+    NibModel<!NIB> m; m.init(smem);
 
     WaveChunks wc;
     wc.c0 = blockIdx.x * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
@@ -37,80 +46,109 @@ __global__ __launch_bounds__(64) void trc_rca_enc_kernel(
     const u32 c = wc.c0 + lane;
     const u32 len = alive ? wc.len_of(lane) : 0u;
     const int lim = trc_rc_limit(len);
+    const u32 off1 = 4u + len / 2u;                            // stream-1 base inside `out` (rccdf.c:215,279)
 
-    TileIn tin; tin.tile = wbase; tin.base = in + (u64)wc.c0 * chunk;
-    StreamOut<false> so, so1;
-    so.rings = wbase + TRC_TILE_BYTES; so.sel = wbase + TRC_TILE_BYTES + NS * TRC_SRING_BYTES;
-    so.scratch = scratch; so.stride = stride; so.c0 = wc.c0; so.wpos = (NS == 2) ? 4u : 0u; so.nfl = 0;
-    so1 = so;
-    if (NS == 2) { so1.rings = so.rings + TRC_SRING_BYTES; so1.scratch = scratch2; so1.stride = stride2; so1.wpos = 0; }
-    RcEnc e, e1; e.start(); e1.start();
-    const u32 off1 = 4u + len / 2u;                            // stream-1 base inside `out` (rccdf.c:215)
+    QuadIn qin; qin.base = in + (u64)wc.c0 * chunk;
+    LaneOut32 o0, o1;
+    o0.start(scratch + (u64)c * stride + (NS == 2 ? 4u : 0u));
+    o1.start(NS == 2 ? scratch2 + (u64)c * stride2 : scratch);
+    RcEnc e0, e1; e0.start(); e1.start();
     bool ovf = alive && NS == 1 && lim <= 0;
 
-    auto put_nibble = [&](RcEnc &en, StreamOut<false> &sq, u8 *tb, u32 x) {
-        u32 c0, c1; m.bounds(tb, x, c0, c1);
-        en.sym(sq, c0, c1 - c0);
-        NibTable T = m.load(tb); trc_nib_adapt(T, c0); m.store(tb, T);
-    };
-
     const u32 S = chunk / TRC_SEG;
-    tin.issue(wc, 0);
+    qin.issue(wc, 0);
     for (u32 s = 0; s < S; s++) {
-        tin.commit();
-        if (s + 1 < S) tin.issue(wc, (s + 1) * TRC_SEG);
+        qin.commit();
+        if (s + 1 < S) qin.issue(wc, (s + 1) * TRC_SEG);
+        uint4 pc0 = qin.read(0), pc1 = qin.read(1), pc2 = qin.read(2), pc3 = qin.read(3);
+#pragma nounroll
         for (u32 k = 0; k < 4; k++) {
-            const u32 p0 = s * TRC_SEG + k * 16u;
-            const uint4 v = tin.read(k);
-            const u32 w[4] = { v.x, v.y, v.z, v.w };
+            uint4 v = pc0; pc0 = pc1; pc1 = pc2; pc2 = pc3;
+            if (!__ballot(alive && !ovf && s * TRC_SEG + k * 16u < len)) continue;
+#pragma nounroll
+            for (u32 d = 0; d < 4; d++) {
+                const u32 w = v.x; v.x = v.y; v.y = v.z; v.z = v.w;
+                const u32 q0 = s * TRC_SEG + k * 16u + d * 4u;
+                const bool run = alive && !ovf;
+                // ---- model: 4 bytes -> records (no coder state involved)
+                u32 rc[8];
+                if (!NIB) {
 #pragma unroll
-            for (int d = 0; d < 4; d++) {                      // period = 4 bytes = 8 nibbles: <= 8 words
-                const u32 q0 = p0 + (u32)d * 4u;
-                if (alive && !ovf && q0 < len) {
-                    const u32 nb = len - q0 < 4u ? len - q0 : 4u;
-                    for (u32 i = 0; i < nb; i++) {
-                        const u32 x = (w[d] >> (8 * i)) & 255u;
-                        put_nibble(e, so, m.table(0), x >> 4);
-                        if (NS == 1) put_nibble(e, so, m.table(1u + (x >> 4)), x & 15u);
-                        else         put_nibble(e1, so1, m.table(1u + (x >> 4)), x & 15u);
+                    for (int i = 0; i < 4; i++) {
+                        const u32 x = (w >> (8 * i)) & 255u, h = x >> 4;
+                        rc[2 * i] = m.record(m.table(0), h);
+                        rc[2 * i + 1] = m.record(m.table(1u + h), x & 15u);
                     }
-                    // OVERFLOW after every byte (NS=1) / OVERFLOWI after every FULL group of 4 (NS=2): both monotone
-                    if (NS == 1) ovf = (int)(4u * e.cw.nwords) >= lim;
-                    else if (nb == 4u) ovf = ((int)(off1 + 4u * e1.cw.nwords) >= lim) || (4u + 4u * e.cw.nwords >= off1);
+                } else if (NS == 1) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) rc[i] = m.record(m.table(0), (w >> (8 * i)) & 15u);
+                } else {
+#pragma unroll
+                    for (int pr = 0; pr < 2; pr++) {           // both symbols against the table before the pair
+                        const u32 x0 = (w >> (16 * pr)) & 15u, x1 = (w >> (16 * pr + 8)) & 15u;
+                        u8 *tb = m.table(0);
+                        u32 a0, a1, b0, b1;
+                        m.bounds(tb, x0, a0, a1); m.bounds(tb, x1, b0, b1);
+                        NibTable T = m.load(tb); m.adapt(T, x0); m.adapt(T, x1); m.store(tb, T);
+                        rc[2 * pr] = (a0 << TRC_PROB_BITS) | (a1 - a0);
+                        rc[2 * pr + 1] = (b0 << TRC_PROB_BITS) | (b1 - b0);
+                    }
                 }
-                so.drain(false, alive);
-                if (NS == 2) so1.drain(false, alive);
+                // ---- range coder: predicated steps
+                if (!NIB) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const bool act = run && q0 + (u32)i < len;
+                        e0.sym_if(o0, act, rc[2 * i] >> TRC_PROB_BITS, rc[2 * i] & 0x7fffu);
+                        if (NS == 1) e0.sym_if(o0, act, rc[2 * i + 1] >> TRC_PROB_BITS, rc[2 * i + 1] & 0x7fffu);
+                        else         e1.sym_if(o1, act, rc[2 * i + 1] >> TRC_PROB_BITS, rc[2 * i + 1] & 0x7fffu);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const bool act = run && q0 + (u32)i < len;
+                        if (NS == 1 || !(i & 1)) e0.sym_if(o0, act, rc[i] >> TRC_PROB_BITS, rc[i] & 0x7fffu);
+                        else                     e1.sym_if(o1, act, rc[i] >> TRC_PROB_BITS, rc[i] & 0x7fffu);
+                    }
+                }
+                // ---- incompressibility tests (all monotone in the word counts)
+                if (NS == 1) ovf = ovf || (run && q0 < len && (int)(4u * e0.cw.nwords) >= lim);
+                else if (!NIB) ovf = ovf || (run && q0 + 4u <= len &&
+                                             ((int)(off1 + 4u * e1.cw.nwords) >= lim || 4u + 4u * e0.cw.nwords >= off1));
+                else ovf = ovf || (run && q0 + 2u <= len && (int)(off1 + 4u * e1.cw.nwords) >= lim);
             }
         }
     }
     u32 out_len = 0;
     if (alive) {
         if (!ovf) {
-            e.finish(so);
-            if (NS == 2) { e1.finish(so1); out_len = so.wpos + so1.wpos; if ((int)out_len >= lim) ovf = true; }
-            else out_len = so.wpos;
+            e0.finish(o0);
+            if (NS == 2) {
+                e1.finish(o1);
+                out_len = 4u + o0.wpos + o1.wpos;
+                if ((int)out_len >= lim || (NIB && 4u + o0.wpos > off1)) ovf = true;
+            } else out_len = o0.wpos;
         }
         if (ovf) out_len = len;
     }
-    so.drain(true, alive && !ovf);
+    o0.finish(alive && !ovf);
     if (NS == 2) {
-        so1.drain(true, alive && !ovf);
-        if (alive && !ovf) *(u32 *)(scratch + (u64)c * stride) = so.wpos - 4u;       // header: len0
+        o1.finish(alive && !ovf);
+        if (alive && !ovf) *(u32 *)(scratch + (u64)c * stride) = o0.wpos;          // header: len0
     }
     if (alive) clen[c] = out_len;
     const u32 gs = trc_wave_sum(out_len);
     if (lane == 0) gsum[wc.c0 >> 6] = gs;
 }
 
-template <int NS>
+template <int NS, bool NIB>
 __global__ __launch_bounds__(64) void trc_rca_dec_kernel(
     const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
     u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const u32 lane = threadIdx.x;
-    NibModel m; m.row = smem + lane * TRC_NIB_ROW; m.reset();
-    u8 *wbase = smem + TRC_NIB_BYTES;
+    NibModel<!NIB> m; m.init(smem);
 
     WaveChunks wc;
     wc.c0 = blockIdx.x * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
@@ -124,55 +162,75 @@ __global__ __launch_bounds__(64) void trc_rca_dec_kernel(
     const u64 off = trc_group_base(goff, gsum, wc.c0 >> 6) + ex;
     const bool coded = alive && cl != len;
 
-    TileOut tout; tout.tile = wbase; tout.base = out + (u64)wc.c0 * chunk;
-    StreamIn si, si1;
-    si.rings = wbase + TRC_TILE_BYTES; si.sel = wbase + TRC_TILE_BYTES + NS * TRC_SRING_BYTES;
-    si.gbase = payload; si.soff = off + (NS == 2 ? 4u : 0u);
-    si1 = si;
-    if (NS == 2) { si1.rings = si.rings + TRC_SRING_BYTES; si1.soff = off + 4u + (coded ? trc_ld32_a2(payload + off) : 0u); }
-    si.prime(coded);
-    if (NS == 2) si1.prime(coded);
-    RcDec dc, dc1;
-    { const u32 a = si.peek32(); si.rpos += 4; const u32 b = si.peek32(); si.rpos += 4; dc.start(a, b); }
-    if (NS == 2) { const u32 a = si1.peek32(); si1.rpos += 4; const u32 b = si1.peek32(); si1.rpos += 4; dc1.start(a, b); }
-    else dc1 = dc;
+    LaneIn<4> s0, s1;
+    const u32 len0 = (NS == 2 && coded) ? trc_ld32_a2(payload + off) : 0u;
+    s0.prime(payload + off + (NS == 2 ? 4u : 0u), coded);
+    s1.prime(payload + off + 4u + len0, NS == 2 && coded);
+    RcDec d0, d1;
+    { const u32 a = s0.peek32(); s0.skip_if(coded); const u32 b = s0.peek32(); s0.skip_if(coded); d0.start(a, b); }
+    { const u32 a = s1.peek32(); s1.skip_if(NS == 2 && coded); const u32 b = s1.peek32(); s1.skip_if(NS == 2 && coded); d1.start(a, b); }
 
-    auto get_nibble = [&](RcDec &dq, StreamIn &sq, u8 *tb) -> u32 {
-        dq.range >>= TRC_PROB_BITS;
-        const u32 q = dq.quotient();
+    auto get = [&](RcDec &dq, LaneIn<4> &sq, u8 *tb, bool act) -> u32 {
+        const u32 q = dq.quotient15();
         NibTable T = m.load(tb);
-        const u32 x = 15u - trc_nib_count_gt(T, q);            // first i with t[i+1] > q, else 15
-        u32 c0, c1; m.bounds(tb, x, c0, c1);
-        dq.consume(sq, c0, c1);
-        trc_nib_adapt(T, q); m.store(tb, T);
+        u32 c0, c1;
+        const u32 x = trc_nib_find(T, q, c0, c1);              // == first i with t[i+1]*r > code, else 15 (cdflget16)
+        dq.consume_if(sq, act, c0, c1);
+        m.adapt(T, x); m.store(tb, T);
         return x;
     };
 
-    const u32 S = chunk / TRC_SEG;
+    QuadOut qout; qout.base = out + (u64)wc.c0 * chunk;
     u8 *dst = out + (u64)c * chunk;
+    const u32 S = chunk / TRC_SEG;
     for (u32 s = 0; s < S; s++) {
+        uint4 pc0 = make_uint4(0, 0, 0, 0), pc1 = pc0, pc2 = pc0, pc3 = pc0;
+#pragma nounroll
         for (u32 k = 0; k < 4; k++) {
             const u32 p0 = s * TRC_SEG + k * 16u;
-            u32 w[4] = { 0, 0, 0, 0 };
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (__ballot(coded && p0 < len)) {
+#pragma nounroll
+                for (u32 d = 0; d < 4; d++) {
+                    const u32 q0 = p0 + d * 4u;
+                    u32 w = 0;
+                    if (!NIB) {
 #pragma unroll
-            for (int d = 0; d < 4; d++) {
-                const u32 q0 = p0 + (u32)d * 4u;
-                si.period(coded && q0 < len, d & 1);
-                if (NS == 2) si1.period(coded && q0 < len, d & 1);
-                if (coded && q0 < len) {
-                    const u32 nb = len - q0 < 4u ? len - q0 : 4u;
-                    for (u32 i = 0; i < nb; i++) {
-                        const u32 h = get_nibble(dc, si, m.table(0));
-                        const u32 l = NS == 1 ? get_nibble(dc, si, m.table(1u + h)) : get_nibble(dc1, si1, m.table(1u + h));
-                        w[d] |= (h << 4 | l) << (8 * i);
+                        for (int i = 0; i < 4; i++) {
+                            const bool act = coded && q0 + (u32)i < len;
+                            const u32 h = get(d0, s0, m.table(0), act);
+                            const u32 l = NS == 1 ? get(d0, s0, m.table(1u + h), act) : get(d1, s1, m.table(1u + h), act);
+                            w |= (h << 4 | l) << (8 * i);
+                        }
+                    } else if (NS == 1) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) w |= get(d0, s0, m.table(0), coded && q0 + (u32)i < len) << (8 * i);
+                    } else {
+#pragma unroll
+                        for (int pr = 0; pr < 2; pr++) {       // both symbols searched in the table before the pair
+                            const bool act0 = coded && q0 + 2u * (u32)pr < len, act1 = coded && q0 + 2u * (u32)pr + 1u < len;
+                            u8 *tb = m.table(0);
+                            const u32 t0 = d0.quotient15(), t1 = d1.quotient15();
+                            NibTable T = m.load(tb);
+                            u32 a0, a1, b0, b1;
+                            const u32 x0 = trc_nib_find(T, t0, a0, a1), x1 = trc_nib_find(T, t1, b0, b1);
+                            d0.consume_if(s0, act0, a0, a1);
+                            d1.consume_if(s1, act1, b0, b1);
+                            m.adapt(T, x0); m.adapt(T, x1); m.store(tb, T);
+                            w |= (x0 | x1 << 8) << (16 * pr);
+                        }
                     }
+                    v.x = v.y; v.y = v.z; v.z = v.w; v.w = w;
+                }
+                if (coded && p0 < len && p0 + 16u > len) {      // ragged end of the last chunk: byte stores
+                    const u32 ww[4] = { v.x, v.y, v.z, v.w };
+                    for (u32 pos = p0; pos < len; pos++) dst[pos] = (u8)(ww[(pos - p0) >> 2] >> (8 * ((pos - p0) & 3u)));
                 }
             }
-            if (coded && p0 + 16u <= len) tout.put(k, make_uint4(w[0], w[1], w[2], w[3]));
-            else if (coded && p0 < len)
-                for (u32 pos = p0; pos < len; pos++) dst[pos] = (u8)(w[(pos - p0) >> 2] >> (8 * ((pos - p0) & 3u)));
+            pc0 = pc1; pc1 = pc2; pc2 = pc3; pc3 = v;
         }
-        tout.flush(wc, s * TRC_SEG);
+        qout.put(0, pc0); qout.put(1, pc1); qout.put(2, pc2); qout.put(3, pc3);
+        qout.flush(wc, s * TRC_SEG);
     }
     u64 rawmask = __ballot(alive && cl == len && len != 0);
     while (rawmask) {
@@ -184,29 +242,27 @@ __global__ __launch_bounds__(64) void trc_rca_dec_kernel(
     }
 }
 
-template <int NS>
+template <int NS, bool NIB>
 static void launch_rca_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
 {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)trc_rca_enc_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RCA_WAVE_LDS(NS)); attr = true; }
-    hipLaunchKernelGGL(trc_rca_enc_kernel<NS>, dim3(w.ngroups), dim3(64), RCA_WAVE_LDS(NS), s,
+    hipLaunchKernelGGL((trc_rca_enc_kernel<NS, NIB>), dim3(w.ngroups), dim3(64), RCA_WAVE_LDS(NIB), s,
                        d_in, (u64)n, chunk, w.nchunks, w.scratch, w.stride, w.scratch2, w.stride2, d_clen, w.gsum);
 }
-template <int NS>
+template <int NS, bool NIB>
 static void launch_rca_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                            const TrcWork &w, uint8_t *d_out, hipStream_t s)
 {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)trc_rca_dec_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RCA_WAVE_LDS(NS)); attr = true; }
-    hipLaunchKernelGGL(trc_rca_dec_kernel<NS>, dim3(w.ngroups), dim3(64), RCA_WAVE_LDS(NS), s,
+    hipLaunchKernelGGL((trc_rca_dec_kernel<NS, NIB>), dim3(w.ngroups), dim3(64), RCA_WAVE_LDS(NIB), s,
                        d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, d_out);
 }
-void trc_launch_rca_enc(int nstreams, const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
+void trc_launch_rca_enc(int nstreams, int nibble, const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
 {
-    if (nstreams == 2) launch_rca_enc<2>(d_in, n, chunk, w, d_clen, s); else launch_rca_enc<1>(d_in, n, chunk, w, d_clen, s);
+    if (nibble) { if (nstreams == 2) launch_rca_enc<2, true>(d_in, n, chunk, w, d_clen, s); else launch_rca_enc<1, true>(d_in, n, chunk, w, d_clen, s); }
+    else        { if (nstreams == 2) launch_rca_enc<2, false>(d_in, n, chunk, w, d_clen, s); else launch_rca_enc<1, false>(d_in, n, chunk, w, d_clen, s); }
 }
-void trc_launch_rca_dec(int nstreams, const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
+void trc_launch_rca_dec(int nstreams, int nibble, const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                         const TrcWork &w, uint8_t *d_out, hipStream_t s)
 {
-    if (nstreams == 2) launch_rca_dec<2>(d_payload, d_clen, n, chunk, w, d_out, s); else launch_rca_dec<1>(d_payload, d_clen, n, chunk, w, d_out, s);
+    if (nibble) { if (nstreams == 2) launch_rca_dec<2, true>(d_payload, d_clen, n, chunk, w, d_out, s); else launch_rca_dec<1, true>(d_payload, d_clen, n, chunk, w, d_out, s); }
+    else        { if (nstreams == 2) launch_rca_dec<2, false>(d_payload, d_clen, n, chunk, w, d_out, s); else launch_rca_dec<1, false>(d_payload, d_clen, n, chunk, w, d_out, s); }
 }
