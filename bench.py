@@ -42,6 +42,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MI
 CODEC_INFO = {
     "anscdf4s": ("static-CDF rANS, 2 states (anscdf4senc/anscdf4sdec per chunk), tables in LDS", "text"),
     "rccdfs":   ("static-CDF range coder (rccdfsenc/rccdfs*dec per chunk), tables in LDS", "text"),
+    "rccdfsm":  ("static-CDF range coder, 32-bit range / 16-bit I/O (rccdfsmenc/rccdfsm*dec per chunk, `-e44`), tables in LDS", "text"),
     "rccdfs2":  ("static-CDF range coder, 2 interleaved streams (rccdfs2enc/rccdfs*2dec per chunk, `-e45`), tables in LDS", "text"),
     "rcs":      ("bitwise order-0 range coder (rcsenc/rcsdec per chunk), 512 B bit model per lane in LDS", "text"),
     "rccdf":    ("adaptive-CDF byte range coder (rccdfenc/rccdfdec per chunk), 544 B CDF16 model per lane in LDS", "bwt"),

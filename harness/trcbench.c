@@ -8,7 +8,7 @@
  * The timed calls take HOST pointers, so these numbers include PCIe both ways; the
  * device-resident numbers come from bench.py.
  *
- *   trcbench [-e id[,id..]] [-I runs] [-c chunk] (file | --zipf N | --text N | --uniform N)
+ *   trcbench [-e id[,id..]] [-I runs] [-c chunk] (file | --zipf N | --text N | --uniform N | --nibble N)
  * ids: 1 rcs | 42 cdfsb | 43 cdfsv | 45 cdfs2 | 46 cdf | 47 cdfi | 56 ans | 57 ans(s) | 58 ans(x) | 65 ans4s | 79 memcpy
  */
 #include <math.h>
@@ -29,12 +29,13 @@ static unsigned long long sm64(unsigned long long *s)
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
-/* kind 0: Zipf(1.1) over 256 symbols, 1: text-like (Zipf(1.6) over 96 printable bytes), 2: uniform */
+/* kind 0: Zipf(1.1) over 256 symbols, 1: text-like (Zipf(1.6) over 96 printable bytes), 2: uniform,
+ * 3: nibble values (Zipf(1.1) over 16 symbols, the `turborc -n` coders) */
 static void gen(unsigned char *p, size_t n, int kind)
 {
     unsigned long long s = 12345;
     double cum[256], tot = 0;
-    int nsym = kind == 1 ? 96 : 256;
+    int nsym = kind == 1 ? 96 : kind == 3 ? 16 : 256;
     for (int i = 0; i < nsym; i++) { tot += kind == 2 ? 1.0 : 1.0 / pow(i + 1.0, kind == 1 ? 1.6 : 1.1); cum[i] = tot; }
     for (size_t k = 0; k < n; k++) {
         double u = (double)(sm64(&s) >> 11) * (1.0 / 9007199254740992.0) * tot;
@@ -59,10 +60,21 @@ static int bench(unsigned char *in, size_t n, unsigned char *out, unsigned char 
     unsigned m = 0;
     const char *name = "?";
     enc3 e3 = 0, d3 = 0; enc4 e4 = 0, d4 = 0; enc5 e5 = 0, d5 = 0;
-    switch (id) {
+    for (size_t i = 0; i < n; i++) if (in[i] > m) m = in[i];
+    /* nibble-valued input (`turborc -n`): ids 46/47/56-58 run the one-table nibble coders, as the reference
+     * harness does under its m<16 gate (turborc.c:499-501,514-520) */
+    if (m < 16) switch (id) {
+    case 46: name = "cdf4 nibble adaptive (rccdf4enc/rccdf4dec)"; e3 = rccdf4enc; d3 = rccdf4dec; break;
+    case 47: name = "cdf4i nibble adaptive interleaved (rccdf4ienc/rccdf4idec)"; e3 = rccdf4ienc; d3 = rccdf4idec; break;
+    case 56: name = "ans auto nibble (anscdf4enc/anscdf4dec)"; e3 = anscdf4enc; d3 = anscdf4dec; break;
+    case 57: name = "ans s nibble (anscdf4encs/anscdf4decs)"; e3 = anscdf4encs; d3 = anscdf4decs; break;
+    case 58: name = "ans x nibble (anscdf4encx/anscdf4decx)"; e3 = anscdf4encx; d3 = anscdf4decx; break;
+    }
+    if (!e3) switch (id) {
     case 1:  name = "rc o0 (rcsenc/rcsdec)"; e3 = rcsenc; d3 = rcsdec; break;
     case 42: name = "cdfsb (rccdfsenc/rccdfsbdec)"; e5 = rccdfsenc; d5 = rccdfsbdec; break;
     case 43: name = "cdfsv (rccdfsenc/rccdfsvbdec)"; e5 = rccdfsenc; d5 = rccdfsvbdec; break;
+    case 44: name = "cdfsm 32-bit range (rccdfsmenc/rccdfsmbdec)"; e5 = rccdfsmenc; d5 = rccdfsmbdec; break;
     case 45: name = "cdfsb interleaved (rccdfs2enc/rccdfsb2dec)"; e5 = rccdfs2enc; d5 = rccdfsb2dec; break;
     case 46: name = "cdf byte adaptive (rccdfenc/rccdfdec)"; e3 = rccdfenc; d3 = rccdfdec; break;
     case 47: name = "cdfi byte adaptive interleaved (rccdfienc/rccdfidec)"; e3 = rccdfienc; d3 = rccdfidec; break;
@@ -74,7 +86,6 @@ static int bench(unsigned char *in, size_t n, unsigned char *out, unsigned char 
     default: return 0;
     }
     if (e4 || e5) {                                    /* untimed, as in the reference harness */
-        for (size_t i = 0; i < n; i++) if (in[i] > m) m = in[i];
         if (cdfini(in, n, cdf, m + 1) < 0) { printf("%2d: cdfini failed: %s\n", id, trc_last_error()); return 1; }
     }
     for (size_t i = 0; i < n; i++) cpy[i] = (unsigned char)~in[i];
@@ -104,7 +115,7 @@ static int bench(unsigned char *in, size_t n, unsigned char *out, unsigned char 
 
 int main(int argc, char **argv)
 {
-    const char *ids = "1,42,45,46,47,56,65,79", *file = 0;
+    const char *ids = "1,42,44,45,46,47,56,65,79", *file = 0;
     int runs = 3, kind = -1;
     size_t n = 0;
     for (int i = 1; i < argc; i++) {
@@ -114,6 +125,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "--zipf") && i + 1 < argc) { kind = 0; n = strtoull(argv[++i], 0, 10); }
         else if (!strcmp(argv[i], "--text") && i + 1 < argc) { kind = 1; n = strtoull(argv[++i], 0, 10); }
         else if (!strcmp(argv[i], "--uniform") && i + 1 < argc) { kind = 2; n = strtoull(argv[++i], 0, 10); }
+        else if (!strcmp(argv[i], "--nibble") && i + 1 < argc) { kind = 3; n = strtoull(argv[++i], 0, 10); }
         else file = argv[i];
     }
     if (file) {
@@ -130,7 +142,7 @@ int main(int argc, char **argv)
         for (char *t = strtok_r(s, ",", &sv); t; t = strtok_r(0, ",", &sv)) bad |= bench(in, n, out, cpy, atoi(t), runs);
         return bad;
     }
-    if (kind < 0 || !n) { fprintf(stderr, "usage: trcbench [-e ids] [-I runs] [-c chunk] (file | --zipf N | --text N | --uniform N)\n"); return 2; }
+    if (kind < 0 || !n) { fprintf(stderr, "usage: trcbench [-e ids] [-I runs] [-c chunk] (file | --zipf N | --text N | --uniform N | --nibble N)\n"); return 2; }
     unsigned char *in = malloc(n * 4 / 3 + 1024), *out = malloc(n * 4 / 3 + 1024), *cpy = malloc(n * 4 / 3 + 1024);
     gen(in, n, kind);
     printf("synthetic kind %d: %zu bytes\n      C Size  ratio%%    E MB/s     D MB/s   Name (host pointers: PCIe included)\n", kind, n);

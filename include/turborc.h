@@ -42,6 +42,13 @@ size_t rccdfsbdec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *c
 size_t rccdfsvldec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum);
 size_t rccdfsvbdec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum);
 
+/* the one-stream static coder with a 32-bit range and 16-bit I/O (reference rccdf.c:648-694, include/turborc.h:521-526;
+ * `turborc -e44`).  A different bitstream from rccdfsenc.  The reference decoders divide through a reciprocal table;
+ * both names decode the same stream here (exact division). */
+size_t rccdfsmenc(unsigned char *in, size_t inlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum);
+size_t rccdfsmldec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum);
+size_t rccdfsmbdec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum);
+
 /* static-CDF range coder, two interleaved streams (reference rccdf.c:125-184; `turborc -e45`) */
 size_t rccdfs2enc(unsigned char *in, size_t inlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum);
 size_t rccdfsl2dec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum);

@@ -150,6 +150,60 @@ size_t orc_rccdfsdec(const uint8_t *in, size_t outlen, uint8_t *out, const uint1
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* rccdfsmenc / rccdfsm{b,l}dec (rccdf.c:648-694), `turborc -e44`: the same coder with a   */
+/* 32-bit range, 16-bit I/O and 15-bit probabilities (RC_SIZE 32, RC_IO 16, turborc_.h:62-68,103-128).       */
+/* Renorm below 2^16 (one step is enough: range >= 2 after the scale), flush adds 2^16 and emits one word    */
+/* when range > 2^17, else adds 1 and emits two.  The reference decoders take code/range through a           */
+/* reciprocal table (turborc_.h:172-190); the plain quotient below is what that table approximates, and the  */
+/* symbol is the largest x with cdf[x] <= quotient (quotients >= 32768 -- possible because range>>15         */
+/* truncates -- select the last symbol, as the reference's searches do).                                     */
+size_t orc_rccdfsmenc(const uint8_t *in, size_t inlen, uint8_t *out, const uint16_t *cdf, unsigned cdfnum)
+{
+    uint32_t range = ~0u, low = 0, mark = 0;
+    uint8_t *op = out;
+    (void)cdfnum;
+#define SM_CARRY() do { if (mark > low) { uint8_t *p_ = op; uint16_t w_; do { p_ -= 2; w_ = (uint16_t)(ld16(p_) + 1); st16(p_, w_); } while (w_ == 0); } } while (0)
+#define SM_RENORM() do { if (range < (1u << 16)) { SM_CARRY(); st16(op, (uint16_t)(low >> 16)); op += 2; low <<= 16; range <<= 16; mark = low; } } while (0)
+    for (size_t i = 0; i < inlen; i++) {
+        unsigned x = in[i];
+        range >>= PROB_BITS;
+        low += range * cdf[x];
+        range *= (uint32_t)cdf[x + 1] - cdf[x];
+        SM_RENORM();
+        if (rc_overflow((size_t)(op - out), inlen)) { memcpy(out, in, inlen); return inlen; }
+    }
+    SM_RENORM();
+    if (range > (1u << 17)) {
+        low += 1u << 16; SM_CARRY();
+        st16(op, (uint16_t)(low >> 16)); op += 2;
+    } else {
+        low += 1; SM_CARRY();
+        st16(op, (uint16_t)(low >> 16)); op += 2;
+        st16(op, (uint16_t)low); op += 2;
+    }
+#undef SM_RENORM
+#undef SM_CARRY
+    return (size_t)(op - out);
+}
+size_t orc_rccdfsmdec(const uint8_t *in, size_t outlen, uint8_t *out, const uint16_t *cdf, unsigned cdfnum)
+{
+    const uint8_t *ip = in + 4;
+    uint32_t range = ~0u, code = (uint32_t)ld16(in) << 16 | ld16(in + 2);
+    for (size_t i = 0; i < outlen; i++) {
+        range >>= PROB_BITS;
+        uint32_t q = code / range;
+        unsigned x = 0, hi = cdfnum;
+        while (x + 1 < hi) { unsigned mid = (x + hi) >> 1; if (cdf[mid] > q) hi = mid; else x = mid; }
+        uint32_t rp = range * cdf[x];
+        range = range * cdf[x + 1] - rp;
+        code -= rp;
+        if (range < (1u << 16)) { range <<= 16; code = code << 16 | ld16(ip); ip += 2; }
+        out[i] = (uint8_t)x;
+    }
+    return outlen;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* M4  rccdfs2enc / rccdfs{l,b}2dec  (rccdf.c:125-184)                                          */
 size_t orc_rccdfs2enc(const uint8_t *in, size_t inlen, uint8_t *out, const uint16_t *cdf, unsigned cdfnum)
 {
@@ -660,6 +714,7 @@ static size_t enc_one(int codec, const uint8_t *in, size_t n, uint8_t *out, cons
     case ORC_RCA4:  return orc_rccdf4enc(in, n, out);
     case ORC_RCAI4: return orc_rccdf4ienc(in, n, out);
     case ORC_ANSA4: return orc_anscdf4enc(in, n, out);
+    case ORC_RCSM:  return orc_rccdfsmenc(in, n, out, cdf, cdfnum);
     }
     return 0;
 }
@@ -676,6 +731,7 @@ static void dec_one(int codec, const uint8_t *in, size_t n, uint8_t *out, const 
     case ORC_RCA4:  orc_rccdf4dec(in, n, out); break;
     case ORC_RCAI4: orc_rccdf4idec(in, n, out); break;
     case ORC_ANSA4: orc_anscdf4dec(in, n, out); break;
+    case ORC_RCSM:  orc_rccdfsmdec(in, n, out, cdf, cdfnum); break;
     }
 }
 size_t orc_chunked_enc(int codec, const uint8_t *in, size_t n, size_t chunk,

@@ -8,7 +8,7 @@ import trc_testlib as T
 from golden.make_golden import gen
 
 pytestmark = pytest.mark.skipif(not T.have_ref(), reason="oracle/_ref/libtrc_ref.so not built")
-CODECS = [T.ANS4S, T.RCS1, T.RCS2, T.RCA, T.ANSA, T.RCB, T.RCAI]
+CODECS = [T.ANS4S, T.RCS1, T.RCS2, T.RCA, T.ANSA, T.RCB, T.RCAI, T.RCSM]
 
 
 @pytest.mark.parametrize("kind", ["zipf", "text", "runs", "uniform", "nibble", "binary"])
@@ -37,6 +37,16 @@ def test_all_static_rc_decoders_agree():
     a = T.orc_enc(T.RCS1, d, cdf, cdfnum)
     for s in ("l", "b", "vl", "vb"):
         assert np.array_equal(T.ref_dec(T.RCS1, a, d.size, cdf, cdfnum, search=s), d)
+
+
+def test_lut_division_decoders_agree():
+    """rccdfsm{b,l}dec (reciprocal-table division, turborc_.h:172-190) decode the oracle's stream"""
+    for kind, n in (("zipf", 50000), ("nibble", 30000)):
+        d = gen(kind, n, 3)
+        _, cdf, cdfnum = T.orc_cdfini(d)
+        a = T.orc_enc(T.RCSM, d, cdf, cdfnum)
+        for s in ("b", "l"):
+            assert np.array_equal(T.ref_dec(T.RCSM, a, d.size, cdf, cdfnum, search=s), d)
 
 
 def test_multiblock_adaptive_rans():

@@ -18,15 +18,15 @@ ORACLE_SO = os.path.join(ORACLE_DIR, "libtrc_oracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libtrc_ref.so")
 
 # codec ids == include/trc_hip.h == oracle/trc_oracle.h
-ANS4S, RCS1, RCS2, RCA, ANSA, RCB, RCAI, RCA4, RCAI4, ANSA4 = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+ANS4S, RCS1, RCS2, RCA, ANSA, RCB, RCAI, RCA4, RCAI4, ANSA4, RCSM = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 CODEC_NAMES = {ANS4S: "anscdf4s", RCS1: "rccdfs", RCS2: "rccdfs2", RCA: "rccdf", ANSA: "anscdf", RCB: "rcs", RCAI: "rccdfi",
-               RCA4: "rccdf4", RCAI4: "rccdf4i", ANSA4: "anscdf4"}
+               RCA4: "rccdf4", RCAI4: "rccdf4i", ANSA4: "anscdf4", RCSM: "rccdfsm"}
 NIBBLE_CODECS = (RCA4, RCAI4, ANSA4)          # `turborc -n` coders: input values 0..15
 # adaptive coders: (oracle encoder, oracle decoder, reference encoder, reference decoder); ANS ones take a variant suffix
 _ADAPTIVE = {RCA: ("rccdfenc", "rccdfdec"), ANSA: ("anscdfenc", "anscdfdec"), RCB: ("rcsenc", "rcsdec"),
              RCAI: ("rccdfienc", "rccdfidec"), RCA4: ("rccdf4enc", "rccdf4dec"), RCAI4: ("rccdf4ienc", "rccdf4idec"),
              ANSA4: ("anscdf4enc", "anscdf4dec")}
-STATIC_CODECS = (ANS4S, RCS1, RCS2)
+STATIC_CODECS = (ANS4S, RCS1, RCS2, RCSM)
 
 _u8p = C.POINTER(C.c_uint8)
 _u16p = C.POINTER(C.c_uint16)
@@ -128,7 +128,7 @@ def oracle():
         sz = C.c_size_t
         lib.orc_cdfini.restype = C.c_int
         lib.orc_cdfini.argtypes = [_u8p, sz, _u16p, C.c_uint]
-        for name in ("orc_rccdfsenc", "orc_rccdfsdec", "orc_rccdfs2enc", "orc_rccdfs2dec"):
+        for name in ("orc_rccdfsenc", "orc_rccdfsdec", "orc_rccdfs2enc", "orc_rccdfs2dec", "orc_rccdfsmenc", "orc_rccdfsmdec"):
             f = getattr(lib, name); f.restype = sz; f.argtypes = [_u8p, sz, _u8p, _u16p, C.c_uint]
         lib.orc_anscdf4senc.restype = sz; lib.orc_anscdf4senc.argtypes = [_u8p, sz, _u8p, _u16p]
         lib.orc_anscdf4sdec.restype = sz; lib.orc_anscdf4sdec.argtypes = [_u8p, sz, _u8p, _u16p, C.c_uint]
@@ -172,6 +172,8 @@ def orc_enc(codec, data, cdf=None, cdfnum=256):
         l = o.orc_rccdfsenc(_p8(data), n, _p8(out), _p16(cdf), cdfnum)
     elif codec == RCS2:
         l = o.orc_rccdfs2enc(_p8(data), n, _p8(out), _p16(cdf), cdfnum)
+    elif codec == RCSM:
+        l = o.orc_rccdfsmenc(_p8(data), n, _p8(out), _p16(cdf), cdfnum)
     elif codec in _ADAPTIVE:
         l = getattr(o, "orc_" + _ADAPTIVE[codec][0])(_p8(data), n, _p8(out))
     else:
@@ -193,6 +195,8 @@ def orc_dec(codec, comp, n, cdf=None, cdfnum=256):
         o.orc_rccdfsdec(_p8(src), n, _p8(out), _p16(cdf), cdfnum)
     elif codec == RCS2:
         o.orc_rccdfs2dec(_p8(src), n, _p8(out), _p16(cdf), cdfnum)
+    elif codec == RCSM:
+        o.orc_rccdfsmdec(_p8(src), n, _p8(out), _p16(cdf), cdfnum)
     elif codec in _ADAPTIVE:
         getattr(o, "orc_" + _ADAPTIVE[codec][1])(_p8(src), n, _p8(out))
     else:
@@ -238,7 +242,8 @@ def ref():
         lib = C.CDLL(REF_SO)
         sz = C.c_size_t
         lib.cdfini.restype = C.c_int; lib.cdfini.argtypes = [_u8p, sz, _u16p, C.c_uint]
-        for name in ("rccdfsenc", "rccdfsbdec", "rccdfsldec", "rccdfsvbdec", "rccdfsvldec", "rccdfs2enc", "rccdfsb2dec"):
+        for name in ("rccdfsenc", "rccdfsbdec", "rccdfsldec", "rccdfsvbdec", "rccdfsvldec", "rccdfs2enc", "rccdfsb2dec",
+                     "rccdfsmenc", "rccdfsmbdec", "rccdfsmldec"):
             f = getattr(lib, name); f.restype = sz; f.argtypes = [_u8p, sz, _u8p, _u16p, C.c_uint]
         for name in ("anscdf4senc", "anscdf4sencs", "anscdf4sencx"):
             f = getattr(lib, name); f.restype = sz; f.argtypes = [_u8p, sz, _u8p, _u16p]
@@ -272,6 +277,8 @@ def ref_enc(codec, data, cdf=None, cdfnum=256, variant=""):
         l = r.rccdfsenc(pin, n, pout, _p16(cdf), cdfnum)
     elif codec == RCS2:
         l = r.rccdfs2enc(pin, n, pout, _p16(cdf), cdfnum)
+    elif codec == RCSM:
+        l = r.rccdfsmenc(pin, n, pout, _p16(cdf), cdfnum)
     elif codec in _ADAPTIVE:
         l = getattr(r, _ADAPTIVE[codec][0] + (variant if codec in (ANSA, ANSA4) else ""))(pin, n, pout)
     else:
@@ -293,6 +300,8 @@ def ref_dec(codec, comp, n, cdf=None, cdfnum=256, variant="", search="b"):
         getattr(r, "rccdfs%sdec" % search)(_p8(src), n, _p8(out), _p16(cdf), cdfnum)
     elif codec == RCS2:
         r.rccdfsb2dec(_p8(src), n, _p8(out), _p16(cdf), cdfnum)
+    elif codec == RCSM:
+        getattr(r, "rccdfsm%sdec" % search)(_p8(src), n, _p8(out), _p16(cdf), cdfnum)
     elif codec in _ADAPTIVE:
         getattr(r, _ADAPTIVE[codec][1] + (variant if codec in (ANSA, ANSA4) else ""))(_p8(src), n, _p8(out))
     return out[:n].copy()

@@ -62,8 +62,8 @@ extern "C" int trc_set_chunk(uint32_t chunk)
 // per call); beyond it a single-workgroup scan kernel runs
 #define TRC_INKERNEL_SCAN_MAX 8192u
 static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
-static inline bool is_static(int codec) { return codec == TRC_ANS4S || codec == TRC_RCS1 || codec == TRC_RCS2; }
-static inline bool codec_ok(int codec) { return codec >= TRC_ANS4S && codec <= TRC_ANSA4; }
+static inline bool is_static(int codec) { return codec == TRC_ANS4S || codec == TRC_RCS1 || codec == TRC_RCS2 || codec == TRC_RCSM; }
+static inline bool codec_ok(int codec) { return codec >= TRC_ANS4S && codec <= TRC_RCSM; }
 static inline bool two_streams(int codec) { return codec == TRC_RCS2 || codec == TRC_RCAI || codec == TRC_RCAI4; }
 // second scratch array: RCS2 stream 1 (same stride) or ANSA's record stack (8 B per input byte + one segment)
 static inline size_t scratch2_stride(int codec, uint32_t chunk)
@@ -201,6 +201,7 @@ extern "C" int trc_encode_dev(int codec, const void *d_in, size_t n, uint32_t ch
     case TRC_ANS4S: trc_launch_ans4s_enc((const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 1; break;
     case TRC_RCS1:  trc_launch_rcs_enc(1, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 0; break;
     case TRC_RCS2:  trc_launch_rcs_enc(2, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 2; break;
+    case TRC_RCSM:  trc_launch_rcs_enc(-1, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 0; break;
     case TRC_RCB:   trc_launch_rcb_enc((const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 0; break;
     case TRC_RCA:   trc_launch_rca_enc(1, 0, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 0; break;
     case TRC_RCAI:  trc_launch_rca_enc(2, 0, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 2; break;
@@ -236,6 +237,7 @@ extern "C" int trc_decode_dev(int codec, const uint32_t *d_clen, const void *d_p
     case TRC_ANS4S: trc_launch_ans4s_dec((const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     case TRC_RCS1:  trc_launch_rcs_dec(1, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     case TRC_RCS2:  trc_launch_rcs_dec(2, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
+    case TRC_RCSM:  trc_launch_rcs_dec(-1, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     case TRC_RCB:   trc_launch_rcb_dec((const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     case TRC_RCA:   trc_launch_rca_dec(1, 0, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     case TRC_RCAI:  trc_launch_rca_dec(2, 0, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
@@ -253,7 +255,7 @@ extern "C" const char *trc_kernel_name(int codec, int decode)
 {
     switch (codec) {
     case TRC_ANS4S: return decode ? "trc_ans4s_dec_kernel" : "trc_ans4s_enc_kernel";
-    case TRC_RCS1: case TRC_RCS2: return decode ? "trc_rcs_dec_kernel" : "trc_rcs_enc_kernel";
+    case TRC_RCS1: case TRC_RCS2: case TRC_RCSM: return decode ? "trc_rcs_dec_kernel" : "trc_rcs_enc_kernel";
     case TRC_RCB: return decode ? "trc_rcb_dec_kernel" : "trc_rcb_enc_kernel";
     case TRC_RCA: case TRC_RCAI: case TRC_RCA4: case TRC_RCAI4: return decode ? "trc_rca_dec_kernel" : "trc_rca_enc_kernel";
     case TRC_ANSA: case TRC_ANSA4: return decode ? "trc_ansa_dec_kernel" : "trc_ansa_model_kernel";
@@ -420,6 +422,10 @@ TRC_EXPORT_RCS1DEC(rccdfsldec)
 TRC_EXPORT_RCS1DEC(rccdfsbdec)
 TRC_EXPORT_RCS1DEC(rccdfsvldec)
 TRC_EXPORT_RCS1DEC(rccdfsvbdec)
+// one stream, 32-bit range / 16-bit I/O (reference rccdf.c:648-694; turborc -e44) -- SURVEY 8f rank 1
+size_t rccdfsmenc(unsigned char *in, size_t inlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum) { return host_encode(TRC_RCSM, in, inlen, out, cdf, (int)cdfnum); }
+size_t rccdfsmbdec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum) { return host_decode(TRC_RCSM, in, outlen, out, cdf, (int)cdfnum); }
+size_t rccdfsmldec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum) { return host_decode(TRC_RCSM, in, outlen, out, cdf, (int)cdfnum); }
 size_t rccdfs2enc(unsigned char *in, size_t inlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum) { return host_encode(TRC_RCS2, in, inlen, out, cdf, (int)cdfnum); }
 size_t rccdfsl2dec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum) { return host_decode(TRC_RCS2, in, outlen, out, cdf, (int)cdfnum); }
 size_t rccdfsb2dec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum) { return host_decode(TRC_RCS2, in, outlen, out, cdf, (int)cdfnum); }

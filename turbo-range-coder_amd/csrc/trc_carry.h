@@ -18,7 +18,9 @@
 #endif
 #endif
 
-struct TrcCarry {
+// FF = the all-ones word of the coder's I/O width (0xFFFFFFFF: 32-bit words, 0xFFFF: 16-bit words)
+template <uint32_t FF>
+struct TrcCarryT {
     uint32_t cache, npend, nwords;   // nwords counts like the reference's output pointer (held-back words included)
     bool have;
     TRC_HD void start() { cache = 0; npend = 0; nwords = 0; have = false; }
@@ -27,20 +29,20 @@ struct TrcCarry {
     TRC_HD void emit(SINK &so, bool cy, uint32_t W)
     {
         nwords++;
-        if (have && !cy && npend == 0 && W != 0xffffffffu) {           // the common case
+        if (have && !cy && npend == 0 && W != FF) {                    // the common case
             so.put32(cache); cache = W;
             return;
         }
         if (cy) {                                                       // cache+1, then zeros: all final
-            so.put32(cache + 1u);
+            so.put32((cache + 1u) & FF);
             for (; npend; npend--) so.put32_slow(0u);
             have = false;
         }
         if (!have) { cache = W; have = true; }
-        else if (W == 0xffffffffu) npend++;
+        else if (W == FF) npend++;
         else {
             so.put32(cache);
-            for (; npend; npend--) so.put32_slow(0xffffffffu);
+            for (; npend; npend--) so.put32_slow(FF);
             cache = W;
         }
     }
@@ -49,7 +51,7 @@ struct TrcCarry {
     template <class SINK>
     TRC_HD void emit_if(SINK &so, bool on, bool cy, uint32_t W)
     {
-        const bool fast = on && have && !cy && npend == 0 && W != 0xffffffffu;
+        const bool fast = on && have && !cy && npend == 0 && W != FF;
         so.put32_if(fast, cache);
         cache = fast ? W : cache;
         nwords += fast ? 1u : 0u;
@@ -60,8 +62,9 @@ struct TrcCarry {
     {
         if (have) {
             so.put32(cache);
-            for (; npend; npend--) so.put32_slow(0xffffffffu);
+            for (; npend; npend--) so.put32_slow(FF);
             have = false;
         }
     }
 };
+typedef TrcCarryT<0xffffffffu> TrcCarry;

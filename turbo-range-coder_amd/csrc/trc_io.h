@@ -224,6 +224,11 @@ struct StreamOut {
         if (pending() + 4u > TRC_SRING - 4u && (size_t)TRC_SEG * (nfl + 2u) <= stride) self_drain();
         put32(v);
     }
+    __device__ __forceinline__ void put16_slow(u32 v)
+    {
+        if (pending() + 2u > TRC_SRING - 4u && (size_t)TRC_SEG * (nfl + 2u) <= stride) self_drain();
+        put16(v);
+    }
 
     // Move finished segments to HBM.  Called by the whole wave at uniform points.
     // final = false: lanes holding >= 64 pending bytes;  final = true: every lane with pending bytes

@@ -41,7 +41,8 @@ void trc_launch_ans4s_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const T
 void trc_launch_ans4s_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                           const TrcWork &w, uint8_t *d_out, hipStream_t s);
 
-// RCS1 / RCS2: static-CDF range coder, 1 or 2 streams (rccdfsenc / rccdfs2enc and their decoders)
+// RCS1 / RCS2: static-CDF range coder, 1 or 2 streams (rccdfsenc / rccdfs2enc and their decoders);
+// nstreams == -1: RCSM, one stream with the 32-bit range / 16-bit I/O geometry (rccdfsmenc / rccdfsm*dec)
 void trc_launch_rcs_enc(int nstreams, const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w,
                         uint32_t *d_clen, hipStream_t s);
 void trc_launch_rcs_dec(int nstreams, const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,

@@ -23,6 +23,7 @@
 __device__ __forceinline__ int trc_rc_limit(u32 len) { return (int)((len * 255u) >> 8) - 8; }
 
 struct RcEnc {
+    static constexpr u32 WBYTES = 4;                                    // bytes per emitted word
     u64 range, low, mark;
     TrcCarry cw;                                                        // held-back words (trc_carry.h)
 
@@ -87,6 +88,13 @@ struct RcEnc {
 struct RcDec {
     u64 range, code;
     __device__ __forceinline__ void start(u32 w0, u32 w1) { range = ~(u64)0; code = ((u64)w0 << 32) | w1; }
+    template <class SI>
+    __device__ __forceinline__ void init(SI &si)                        // rcdinit: two 32-bit words
+    {
+        const u32 a = si.peek32(); si.rpos += 4; const u32 b = si.peek32(); si.rpos += 4;
+        start(a, b);
+    }
+    __device__ __forceinline__ u32 slot() { range >>= TRC_PROB_BITS; return quotient(); }   // _rccdf: scale, then code/range
     // t = code / r for r = range >> 15 (the caller has NOT shifted range), branch-free: the f32 estimate is within
     // +-1 of the exact quotient (relative errors: operand truncation 2^-23, cvt 2^-24, v_rcp_f32 1 ulp, product 2^-24,
     // times t < 2^15 => < 0.02 absolute), so one correction step each way is exact for every valid stream.
@@ -148,5 +156,87 @@ struct RcDec {
         range = range * c1 - rp;
         code -= rp;
         renorm(si);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// The 32-bit geometry of `turborc -e44` (rccdfsm*, rccdf.c:648-694: RC_SIZE 32, RC_IO 16, RC_BITS 15): 32-bit
+// range/low, 16-bit words, renorm below 2^16 (a single step: range >= 2 after the scale), flush adds 2^16 and
+// emits one word when range > 2^17, else adds 1 and emits two (turborc_.h:118-128 with the 32-bit types).
+// Same append-only carry scheme with 16-bit words.
+template <class SO>
+struct TrcSink16 {                                                      // the carry logic's sink interface on 16-bit words
+    SO &so;
+    __device__ __forceinline__ void put32(u32 v) { so.put16(v); }
+    __device__ __forceinline__ void put32_slow(u32 v) { so.put16_slow(v); }
+    __device__ __forceinline__ void put32_if(bool take, u32 v) { so.put16_if(take, v); }
+};
+struct RcEncSm {
+    static constexpr u32 WBYTES = 2;
+    u32 range, low, mark;
+    TrcCarryT<0xffffu> cw;
+    __device__ __forceinline__ void start() { range = ~0u; low = mark = 0; cw.start(); }
+    template <class SO>
+    __device__ __forceinline__ void renorm(SO &so)
+    {
+        if (range < (1u << 16)) {
+            TrcSink16<SO> k{so};
+            cw.emit(k, mark > low, low >> 16);
+            low <<= 16; range <<= 16; mark = low;
+        }
+    }
+    template <class SO>
+    __device__ __forceinline__ void sym(SO &so, u32 c0, u32 f)
+    {
+        range >>= TRC_PROB_BITS;
+        low += range * c0;
+        range *= f;
+        renorm(so);
+    }
+    template <class SO>
+    __device__ __forceinline__ void finish(SO &so)
+    {
+        TrcSink16<SO> k{so};
+        renorm(so);
+        if (range > (1u << 17)) {
+            low += 1u << 16;
+            cw.emit(k, mark > low, low >> 16);
+        } else {
+            low += 1;
+            cw.emit(k, mark > low, low >> 16);
+            cw.emit(k, false, low & 0xffffu);
+        }
+        cw.release(k);
+    }
+};
+struct RcDecSm {
+    u32 range, code;
+    template <class SI>
+    __device__ __forceinline__ void init(SI &si)                        // rcdinit: two 16-bit words, first one on top
+    {
+        const u32 a = si.peek32(); si.rpos += 4;
+        range = ~0u; code = (a << 16) | (a >> 16);
+    }
+    // scale, then code/range exactly (the reference goes through a reciprocal table, turborc_.h:172-190).  The
+    // quotient can exceed 32767 because range>>15 truncates; every reference search then yields the last symbol.
+    __device__ __forceinline__ u32 slot()
+    {
+        range >>= TRC_PROB_BITS;                                         // 2 <= range < 2^17
+        u32 t = (u32)((float)code * __builtin_amdgcn_rcpf((float)range));   // < 49152, within +-1
+        u64 p = (u64)t * range;
+        if (p > code) { t--; p -= range; }
+        if ((u64)code - p >= range) t++;
+        return t > TRC_PROB_ONE - 1 ? TRC_PROB_ONE - 1 : t;
+    }
+    template <class SI>
+    __device__ __forceinline__ void consume(SI &si, u32 c0, u32 c1)
+    {
+        const u32 rp = range * c0;
+        range = range * c1 - rp;
+        code -= rp;
+        const bool rn = range < (1u << 16);
+        const u32 w = si.peek16();
+        if (rn) { range <<= 16; code = (code << 16) | w; }
+        si.rpos += rn ? 2u : 0u;
     }
 };

@@ -1,9 +1,10 @@
-// trc_rc_static.hip -- static-CDF range coder: one stream (TRC_RCS1) and two interleaved streams
-// (TRC_RCS2, what `turborc -e45` runs).
+// trc_rc_static.hip -- static-CDF range coder: one stream (TRC_RCS1), two interleaved streams (TRC_RCS2, what
+// `turborc -e45` runs), and the 32-bit-range / 16-bit-I/O variant of the one-stream coder (TRC_RCSM, `turborc -e44`).
 //
 // Per chunk the payload is exactly what the reference returns for that slice:
 //   RCS1  rccdfsenc  (rccdf.c:71-81)   : [u32 words of one 64-bit range coder]
 //   RCS2  rccdfs2enc (rccdf.c:125-143) : [u32 len0][stream 0: even-index bytes (+ odd tail byte)][stream 1: odd-index bytes]
+//   RCSM  rccdfsmenc (rccdf.c:655-665) : [u16 words of one 32-bit range coder]   (GEO = 1 below; trc_rc.h RcEncSm/RcDecSm)
 // including the raw fallbacks (OVERFLOW rcutil_.h:130, OVERFLOWI rccdf.c:46).  All reference
 // decoders of a stream (linear/binary/division search, rccdf.c:84-122,146-184) select the same
 // symbols; here the symbol comes from code/range (exact, trc_rc.h) through the slot->symbol LUT.
@@ -16,7 +17,11 @@
 
 #define RCS_WAVE_LDS(NS) ((NS) * TRC_SRING_BYTES + TRC_SEL_BYTES)     // chunk bytes travel through in-register quad transposes
 
-template <int NS>
+template <int GEO> struct RcGeo;
+template <> struct RcGeo<0> { typedef RcEnc Enc; typedef RcDec Dec; };
+template <> struct RcGeo<1> { typedef RcEncSm Enc; typedef RcDecSm Dec; };
+
+template <int NS, int GEO>
 __global__ __launch_bounds__(64) void trc_rcs_enc_kernel(
     const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks, const u32 *__restrict__ tab_g,
     u8 *__restrict__ scrA, u32 strideA, u8 *__restrict__ scrB, u32 strideB,
@@ -44,7 +49,9 @@ __global__ __launch_bounds__(64) void trc_rcs_enc_kernel(
     so0.scratch = scrA; so0.stride = strideA; so0.c0 = wc.c0; so0.wpos = (NS == 2) ? 4u : 0u; so0.nfl = 0;
     so1 = so0;
     if (NS == 2) { so1.rings = so0.rings + TRC_SRING_BYTES; so1.scratch = scrB; so1.stride = strideB; so1.wpos = 0; }
-    RcEnc e0, e1; e0.start(); e1.start();
+    typedef typename RcGeo<GEO>::Enc Enc;
+    constexpr u32 WB = Enc::WBYTES;
+    Enc e0, e1; e0.start(); e1.start();
     const u32 off1 = (NS == 2 && len >= 4u) ? 4u + ((len - 4u) * 37u) / 64u : 0u;   // stream-1 base inside `out` (rccdf.c:126)
     bool ovf = alive && (NS == 2 ? len < 10u : lim <= 0);       // tiny inputs: always raw
     const u32 pairs = len & ~1u;
@@ -78,15 +85,15 @@ __global__ __launch_bounds__(64) void trc_rcs_enc_kernel(
                     const u32 t = tab[mine[pos]];
                     if (NS == 2 && pos < pairs && (pos & 1u)) {
                         e1.sym(so1, t & 0xffffu, t >> 16);          // pair complete: OVERFLOWI (never after the odd tail byte)
-                        ovf = ovf || ((int)(off1 + 4u * e1.cw.nwords) >= lim) || (4u + 4u * e0.cw.nwords >= off1);
+                        ovf = ovf || ((int)(off1 + WB * e1.cw.nwords) >= lim) || (4u + WB * e0.cw.nwords >= off1);
                     } else e0.sym(so0, t & 0xffffu, t >> 16);
                 }
             }
             so0.drain(false, alive);
             if (NS == 2) so1.drain(false, alive);
             // monotone overflow tests (position = last byte coded so far is < pairs for every full piece)
-            if (NS == 1) ovf = ovf || (alive && (int)(4u * e0.cw.nwords) >= lim);
-            else if (act && p0 + 16u <= len) ovf = ovf || ((int)(off1 + 4u * e1.cw.nwords) >= lim) || (4u + 4u * e0.cw.nwords >= off1);
+            if (NS == 1) ovf = ovf || (alive && (int)(WB * e0.cw.nwords) >= lim);
+            else if (act && p0 + 16u <= len) ovf = ovf || ((int)(off1 + WB * e1.cw.nwords) >= lim) || (4u + WB * e0.cw.nwords >= off1);
         }
     }
     u32 out_len = 0;
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(64) void trc_rcs_enc_kernel(
     if (lane == 0) gsum[wc.c0 >> 6] = gs;
 }
 
-template <int NS>
+template <int NS, int GEO>
 __global__ __launch_bounds__(768) void trc_rcs_dec_kernel(
     const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
     u64 n, u32 chunk, u32 nchunks, const u8 *__restrict__ lut_g, const u32 *__restrict__ tab_g, u8 *__restrict__ out)
@@ -149,14 +156,13 @@ __global__ __launch_bounds__(768) void trc_rcs_dec_kernel(
     }
     s0.prime(coded);
     if (NS == 2) s1.prime(coded);
-    RcDec d0, d1;
-    { const u32 a = s0.peek32(); s0.rpos += 4; const u32 b = s0.peek32(); s0.rpos += 4; d0.start(a, b); }
-    if (NS == 2) { const u32 a = s1.peek32(); s1.rpos += 4; const u32 b = s1.peek32(); s1.rpos += 4; d1.start(a, b); }
-    else d1 = d0;
+    typedef typename RcGeo<GEO>::Dec Dec;
+    Dec d0, d1;
+    d0.init(s0);
+    if (NS == 2) d1.init(s1); else d1 = d0;
 
-    auto get = [&](RcDec &d, StreamIn &si) -> u32 {
-        d.range >>= TRC_PROB_BITS;
-        const u32 x = lut[d.quotient()];
+    auto get = [&](Dec &d, StreamIn &si) -> u32 {
+        const u32 x = lut[d.slot()];
         const u32 t = tab[x];
         d.consume(si, t & 0xffffu, (t & 0xffffu) + (t >> 16));
         return x;
@@ -204,30 +210,34 @@ void trc_launch_rcs_enc(int nstreams, const uint8_t *d_in, size_t n, uint32_t ch
 {
     const u32 *tab = (const u32 *)(w.tables + TRC_TAB_DEC);
     if (nstreams == 1)
-        hipLaunchKernelGGL(trc_rcs_enc_kernel<1>, dim3(w.ngroups), dim3(64), 1024 + RCS_WAVE_LDS(1), s,
+        hipLaunchKernelGGL((trc_rcs_enc_kernel<1, 0>), dim3(w.ngroups), dim3(64), 1024 + RCS_WAVE_LDS(1), s,
                            d_in, (u64)n, chunk, w.nchunks, tab, w.scratch, w.stride, w.scratch, w.stride, d_clen, w.gsum);
-    else
-        hipLaunchKernelGGL(trc_rcs_enc_kernel<2>, dim3(w.ngroups), dim3(64), 1024 + RCS_WAVE_LDS(2), s,
+    else if (nstreams == 2)
+        hipLaunchKernelGGL((trc_rcs_enc_kernel<2, 0>), dim3(w.ngroups), dim3(64), 1024 + RCS_WAVE_LDS(2), s,
                            d_in, (u64)n, chunk, w.nchunks, tab, w.scratch, w.stride, w.scratch2, w.stride2, d_clen, w.gsum);
+    else                                                       // nstreams == -1: one stream, 32-bit range / 16-bit words (RCSM)
+        hipLaunchKernelGGL((trc_rcs_enc_kernel<1, 1>), dim3(w.ngroups), dim3(64), 1024 + RCS_WAVE_LDS(1), s,
+                           d_in, (u64)n, chunk, w.nchunks, tab, w.scratch, w.stride, w.scratch, w.stride, d_clen, w.gsum);
 }
 
-template <int NS>
+template <int NS, int GEO>
 static void launch_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                        const TrcWork &w, uint8_t *d_out, hipStream_t s)
 {
     const u32 maxw = NS == 1 ? 12u : 7u;                       // 34 KiB tables + waves x (NS rings) must fit 160 KiB
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)trc_rcs_dec_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(32768 + 1024 + maxw * RCS_WAVE_LDS(NS))); attr = true; }
+    if (!attr) { (void)hipFuncSetAttribute((const void *)trc_rcs_dec_kernel<NS, GEO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(32768 + 1024 + maxw * RCS_WAVE_LDS(NS))); attr = true; }
     u32 wpb = (w.ngroups + 255u) / 256u;                       // just enough waves per workgroup to give every CU one
     wpb = wpb < 1u ? 1u : wpb > maxw ? maxw : wpb;
     const size_t sm = 32768 + 1024 + wpb * RCS_WAVE_LDS(NS);
-    hipLaunchKernelGGL((trc_rcs_dec_kernel<NS>), dim3((w.ngroups + wpb - 1) / wpb), dim3(64 * wpb), sm, s,
+    hipLaunchKernelGGL((trc_rcs_dec_kernel<NS, GEO>), dim3((w.ngroups + wpb - 1) / wpb), dim3(64 * wpb), sm, s,
                        d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, w.tables + TRC_TAB_LUT,
                        (const u32 *)(w.tables + TRC_TAB_DEC), d_out);
 }
 void trc_launch_rcs_dec(int nstreams, const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                         const TrcWork &w, uint8_t *d_out, hipStream_t s)
 {
-    if (nstreams == 1) launch_dec<1>(d_payload, d_clen, n, chunk, w, d_out, s);
-    else               launch_dec<2>(d_payload, d_clen, n, chunk, w, d_out, s);
+    if (nstreams == 1)      launch_dec<1, 0>(d_payload, d_clen, n, chunk, w, d_out, s);
+    else if (nstreams == 2) launch_dec<2, 0>(d_payload, d_clen, n, chunk, w, d_out, s);
+    else                    launch_dec<1, 1>(d_payload, d_clen, n, chunk, w, d_out, s);
 }

@@ -16,12 +16,12 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 LIB = os.environ.get("TRC_LIB") or os.path.join(PKG, "libturborc_hip.so")   # TRC_LIB: A/B builds for ablations
 
-ANS4S, RCS1, RCS2, RCA, ANSA, RCB, RCAI, RCA4, RCAI4, ANSA4 = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+ANS4S, RCS1, RCS2, RCA, ANSA, RCB, RCAI, RCA4, RCAI4, ANSA4, RCSM = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 CODEC_NAMES = {ANS4S: "anscdf4s", RCS1: "rccdfs", RCS2: "rccdfs2", RCA: "rccdf", ANSA: "anscdf", RCB: "rcs", RCAI: "rccdfi",
-               RCA4: "rccdf4", RCAI4: "rccdf4i", ANSA4: "anscdf4"}
+               RCA4: "rccdf4", RCAI4: "rccdf4i", ANSA4: "anscdf4", RCSM: "rccdfsm"}
 NIBBLE_CODECS = (RCA4, RCAI4, ANSA4)                           # `turborc -n` coders: input values 0..15
-STATIC = (ANS4S, RCS1, RCS2)
-AVAILABLE = (ANS4S, RCS1, RCS2, RCB, RCA, ANSA, RCAI, RCA4, RCAI4, ANSA4)          # codecs with HIP kernels behind them (grows per round)
+STATIC = (ANS4S, RCS1, RCS2, RCSM)
+AVAILABLE = (ANS4S, RCS1, RCS2, RCB, RCA, ANSA, RCAI, RCA4, RCAI4, ANSA4, RCSM)          # codecs with HIP kernels behind them (grows per round)
 PAD = 256
 HDR = 32
 
@@ -169,9 +169,9 @@ class DeviceCoder:
 
 # ------------------------------------------------------ reference-signature layer (host pointers) ---
 _HOST_ENC = {ANS4S: "anscdf4senc", RCS1: "rccdfsenc", RCS2: "rccdfs2enc", RCA: "rccdfenc", ANSA: "anscdfenc", RCB: "rcsenc", RCAI: "rccdfienc",
-             RCA4: "rccdf4enc", RCAI4: "rccdf4ienc", ANSA4: "anscdf4enc"}
+             RCA4: "rccdf4enc", RCAI4: "rccdf4ienc", ANSA4: "anscdf4enc", RCSM: "rccdfsmenc"}
 _HOST_DEC = {ANS4S: "anscdf4sdec", RCS1: "rccdfsbdec", RCS2: "rccdfsb2dec", RCA: "rccdfdec", ANSA: "anscdfdec", RCB: "rcsdec", RCAI: "rccdfidec",
-             RCA4: "rccdf4dec", RCAI4: "rccdf4idec", ANSA4: "anscdf4dec"}
+             RCA4: "rccdf4dec", RCAI4: "rccdf4idec", ANSA4: "anscdf4dec", RCSM: "rccdfsmbdec"}
 
 
 def _host_fn(name, codec):
@@ -179,7 +179,7 @@ def _host_fn(name, codec):
     f.restype = _sz
     if codec == ANS4S:
         f.argtypes = [_u8p, _sz, _u8p, _u16p]
-    elif codec in (RCS1, RCS2):
+    elif codec in (RCS1, RCS2, RCSM):
         f.argtypes = [_u8p, _sz, _u8p, _u16p, C.c_uint]
     else:
         f.argtypes = [_u8p, _sz, _u8p]
@@ -195,7 +195,7 @@ def host_encode(codec, data, cdf=None, cdfnum=256, name=None):
     pin, pout = data.ctypes.data_as(_u8p), out.ctypes.data_as(_u8p)
     if codec == ANS4S:
         l = f(pin, n, pout, cdf.ctypes.data_as(_u16p))
-    elif codec in (RCS1, RCS2):
+    elif codec in (RCS1, RCS2, RCSM):
         l = f(pin, n, pout, cdf.ctypes.data_as(_u16p), cdfnum)
     else:
         l = f(pin, n, pout)
@@ -214,7 +214,7 @@ def host_decode(codec, comp, n, cdf=None, cdfnum=256, name=None):
     pin, pout = src.ctypes.data_as(_u8p), out.ctypes.data_as(_u8p)
     if codec == ANS4S:
         l = f(pin, n, pout, cdf.ctypes.data_as(_u16p))
-    elif codec in (RCS1, RCS2):
+    elif codec in (RCS1, RCS2, RCSM):
         l = f(pin, n, pout, cdf.ctypes.data_as(_u16p), cdfnum)
     else:
         l = f(pin, n, pout)
