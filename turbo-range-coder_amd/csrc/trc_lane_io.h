@@ -13,7 +13,8 @@
 #pragma once
 #include "trc_dev.h"
 
-struct __attribute__((packed, aligned(4))) trc_u128_a4 { u32 x, y, z, w; };
+typedef u32 trc_u32x4 __attribute__((ext_vector_type(4)));
+typedef trc_u32x4 trc_u32x4_a4 __attribute__((aligned(4)));          // 16-byte store that only needs dword alignment
 
 struct LaneOut32 {
     u8 *dst;             // this lane's region (4-byte aligned)
@@ -24,11 +25,14 @@ struct LaneOut32 {
     __device__ __forceinline__ void put32_if(bool take, u32 v)
     {
         if (take && (wpos & 12u) == 12u) {
-            trc_u128_a4 q; q.x = h0; q.y = h1; q.z = h2; q.w = v;
-            *(trc_u128_a4 *)(dst + wpos - 12u) = q;
+            const trc_u32x4 q = { h0, h1, h2, v };
+            *(trc_u32x4_a4 *)(dst + wpos - 12u) = q;
         }
-        h0 = take ? h1 : h0; h1 = take ? h2 : h1; h2 = take ? v : h2;
-        wpos += take ? 4u : 0u;
+        // bit-select form (v_bfi_b32): a ?: on the members can become a select of their ADDRESSES, which pins the
+        // whole struct in scratch memory
+        const u32 m = take ? 0xffffffffu : 0u;
+        h0 = (h1 & m) | (h0 & ~m); h1 = (h2 & m) | (h1 & ~m); h2 = (v & m) | (h2 & ~m);
+        wpos += 4u & m;
     }
     __device__ __forceinline__ void put32(u32 v) { put32_if(true, v); }
     __device__ __forceinline__ void put32_slow(u32 v) { put32_if(true, v); }

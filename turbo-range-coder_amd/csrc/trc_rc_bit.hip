@@ -8,16 +8,22 @@
 //   p -= ((p - (bit<<15)) >> 5) + bit (32-bit unsigned arithmetic, low 16 bits kept);
 //   renormalisation ONLY before bits 7,5,3,1 (the reference's _RCENORM1 is empty, _RCENORM2 live).
 //
-// One lane = one chunk = one range-coder state.  The lane's 256 x u16 model lives in LDS in a
-// [context][lane] layout (2 lanes per bank, independent of the context each lane is at), 32 KiB per
-// wave: that, not registers, bounds occupancy (3 waves per CU).  Eight dependent LDS
-// read-modify-writes per byte make this the slowest coder of the family; HBM traffic is coalesced
-// through the same tiles/rings as everywhere else (trc_io.h).
+// One lane = one chunk = one range-coder state.  The lane's 256 x u16 model lives in LDS in a [context][lane] layout
+// (2 lanes per bank, independent of the context each lane is at), 32 KiB per wave, and it is the ONLY thing in LDS:
+// chunk bytes move through in-register quad transposes (trc_io.h QuadIn/QuadOut), the coded stream through a 16-byte
+// register window per lane (trc_lane_io.h), so five waves share a CU.  What bounds the coder is the latency of the
+// model accesses, eight per byte:
+//   encoder  the eight nodes a byte visits are known from the byte itself ((0x100|x) >> (8-k)) and are all different,
+//            so their probabilities are read in one batch, the eight coding steps run on registers (predicated renorm,
+//            no branches), and the eight updated probabilities are written back in one batch;
+//   decoder  the path depends on the decoded bits; both children of the current node are requested before the bit is
+//            resolved, so the next probability is already on its way while the current step computes.
 #include "trc_rc.h"
+#include "trc_lane_io.h"
 #include "trc_launch.h"
 
 #define RCB_MODEL_BYTES (256u * 64u * 2u)                  // [ctx][lane] u16
-#define RCB_WAVE_LDS    (RCB_MODEL_BYTES + TRC_TILE_BYTES + TRC_SRING_BYTES + TRC_SEL_BYTES)
+#define RCB_WAVE_LDS    RCB_MODEL_BYTES
 
 __device__ __forceinline__ u32 rcb_adapt(u32 p, u32 bit) { return (p - (((p - (bit << TRC_PROB_BITS)) >> 5) + bit)) & 0xffffu; }
 
@@ -28,7 +34,6 @@ __global__ __launch_bounds__(64) void trc_rcb_enc_kernel(
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const u32 lane = threadIdx.x;
     u16 *mb = (u16 *)smem + lane;                              // mb[ctx * 64]
-    u8 *wbase = smem + RCB_MODEL_BYTES;
     for (u32 i = 0; i < 256; i++) mb[i * 64] = (u16)(TRC_PROB_ONE >> 1);
 
     WaveChunks wc;
@@ -40,43 +45,64 @@ __global__ __launch_bounds__(64) void trc_rcb_enc_kernel(
     const u32 len = alive ? wc.len_of(lane) : 0u;
     const int lim = trc_rc_limit(len);
 
-    TileIn tin; tin.tile = wbase; tin.base = in + (u64)wc.c0 * chunk;
-    StreamOut<false> so;
-    so.rings = wbase + TRC_TILE_BYTES; so.sel = wbase + TRC_TILE_BYTES + TRC_SRING_BYTES;
-    so.scratch = scratch; so.stride = stride; so.c0 = wc.c0; so.wpos = 0; so.nfl = 0;
+    QuadIn qin; qin.base = in + (u64)wc.c0 * chunk;
+    LaneOut32 so; so.start(scratch + (u64)c * stride);
     RcEnc e; e.start();
     bool ovf = alive && lim <= 0;
 
-    auto put_byte = [&](u32 x) {
-        u32 ctx = 1;
+    // one byte: where !act nothing but the (dead) lane's own model changes.  The body is a 4-trip loop over bit
+    // pairs (renorm + two steps) so that the kernel stays small in the instruction cache.
+    auto put_byte = [&](u32 x, bool act) {
+        const u32 path = 0x100u | x;
+        u32 pp0, pp1, pp2, pp3;                                // the eight probabilities, two per register
+        {
+            const u32 a0 = mb[(path >> 8) * 64], a1 = mb[(path >> 7) * 64], a2 = mb[(path >> 6) * 64], a3 = mb[(path >> 5) * 64];
+            const u32 a4 = mb[(path >> 4) * 64], a5 = mb[(path >> 3) * 64], a6 = mb[(path >> 2) * 64], a7 = mb[(path >> 1) * 64];
+            pp0 = a0 | a1 << 16; pp1 = a2 | a3 << 16; pp2 = a4 | a5 << 16; pp3 = a6 | a7 << 16;
+        }
+        u32 xs = x << 24, node = 1;
+#pragma nounroll
+        for (u32 j = 0; j < 4; j++) {
+            {                                                  // renorm before bits 7,5,3,1 only (_RCENORM2)
+                const bool rn = act && e.range < TRC_TOP32;
+                e.cw.emit_if(so, rn, e.mark > e.low, (u32)(e.low >> 32));
+                e.low = rn ? e.low << 32 : e.low;
+                e.range = rn ? e.range << 32 : e.range;
+                e.mark = rn ? e.low : e.mark;
+            }
 #pragma unroll
-        for (int b = 7; b >= 0; b--) {
-            if (b & 1) e.renorm(so);                           // before bits 7,5,3,1 only
-            const u32 p = mb[ctx * 64], bit = (x >> b) & 1u;
-            e.bit(so, p, bit);
-            mb[ctx * 64] = (u16)rcb_adapt(p, bit);
-            ctx = ctx * 2 + bit;
+            for (int h = 0; h < 2; h++) {
+                const u32 p = h ? pp0 >> 16 : pp0 & 0xffffu;
+                const u32 bit = xs >> 31; xs <<= 1;
+                const u64 cut = (e.range >> TRC_PROB_BITS) * p;                  // rcbe_
+                const u64 nr = bit ? cut : e.range - cut;
+                e.low += (act && !bit) ? cut : 0;
+                e.range = act ? nr : e.range;
+                mb[node * 64] = (u16)rcb_adapt(p, bit);
+                node = node * 2 + bit;
+            }
+            pp0 = pp1; pp1 = pp2; pp2 = pp3;
         }
     };
 
     const u32 S = chunk / TRC_SEG;
-    tin.issue(wc, 0);
+    qin.issue(wc, 0);
     for (u32 s = 0; s < S; s++) {
-        tin.commit();
-        if (s + 1 < S) tin.issue(wc, (s + 1) * TRC_SEG);
+        qin.commit();
+        if (s + 1 < S) qin.issue(wc, (s + 1) * TRC_SEG);
+        uint4 pc0 = qin.read(0), pc1 = qin.read(1), pc2 = qin.read(2), pc3 = qin.read(3);
+#pragma nounroll
         for (u32 k = 0; k < 4; k++) {
-            const u32 p0 = s * TRC_SEG + k * 16u;
-            const uint4 v = tin.read(k);
-            const u32 w[4] = { v.x, v.y, v.z, v.w };
-#pragma unroll
-            for (int d = 0; d < 4; d++) {                      // period = 4 bytes: <= 8 words (<= 2 per byte)
-                const u32 q0 = p0 + (u32)d * 4u;
-                if (alive && !ovf && q0 < len) {
-                    const u32 nb = len - q0 < 4u ? len - q0 : 4u;
-                    for (u32 i = 0; i < nb; i++) put_byte((w[d] >> (8 * i)) & 255u);
-                }
-                so.drain(false, alive);
-                ovf = ovf || (alive && (int)(4u * e.cw.nwords) >= lim);
+            uint4 v = pc0; pc0 = pc1; pc1 = pc2; pc2 = pc3;
+            if (!__ballot(alive && !ovf && s * TRC_SEG + k * 16u < len)) continue;
+#pragma nounroll
+            for (u32 d = 0; d < 4; d++) {
+                const u32 w = v.x; v.x = v.y; v.y = v.z; v.z = v.w;
+                const u32 q0 = s * TRC_SEG + k * 16u + d * 4u;
+                const bool run = alive && !ovf;
+#pragma nounroll
+                for (u32 i = 0; i < 4; i++) put_byte((w >> (8 * i)) & 255u, run && q0 + i < len);
+                ovf = ovf || (run && q0 < len && (int)(4u * e.cw.nwords) >= lim);   // OVERFLOW per byte, monotone
             }
         }
     }
@@ -85,7 +111,7 @@ __global__ __launch_bounds__(64) void trc_rcb_enc_kernel(
         if (!ovf) { e.finish(so); out_len = so.wpos; }
         else out_len = len;
     }
-    so.drain(true, alive && !ovf);
+    so.finish(alive && !ovf);
     if (alive) clen[c] = out_len;
     const u32 gs = trc_wave_sum(out_len);
     if (lane == 0) gsum[wc.c0 >> 6] = gs;
@@ -98,7 +124,6 @@ __global__ __launch_bounds__(64) void trc_rcb_dec_kernel(
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const u32 lane = threadIdx.x;
     u16 *mb = (u16 *)smem + lane;
-    u8 *wbase = smem + RCB_MODEL_BYTES;
     for (u32 i = 0; i < 256; i++) mb[i * 64] = (u16)(TRC_PROB_ONE >> 1);
 
     WaveChunks wc;
@@ -113,50 +138,68 @@ __global__ __launch_bounds__(64) void trc_rcb_dec_kernel(
     const u64 off = trc_group_base(goff, gsum, wc.c0 >> 6) + ex;
     const bool coded = alive && cl != len;
 
-    TileOut tout; tout.tile = wbase; tout.base = out + (u64)wc.c0 * chunk;
-    StreamIn si;
-    si.rings = wbase + TRC_TILE_BYTES; si.sel = wbase + TRC_TILE_BYTES + TRC_SRING_BYTES;
-    si.gbase = payload; si.soff = off;
-    si.prime(coded);
+    LaneIn<4> si; si.prime(payload + off, coded);
     RcDec dc;
-    { const u32 a = si.peek32(); si.rpos += 4; const u32 b = si.peek32(); si.rpos += 4; dc.start(a, b); }
+    { const u32 a = si.peek32(); si.skip_if(coded); const u32 b = si.peek32(); si.skip_if(coded); dc.start(a, b); }
 
-    auto get_byte = [&]() -> u32 {
+    auto get_byte = [&](bool act) -> u32 {
         u32 ctx = 1;
+        u32 p = mb[64];
+#pragma nounroll
+        for (u32 j = 0; j < 4; j++) {
+            {                                                  // renorm before bits 7,5,3,1 only
+                const bool rn = act && dc.range < TRC_TOP32;
+                const u32 w = si.peek32();
+                dc.range = rn ? dc.range << 32 : dc.range;
+                dc.code = rn ? (dc.code << 32) | w : dc.code;
+                si.skip_if(rn);
+            }
 #pragma unroll
-        for (int b = 7; b >= 0; b--) {
-            if (b & 1) dc.renorm(si);
-            const u32 p = mb[ctx * 64];
-            const u64 cut = (dc.range >> TRC_PROB_BITS) * p;
-            const bool one = dc.code < cut;                    // rcbd_
-            dc.range = one ? cut : dc.range - cut;
-            dc.code -= one ? 0 : cut;
-            mb[ctx * 64] = (u16)rcb_adapt(p, one ? 1u : 0u);
-            ctx = ctx * 2 + (one ? 1u : 0u);
+            for (int h = 0; h < 2; h++) {
+                // both children are requested before this bit is known (below the last level the index wraps into the
+                // model and the values are unused)
+                const u32 lc = (2u * ctx) & 255u;
+                const u32 pl = mb[lc * 64], pr = mb[(lc + 1u) * 64];
+                const u64 cut = (dc.range >> TRC_PROB_BITS) * p;
+                const bool one = dc.code < cut;                // rcbd_
+                const u64 nr = one ? cut : dc.range - cut, nc = one ? dc.code : dc.code - cut;
+                dc.range = act ? nr : dc.range;
+                dc.code = act ? nc : dc.code;
+                mb[ctx * 64] = (u16)rcb_adapt(p, one ? 1u : 0u);
+                ctx = ctx * 2 + (one ? 1u : 0u);
+                p = one ? pr : pl;
+            }
         }
         return ctx & 255u;
     };
 
-    const u32 S = chunk / TRC_SEG;
+    QuadOut qout; qout.base = out + (u64)wc.c0 * chunk;
     u8 *dst = out + (u64)c * chunk;
+    const u32 S = chunk / TRC_SEG;
     for (u32 s = 0; s < S; s++) {
+        uint4 pc0 = make_uint4(0, 0, 0, 0), pc1 = pc0, pc2 = pc0, pc3 = pc0;
+#pragma nounroll
         for (u32 k = 0; k < 4; k++) {
             const u32 p0 = s * TRC_SEG + k * 16u;
-            u32 w[4] = { 0, 0, 0, 0 };
-#pragma unroll
-            for (int d = 0; d < 4; d++) {
-                const u32 q0 = p0 + (u32)d * 4u;
-                si.period(coded && q0 < len, d & 1);
-                if (coded && q0 < len) {
-                    const u32 nb = len - q0 < 4u ? len - q0 : 4u;
-                    for (u32 i = 0; i < nb; i++) w[d] |= get_byte() << (8 * i);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (__ballot(coded && p0 < len)) {
+#pragma nounroll
+                for (u32 d = 0; d < 4; d++) {
+                    const u32 q0 = p0 + d * 4u;
+                    u32 w = 0;
+#pragma nounroll
+                    for (u32 i = 0; i < 4; i++) w |= get_byte(coded && q0 + i < len) << (8 * i);
+                    v.x = v.y; v.y = v.z; v.z = v.w; v.w = w;
+                }
+                if (coded && p0 < len && p0 + 16u > len) {      // ragged end of the last chunk: byte stores
+                    const u32 ww[4] = { v.x, v.y, v.z, v.w };
+                    for (u32 pos = p0; pos < len; pos++) dst[pos] = (u8)(ww[(pos - p0) >> 2] >> (8 * ((pos - p0) & 3u)));
                 }
             }
-            if (coded && p0 + 16u <= len) tout.put(k, make_uint4(w[0], w[1], w[2], w[3]));
-            else if (coded && p0 < len)
-                for (u32 pos = p0; pos < len; pos++) dst[pos] = (u8)(w[(pos - p0) >> 2] >> (8 * ((pos - p0) & 3u)));
+            pc0 = pc1; pc1 = pc2; pc2 = pc3; pc3 = v;
         }
-        tout.flush(wc, s * TRC_SEG);
+        qout.put(0, pc0); qout.put(1, pc1); qout.put(2, pc2); qout.put(3, pc3);
+        qout.flush(wc, s * TRC_SEG);
     }
     u64 rawmask = __ballot(alive && cl == len && len != 0);
     while (rawmask) {
