@@ -145,61 +145,75 @@ __global__ __launch_bounds__(256) void trc_gather_kernel(const u8 *__restrict__ 
         }
         return;
     }
-    auto find = [&](u32 d) -> u32 {                           // chunk k with ex[k] <= d < ex[k+1]
-        u32 lo = 0, hi = 64;
-        while (lo + 1 < hi) { const u32 mid = (lo + hi) >> 1; if (ex_s[mid] <= d) lo = mid; else hi = mid; }
-        return lo;
-    };
     auto src_of = [&](u32 k) -> const u8 * {
         return trc_gather_src(k, ex_s[k + 1] - ex_s[k], g * 64 + k, n, chunk, in, scratch, stride, mode);
     };
-    // bytes before the first / after the last dst-aligned vector
+    // The group's bytes go out as dst-aligned 16-byte vectors.  Vector v (bytes [head + 16v, +16) of the group) belongs
+    // to the chunk that holds its FIRST byte; four threads walk the vectors of one chunk, so nothing has to be searched:
+    // every load address follows from the prefix table, and a thread's loads are all independent.  A vector that runs
+    // past its chunk's end takes the rest from the next chunk (second load, merged by byte mask); in the rare case that
+    // the next chunk is shorter than that rest (tiny chunks) the vector is assembled byte by byte.
     u32 head = (u32)((16u - ((uintptr_t)dst0 & 15u)) & 15u);
     if (head > tot) head = tot;
     const u32 nvec = (tot - head) >> 4;
     const u32 tail0 = head + (nvec << 4);
-    for (u32 b = tid; b < head + (tot - tail0); b += 256) {
+    for (u32 b = tid; b < head + (tot - tail0); b += 256) {     // bytes before the first / after the last aligned vector
         const u32 d = b < head ? b : tail0 + (b - head);
-        const u32 k = find(d);
-        dst0[d] = src_of(k)[d - ex_s[k]];
+        u32 lo = 0, hi = 64;
+        while (lo + 1 < hi) { const u32 mid = (lo + hi) >> 1; if (ex_s[mid] <= d) lo = mid; else hi = mid; }
+        dst0[d] = src_of(lo)[d - ex_s[lo]];
     }
-    // four vectors per thread per trip so that 4-8 independent loads are in flight
-    for (u32 v0 = tid; v0 < nvec; v0 += 1024) {
-        u32 d[4], k[4], sp[4];
-        uint4 a[4], b[4];
-        bool ok[4], slow[4];
+    {
+        const u32 k = tid >> 2, sub = tid & 3u;
+        const u32 e0 = ex_s[k], e1 = ex_s[k + 1];
+        // vectors whose first byte lies in [e0, e1): first index = ceil((e0 - head)/16) (0 if e0 <= head), end likewise from e1
+        const u32 v_lo = e0 <= head ? 0u : (e0 - head + 15u) >> 4;
+        u32 v_hi = e1 <= head ? 0u : (e1 - head + 15u) >> 4;
+        if (v_hi > nvec) v_hi = nvec;
+        const u8 *sa = src_of(k);
+        const u8 *sb = k + 1 < 64 ? src_of(k + 1) : sa;
+        const u32 e2 = ex_s[k + 2 > 64 ? 64 : k + 2];
+        for (u32 v0 = v_lo + sub; v0 < v_hi; v0 += 16) {        // four vectors per thread per trip
+            uint4 a[4], b[4];
+            u32 d[4];
+            bool ok[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const u32 v = v0 + 256u * (u32)j;
-            ok[j] = v < nvec;
-            d[j] = head + ((ok[j] ? v : v0) << 4);
-            k[j] = find(d[j]);
-            const u32 e1 = ex_s[k[j] + 1];
-            sp[j] = e1 - d[j];                                 // bytes of this vector that belong to chunk k (>= 16: all)
-            const bool two = sp[j] < 16u;
-            slow[j] = two && (k[j] + 1 >= 64 || d[j] + 16u > ex_s[k[j] + 2 > 64 ? 64 : k[j] + 2]);
-            a[j] = trc_ld16_a2(src_of(k[j]) + (d[j] - ex_s[k[j]]));
-            b[j] = (two && !slow[j]) ? trc_ld16_a2(src_of(k[j] + 1) - sp[j]) : a[j];
-        }
+            for (int j = 0; j < 4; j++) {
+                const u32 v = v0 + 4u * (u32)j;
+                ok[j] = v < v_hi;
+                d[j] = head + ((ok[j] ? v : v0) << 4);
+                a[j] = trc_ld16_a2(sa + (d[j] - e0));
+                b[j] = a[j];
+            }
+            // only the chunk's last vector can straddle its end
+            const u32 vl = v_hi - 1u;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (!ok[j]) continue;
-            if (!slow[j]) {
-                const u32 aw[4] = { a[j].x, a[j].y, a[j].z, a[j].w }, bw[4] = { b[j].x, b[j].y, b[j].z, b[j].w };
-                u32 r[4];
+            for (int j = 0; j < 4; j++) {
+                const u32 v = v0 + 4u * (u32)j;
+                if (ok[j] && v == vl && d[j] + 16u > e1 && d[j] + 16u <= e2) b[j] = trc_ld16_a2(sb - (e1 - d[j]));
+            }
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int nb = (int)(sp[j] > 16u ? 16u : sp[j]) - 4 * q;
-                    const u32 m = nb >= 4 ? 0xffffffffu : nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u);
-                    r[q] = (aw[q] & m) | (bw[q] & ~m);
-                }
-                *(uint4 *)(dst0 + d[j]) = make_uint4(r[0], r[1], r[2], r[3]);
-            } else {                                           // three or more chunks inside 16 bytes (tiny chunks): byte by byte
-                u32 kk = k[j];
-                const u8 *p = src_of(kk);
-                for (u32 q = 0; q < 16; q++) {
-                    while (d[j] + q >= ex_s[kk + 1]) { kk++; p = src_of(kk); }
-                    dst0[d[j] + q] = p[d[j] + q - ex_s[kk]];
+            for (int j = 0; j < 4; j++) {
+                if (!ok[j]) continue;
+                const u32 sp = e1 - d[j];                       // bytes of this vector inside chunk k (>= 16: all)
+                if (sp >= 16u) { *(uint4 *)(dst0 + d[j]) = a[j]; continue; }
+                if (d[j] + 16u <= e2) {
+                    const u32 aw[4] = { a[j].x, a[j].y, a[j].z, a[j].w }, bw[4] = { b[j].x, b[j].y, b[j].z, b[j].w };
+                    u32 r[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int nb = (int)sp - 4 * q;
+                        const u32 m = nb >= 4 ? 0xffffffffu : nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u);
+                        r[q] = (aw[q] & m) | (bw[q] & ~m);
+                    }
+                    *(uint4 *)(dst0 + d[j]) = make_uint4(r[0], r[1], r[2], r[3]);
+                } else {                                       // three or more chunks inside 16 bytes: byte by byte
+                    u32 kk = k;
+                    const u8 *p = sa;
+                    for (u32 q = 0; q < 16; q++) {
+                        while (d[j] + q >= ex_s[kk + 1]) { kk++; p = src_of(kk); }
+                        dst0[d[j] + q] = p[d[j] + q - ex_s[kk]];
+                    }
                 }
             }
         }
