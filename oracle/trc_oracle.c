@@ -654,6 +654,94 @@ size_t orc_anscdf4dec(const uint8_t *in, size_t outlen, uint8_t *out)
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* anscdf1enc / anscdf1dec (anscdf.c:607-645; mnenc8x2x/mndec8x2x anscdf_.h:121-126,164-174), */
+/* `turborc -e64`: the byte rANS of M8 with an order-1 model -- hi table selected by the previous byte, lo table  */
+/* by (previous byte, hi nibble); 256 x (17 + 16 x 17) u16 = 148 KB, reset per 4 MiB block.  The context byte     */
+/* itself is NOT reset between blocks (declared outside the block loop); an odd tail pairs with a coded dummy 0,   */
+/* which also becomes the context.                                                                               */
+typedef struct { uint16_t hi[256][17]; uint16_t lo[256][16][17]; } o1model_t;
+static void o1_reset(o1model_t *m)
+{
+    for (int c = 0; c < 256; c++)
+        for (int j = 0; j <= 16; j++) {
+            m->hi[c][j] = (uint16_t)(j << 11);
+            for (int i = 0; i < 16; i++) m->lo[c][i][j] = (uint16_t)(j << 11);
+        }
+}
+size_t orc_anscdf1enc(const uint8_t *in, size_t inlen, uint8_t *out)
+{
+    size_t blk = inlen < ANS_BLOCK ? inlen : ANS_BLOCK;
+    uint32_t *stack = (uint32_t *)malloc((blk + 1) * 2 * sizeof(uint32_t) + 64);
+    o1model_t *m = (o1model_t *)malloc(sizeof *m);
+    uint8_t *op = out, *oend = out + inlen;
+    size_t pos = 0;
+    unsigned cx = 0;
+    if (!stack || !m) { free(stack); free(m); return 0; }
+    while (pos < inlen) {
+        size_t len = inlen - pos < blk ? inlen - pos : blk, k, ns = 0;
+        o1_reset(m);
+        for (k = 0; k < len + (len & 1); k += 2) {
+            unsigned xs[2] = { in[pos + k], (k + 1 < len) ? in[pos + k + 1] : 0u };
+            for (int b = 0; b < 2; b++) {
+                unsigned h = xs[b] >> 4, l = xs[b] & 15, sid = 3u - 2u * (unsigned)b;
+                uint16_t *th = m->hi[cx], *tl = m->lo[cx][h];
+                stack[ns++] = sid << 30 | (uint32_t)th[h] << 15 | (uint32_t)(th[h + 1] - th[h]);
+                nib_adapt(th, h);
+                stack[ns++] = (sid - 1) << 30 | (uint32_t)tl[l] << 15 | (uint32_t)(tl[l + 1] - tl[l]);
+                nib_adapt(tl, l);
+                cx = xs[b];
+            }
+        }
+        uint32_t st[4] = { ANS_LO, ANS_LO, ANS_LO, ANS_LO };
+        uint8_t *ep = oend;
+        while (ns) {
+            uint32_t r = stack[--ns];
+            if (ep <= op + 2 + 16) goto raw;
+            ans_put(&st[r >> 30], (r >> 15) & 0x7fff, r & 0x7fff, &ep);
+        }
+        for (k = 0; k < 4; k++) { ep -= 4; st32(ep, st[k]); }
+        if (ep <= op) goto raw;
+        size_t l = (size_t)(oend - ep);
+        if (op + l >= oend) goto raw;
+        memmove(op, ep, l); op += l;
+        pos += len;
+    }
+    free(stack); free(m);
+    return (size_t)(op - out);
+raw:
+    free(stack); free(m);
+    memcpy(out, in, inlen);                            /* whole input from its true start (cf. orc_anscdfenc) */
+    return inlen;
+}
+size_t orc_anscdf1dec(const uint8_t *in, size_t outlen, uint8_t *out)
+{
+    size_t blk = outlen < ANS_BLOCK ? outlen : ANS_BLOCK, pos = 0;
+    const uint8_t *ip = in;
+    o1model_t *m = (o1model_t *)malloc(sizeof *m);
+    unsigned cx = 0;
+    if (!m) return 0;
+    while (pos < outlen) {
+        size_t len = outlen - pos < blk ? outlen - pos : blk, k;
+        uint32_t st[4];
+        o1_reset(m);
+        for (k = 0; k < 4; k++) { st[k] = ld32(ip); ip += 4; }
+        for (k = 0; k < len; k += 2) {
+            unsigned h0 = ansd_nibble(&st[0], m->hi[cx]), l0 = ansd_nibble(&st[1], m->lo[cx][h0]);
+            cx = h0 << 4 | l0;
+            unsigned h1 = ansd_nibble(&st[2], m->hi[cx]), l1 = ansd_nibble(&st[3], m->lo[cx][h1]);
+            cx = h1 << 4 | l1;
+            ansd_renorm(&st[0], &ip); ansd_renorm(&st[1], &ip);
+            ansd_renorm(&st[2], &ip); ansd_renorm(&st[3], &ip);
+            out[pos + k] = (uint8_t)(h0 << 4 | l0);
+            if (k + 1 < len) out[pos + k + 1] = (uint8_t)cx;
+        }
+        pos += len;
+    }
+    free(m);
+    return outlen;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* M9  rcsenc / rcsdec  (rc_.c:37-58, mb_o0.h:27-41,89-112, turborc_.h:417-452, mbc_s.h:53-55)  */
 static inline uint16_t bit_adapt(uint32_t p, uint32_t bit)
 {
@@ -715,6 +803,7 @@ static size_t enc_one(int codec, const uint8_t *in, size_t n, uint8_t *out, cons
     case ORC_RCAI4: return orc_rccdf4ienc(in, n, out);
     case ORC_ANSA4: return orc_anscdf4enc(in, n, out);
     case ORC_RCSM:  return orc_rccdfsmenc(in, n, out, cdf, cdfnum);
+    case ORC_ANSO1: return orc_anscdf1enc(in, n, out);
     }
     return 0;
 }
@@ -732,6 +821,7 @@ static void dec_one(int codec, const uint8_t *in, size_t n, uint8_t *out, const 
     case ORC_RCAI4: orc_rccdf4idec(in, n, out); break;
     case ORC_ANSA4: orc_anscdf4dec(in, n, out); break;
     case ORC_RCSM:  orc_rccdfsmdec(in, n, out, cdf, cdfnum); break;
+    case ORC_ANSO1: orc_anscdf1dec(in, n, out); break;
     }
 }
 size_t orc_chunked_enc(int codec, const uint8_t *in, size_t n, size_t chunk,

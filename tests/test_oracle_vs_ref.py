@@ -8,7 +8,7 @@ import trc_testlib as T
 from golden.make_golden import gen
 
 pytestmark = pytest.mark.skipif(not T.have_ref(), reason="oracle/_ref/libtrc_ref.so not built")
-CODECS = [T.ANS4S, T.RCS1, T.RCS2, T.RCA, T.ANSA, T.RCB, T.RCAI, T.RCSM]
+CODECS = [T.ANS4S, T.RCS1, T.RCS2, T.RCA, T.ANSA, T.RCB, T.RCAI, T.RCSM, T.ANSO1]
 
 
 @pytest.mark.parametrize("kind", ["zipf", "text", "runs", "uniform", "nibble", "binary"])

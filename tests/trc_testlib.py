@@ -18,14 +18,14 @@ ORACLE_SO = os.path.join(ORACLE_DIR, "libtrc_oracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libtrc_ref.so")
 
 # codec ids == include/trc_hip.h == oracle/trc_oracle.h
-ANS4S, RCS1, RCS2, RCA, ANSA, RCB, RCAI, RCA4, RCAI4, ANSA4, RCSM = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
+ANS4S, RCS1, RCS2, RCA, ANSA, RCB, RCAI, RCA4, RCAI4, ANSA4, RCSM, ANSO1 = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
 CODEC_NAMES = {ANS4S: "anscdf4s", RCS1: "rccdfs", RCS2: "rccdfs2", RCA: "rccdf", ANSA: "anscdf", RCB: "rcs", RCAI: "rccdfi",
-               RCA4: "rccdf4", RCAI4: "rccdf4i", ANSA4: "anscdf4", RCSM: "rccdfsm"}
+               RCA4: "rccdf4", RCAI4: "rccdf4i", ANSA4: "anscdf4", RCSM: "rccdfsm", ANSO1: "anscdf1"}
 NIBBLE_CODECS = (RCA4, RCAI4, ANSA4)          # `turborc -n` coders: input values 0..15
 # adaptive coders: (oracle encoder, oracle decoder, reference encoder, reference decoder); ANS ones take a variant suffix
 _ADAPTIVE = {RCA: ("rccdfenc", "rccdfdec"), ANSA: ("anscdfenc", "anscdfdec"), RCB: ("rcsenc", "rcsdec"),
              RCAI: ("rccdfienc", "rccdfidec"), RCA4: ("rccdf4enc", "rccdf4dec"), RCAI4: ("rccdf4ienc", "rccdf4idec"),
-             ANSA4: ("anscdf4enc", "anscdf4dec")}
+             ANSA4: ("anscdf4enc", "anscdf4dec"), ANSO1: ("anscdf1enc", "anscdf1dec")}
 STATIC_CODECS = (ANS4S, RCS1, RCS2, RCSM)
 
 _u8p = C.POINTER(C.c_uint8)
@@ -248,7 +248,7 @@ def ref():
         for name in ("anscdf4senc", "anscdf4sencs", "anscdf4sencx"):
             f = getattr(lib, name); f.restype = sz; f.argtypes = [_u8p, sz, _u8p, _u16p]
         names = [n for pair in _ADAPTIVE.values() for n in pair]
-        names += [n + v for n in ("anscdfenc", "anscdfdec", "anscdf4enc", "anscdf4dec") for v in ("s", "x")]
+        names += [n + v for n in ("anscdfenc", "anscdfdec", "anscdf4enc", "anscdf4dec", "anscdf1enc", "anscdf1dec") for v in ("s", "x")]
         for name in names:
             f = getattr(lib, name); f.restype = sz; f.argtypes = [_u8p, sz, _u8p]
         _ref = lib
@@ -280,7 +280,7 @@ def ref_enc(codec, data, cdf=None, cdfnum=256, variant=""):
     elif codec == RCSM:
         l = r.rccdfsmenc(pin, n, pout, _p16(cdf), cdfnum)
     elif codec in _ADAPTIVE:
-        l = getattr(r, _ADAPTIVE[codec][0] + (variant if codec in (ANSA, ANSA4) else ""))(pin, n, pout)
+        l = getattr(r, _ADAPTIVE[codec][0] + (variant if codec in (ANSA, ANSA4, ANSO1) else ""))(pin, n, pout)
     else:
         raise ValueError(codec)
     return buf[oo:oo + l].copy()
@@ -303,7 +303,7 @@ def ref_dec(codec, comp, n, cdf=None, cdfnum=256, variant="", search="b"):
     elif codec == RCSM:
         getattr(r, "rccdfsm%sdec" % search)(_p8(src), n, _p8(out), _p16(cdf), cdfnum)
     elif codec in _ADAPTIVE:
-        getattr(r, _ADAPTIVE[codec][1] + (variant if codec in (ANSA, ANSA4) else ""))(_p8(src), n, _p8(out))
+        getattr(r, _ADAPTIVE[codec][1] + (variant if codec in (ANSA, ANSA4, ANSO1) else ""))(_p8(src), n, _p8(out))
     return out[:n].copy()
 
 
