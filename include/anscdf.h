@@ -46,6 +46,17 @@ LIBAPI size_t anscdfdecs(unsigned char *in, size_t outlen, unsigned char *out);
 LIBAPI size_t anscdfencx(unsigned char *in, size_t inlen, unsigned char *out);
 LIBAPI size_t anscdfdecx(unsigned char *in, size_t outlen, unsigned char *out);
 
+/* order-1 adaptive-CDF byte rANS (reference include/anscdf.h:51-52,84-89; anscdf.c:607-645; `turborc -e64`):
+ * anscdfenc with the tables selected by the previous byte */
+LIBAPI size_t anscdf1enc(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdf1dec(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdf1enc0(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdf1dec0(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdf1encs(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdf1decs(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdf1encx(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdf1decx(unsigned char *in, size_t outlen, unsigned char *out);
+
 /* adaptive-CDF nibble rANS on values 0..15, 2 states (reference include/anscdf.h:44-45,70-75; anscdf.c:87-133;
  * `turborc -n -e56/57/58`).  The decoder takes the n%4 tail from the state the encoder used (the reference's
  * decoder does not round-trip such lengths). */

@@ -45,7 +45,9 @@ enum trc_codec {
     TRC_RCA4  = 8,  /* rccdf4enc   / rccdf4dec     adaptive-CDF nibble RC         rccdf.c:250-275  (-n -e46) */
     TRC_RCAI4 = 9,  /* rccdf4ienc  / rccdf4idec    ... on 2 interleaved streams   rccdf.c:277-323  (-n -e47) */
     TRC_ANSA4 = 10, /* anscdf4enc  / anscdf4dec    adaptive-CDF nibble rANS, 2 st. anscdf.c:87-133 (-n -e56) */
-    TRC_RCSM  = 11  /* rccdfsmenc  / rccdfsm*dec   static-CDF RC, 32-bit range, 16-bit I/O rccdf.c:648-694 (-e44) */
+    TRC_RCSM  = 11, /* rccdfsmenc  / rccdfsm*dec   static-CDF RC, 32-bit range, 16-bit I/O rccdf.c:648-694 (-e44) */
+    TRC_ANSO1 = 12  /* anscdf1enc  / anscdf1dec    order-1 adaptive-CDF byte rANS  anscdf.c:607-645 (-e64); 136 KiB of
+                       model per chunk in the workspace: use chunks of 4 KiB and more */
 };
 
 #define TRC_MAGIC        0x31435254u   /* "TRC1" */

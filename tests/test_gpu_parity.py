@@ -251,8 +251,8 @@ def test_c_harness_links_and_roundtrips(torch_cuda):
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-s", "-C", os.path.join(root, "harness")])
     for args in (["--zipf", "3000001"], ["--text", "1000000", "-c", "1024"], ["--uniform", "500000"], ["--nibble", "2000003"]):
-        r = subprocess.run([exe, "-I", "1", "-e", "1,42,43,44,45,46,47,56,57,58,65,79"] + args, capture_output=True, text=True, timeout=300)
+        r = subprocess.run([exe, "-I", "1", "-e", "1,42,43,44,45,46,47,56,57,58,64,65,79"] + args, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         assert "MISMATCH" not in r.stdout and "failed" not in r.stdout, r.stdout
-        assert r.stdout.count(":") >= 13, r.stdout            # every requested id printed its row
+        assert r.stdout.count(":") >= 14, r.stdout            # every requested id printed its row
         assert ("nibble" in r.stdout) == (args[0] == "--nibble")   # values 0..15 route ids 46/47/56-58 to the one-table coders

@@ -300,6 +300,16 @@ static void launch_ansa_dec(const uint8_t *d_payload, const uint32_t *d_clen, si
     hipLaunchKernelGGL((trc_ansa_dec_kernel<NIB>), dim3(w.ngroups), dim3(64), ANSA_MODEL_LDS(NIB), s,
                        d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, d_out);
 }
+// pass 2 alone (the order-1 coder of trc_ans_o1.hip produces the same record stack with its own pass 1)
+void trc_launch_ansa_code(int nibble, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
+{
+    if (nibble)
+        hipLaunchKernelGGL((trc_ansa_code_kernel<true>), dim3(w.ngroups), dim3(64), ANSA_CODE_LDS, s,
+                           (const u8 *)w.scratch2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
+    else
+        hipLaunchKernelGGL((trc_ansa_code_kernel<false>), dim3(w.ngroups), dim3(64), ANSA_CODE_LDS, s,
+                           (const u8 *)w.scratch2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
+}
 void trc_launch_ansa_enc(int nibble, const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
 {
     if (nibble) launch_ansa_enc<true>(d_in, n, chunk, w, d_clen, s); else launch_ansa_enc<false>(d_in, n, chunk, w, d_clen, s);

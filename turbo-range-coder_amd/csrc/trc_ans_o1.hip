@@ -1,0 +1,253 @@
+// trc_ans_o1.hip -- order-1 adaptive-CDF byte rANS (codec TRC_ANSO1; anscdf1enc / anscdf1dec, anscdf.c:607-645,
+// mnenc8x2x / mndec8x2x anscdf_.h:121-126,164-174; `turborc -e64`) -- SURVEY 8f rank 2.
+//
+// The coder of trc_ans_adaptive.hip with the CDF16 tables selected by the previous byte: hi table by ctx, lo table
+// by (ctx, hi nibble); 256 x 17 tables x 32 B = 136 KiB per chunk, context 0 at the start of a chunk, an odd tail
+// pairs with a coded dummy 0.  Payload layout, record format, raw rule and the backward coding pass are those of
+// TRC_ANSA (the second pass IS trc_ansa_code_kernel<false>).
+//
+// 136 KiB per chunk rules LDS out (one chunk per CU would leave 256 lanes busy on the whole chip).  The models live
+// in HBM instead -- 288 GB per GPU hold two million of them -- one contiguous block per chunk, each lane working on
+// its own: a table is two 16-byte global loads, the update runs on registers (K table in LDS, trc_nibmodel.h), two
+// 16-byte stores.  The symbol bounds come out of the register copy by select trees, so a nibble costs one memory
+// round trip.  The encoder knows both tables of a byte in advance (context and hi nibble are input bytes) and
+// requests them together; the decoder learns the lo table only from the hi nibble it has just decoded.  Nothing in
+// LDS but the K table, so occupancy is limited by registers only and the round trips overlap across waves.
+#include "trc_io.h"
+#include "trc_lane_io.h"
+#include "trc_nibmodel.h"
+#include "trc_launch.h"
+
+#define O1_MODEL_BYTES TRC_O1_MODEL_BYTES                    // 139264 per chunk
+
+__global__ __launch_bounds__(256) void trc_o1_fill_kernel(uint4 *__restrict__ model, u64 nvec)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nvec) return;
+    const u32 k = (u32)(i & 1u) * 4u;                       // which half of a 32-byte table: entries 8k' .. (cdf[j] = j << 11)
+    model[i] = make_uint4(trc_pk((2 * k) << 11, (2 * k + 1) << 11), trc_pk((2 * k + 2) << 11, (2 * k + 3) << 11),
+                          trc_pk((2 * k + 4) << 11, (2 * k + 5) << 11), trc_pk((2 * k + 6) << 11, (2 * k + 7) << 11));
+}
+
+__device__ __forceinline__ NibTable o1_load(const u8 *tb)
+{
+    NibTable T;
+    const uint4 a = *(const uint4 *)tb, b = *(const uint4 *)(tb + 16);
+    T.d[0] = a.x; T.d[1] = a.y; T.d[2] = a.z; T.d[3] = a.w; T.d[4] = b.x; T.d[5] = b.y; T.d[6] = b.z; T.d[7] = b.w;
+    return T;
+}
+__device__ __forceinline__ void o1_store(u8 *tb, const NibTable &T)
+{
+    *(uint4 *)tb = make_uint4(T.d[0], T.d[1], T.d[2], T.d[3]);
+    *(uint4 *)(tb + 16) = make_uint4(T.d[4], T.d[5], T.d[6], T.d[7]);
+}
+// entry pair (t[x], t[x+1]) out of the register copy (entry 16 = 32768)
+__device__ __forceinline__ void o1_bounds(const NibTable &T, u32 x, u32 &c0, u32 &c1)
+{
+    const bool b2 = x & 8u, b1 = x & 4u, b0 = x & 2u;
+    const u32 e0 = b2 ? T.d[4] : T.d[0], e1 = b2 ? T.d[5] : T.d[1], e2 = b2 ? T.d[6] : T.d[2],
+              e3 = b2 ? T.d[7] : T.d[3], e4 = b2 ? TRC_PROB_ONE : T.d[4];
+    const u32 f0 = b1 ? e2 : e0, f1 = b1 ? e3 : e1, f2 = b1 ? e4 : e2;
+    const u32 g0 = b0 ? f1 : f0, g1 = b0 ? f2 : f1;
+    const bool odd = x & 1u;
+    c0 = odd ? g0 >> 16 : g0 & 0xffffu;
+    c1 = odd ? g1 & 0xffffu : g0 >> 16;
+}
+__device__ __forceinline__ void o1_adapt(NibTable &T, const u8 *kb, u32 x)
+{
+    const uint4 a = *(const uint4 *)(kb + x * 32u), b = *(const uint4 *)(kb + x * 32u + 16);
+    const u32 K[8] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const trc_s2 v = trc_as_s2(T.d[k]);
+        T.d[k] = trc_as_u32(v + ((trc_as_s2(K[k]) - v) >> (trc_s2)7));
+    }
+}
+__device__ __forceinline__ void o1_init_k(u8 *kb)
+{
+    const u32 lane = trc_lane();
+#pragma unroll
+    for (u32 j = 0; j < 2; j++) {
+        const u32 idx = lane * 2u + j, x = idx >> 3, k = idx & 7u;
+        const u32 e0 = 2u * k, e1 = 2u * k + 1u;
+        ((u32 *)kb)[idx] = trc_pk(10u * e0 + (e0 > x ? 32736u : 0u), 10u * e1 + (e1 > x ? 32736u : 0u));
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------ encode, pass 1 ---
+__global__ __launch_bounds__(64) void trc_o1_model_kernel(
+    const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ model, u8 *__restrict__ recs)
+{
+    __shared__ __attribute__((aligned(16))) u8 kb[TRC_NIBK_BYTES];
+    const u32 lane = threadIdx.x;
+    o1_init_k(kb);
+
+    WaveChunks wc;
+    wc.c0 = blockIdx.x * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
+    wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
+    wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
+    WaveChunks wr = wc;
+    wr.chunk = 8u * chunk; wr.lastlen = 8u * (wc.lastlen + (wc.lastlen & 1u));
+    const bool alive = lane < wc.rows;
+    const u32 len = alive ? wc.len_of(lane) : 0u;
+    const u32 plen = len + (len & 1u);                         // bytes coded, dummy included
+    u8 *mine = model + (u64)(wc.c0 + (alive ? lane : 0u)) * O1_MODEL_BYTES;   // dead lanes alias lane 0's model but never touch it
+
+    QuadIn qin; qin.base = in + (u64)wc.c0 * chunk;
+    QuadOut qout; qout.base = recs + (u64)wc.c0 * wr.chunk;
+    u32 cx = 0;
+
+    const u32 S = chunk / TRC_SEG;
+    qin.issue(wc, 0);
+    for (u32 s = 0; s < S; s++) {
+        qin.commit();
+        if (s + 1 < S) qin.issue(wc, (s + 1) * TRC_SEG);
+        uint4 pc0 = qin.read(0), pc1 = qin.read(1), pc2 = qin.read(2), pc3 = qin.read(3);
+#pragma nounroll
+        for (u32 k = 0; k < 4; k++) {
+            const uint4 v = pc0; pc0 = pc1; pc1 = pc2; pc2 = pc3;
+            const u32 p0 = s * TRC_SEG + k * 16u;
+            if (!__ballot(alive && p0 < len)) continue;
+            const u32 w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+            for (int h = 0; h < 2; h++) {                      // 8 input bytes -> 16 records = one 64-byte record segment
+                u32 r[16];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const u32 pos = p0 + 8u * (u32)h + (u32)i;
+                    u32 x = (w[2 * h + (i >> 2)] >> (8 * (i & 3))) & 255u;
+                    if (pos >= len) x = 0;                     // the coded dummy of an odd tail (and unused padding)
+                    r[2 * i] = r[2 * i + 1] = 0;
+                    if (alive && pos < plen) {
+                        u8 *th = mine + (cx * 17u) * 32u, *tl = th + (1u + (x >> 4)) * 32u;
+                        NibTable H = o1_load(th), L = o1_load(tl);        // both tables of the byte are known up front
+                        u32 a0, a1, b0, b1;
+                        o1_bounds(H, x >> 4, a0, a1); o1_bounds(L, x & 15u, b0, b1);
+                        o1_adapt(H, kb, x >> 4); o1_adapt(L, kb, x & 15u);
+                        o1_store(th, H); o1_store(tl, L);
+                        r[2 * i] = (a0 << TRC_PROB_BITS) | (a1 - a0);
+                        r[2 * i + 1] = (b0 << TRC_PROB_BITS) | (b1 - b0);
+                        cx = x;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) qout.put((u32)j, make_uint4(r[4 * j], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]));
+                qout.flush(wr, (p0 + 8u * (u32)h) * 8u);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------- decode ---
+__global__ __launch_bounds__(64) void trc_o1_dec_kernel(
+    const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
+    u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ model, u8 *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) u8 kb[TRC_NIBK_BYTES];
+    const u32 lane = threadIdx.x;
+    o1_init_k(kb);
+
+    WaveChunks wc;
+    wc.c0 = blockIdx.x * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
+    wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
+    wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
+    const bool alive = lane < wc.rows;
+    const u32 c = wc.c0 + lane;
+    const u32 len = alive ? wc.len_of(lane) : 0u;
+    const u32 cl = alive ? clen[c] : 0u;
+    const u32 ex = trc_wave_incl_scan(cl) - cl;
+    const u64 off = trc_group_base(goff, gsum, wc.c0 >> 6) + ex;
+    const bool coded = alive && cl != len;
+    u8 *mine = model + (u64)(wc.c0 + (alive ? lane : 0u)) * O1_MODEL_BYTES;
+
+    u32 st[4] = { TRC_ANS_LOW, TRC_ANS_LOW, TRC_ANS_LOW, TRC_ANS_LOW };
+    if (coded) for (u32 k = 0; k < 4; k++) st[k] = trc_ld32_a2(payload + off + 4u * k);   // decoder st[i] = encoder st[3-i] (mnfill)
+    LaneIn<2> si; si.prime(payload + off + 16u, coded);
+    u32 cx = 0;
+
+    // cdf16ansdec on a table in HBM (only lanes with act touch memory)
+    auto get_nibble = [&](u32 &s, u8 *tb) -> u32 {
+        const u32 slot = s & (TRC_PROB_ONE - 1);
+        NibTable T = o1_load(tb);
+        u32 c0, c1;
+        const u32 x = trc_nib_find(T, slot, c0, c1);
+        s = __umul24(c1 - c0, s >> TRC_PROB_BITS) + slot - c0;
+        o1_adapt(T, kb, x); o1_store(tb, T);
+        return x;
+    };
+    auto renorm = [&](u32 &s, bool act) {
+        const u32 w = si.peek16();
+        const bool rn = act && s < TRC_ANS_LOW;
+        s = rn ? (s << 16) | w : s;
+        si.skip_if(rn);
+    };
+
+    QuadOut qout; qout.base = out + (u64)wc.c0 * chunk;
+    u8 *dst = out + (u64)c * chunk;
+    const u32 S = chunk / TRC_SEG;
+    for (u32 s = 0; s < S; s++) {
+        uint4 pc0 = make_uint4(0, 0, 0, 0), pc1 = pc0, pc2 = pc0, pc3 = pc0;
+#pragma nounroll
+        for (u32 k = 0; k < 4; k++) {
+            const u32 p0 = s * TRC_SEG + k * 16u;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (__ballot(coded && p0 < len)) {
+#pragma nounroll
+                for (u32 d = 0; d < 4; d++) {
+                    const u32 q0 = p0 + d * 4u;
+                    u32 w = 0;
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {              // mndec8x2x: two bytes, then four renorms in order st0..st3
+                        const bool act = coded && q0 + 2u * (u32)j < len;     // the second byte of an odd tail is the dummy
+                        if (act) {
+                            u8 *th = mine + (cx * 17u) * 32u;
+                            const u32 h0 = get_nibble(st[0], th), l0 = get_nibble(st[1], th + (1u + h0) * 32u);
+                            cx = h0 << 4 | l0;
+                            th = mine + (cx * 17u) * 32u;
+                            const u32 h1 = get_nibble(st[2], th), l1 = get_nibble(st[3], th + (1u + h1) * 32u);
+                            w |= (cx | (h1 << 4 | l1) << 8) << (16 * j);
+                            cx = h1 << 4 | l1;
+                        }
+                        renorm(st[0], act); renorm(st[1], act); renorm(st[2], act); renorm(st[3], act);
+                    }
+                    v.x = v.y; v.y = v.z; v.z = v.w; v.w = w;
+                }
+                if (coded && p0 < len && p0 + 16u > len) {      // ragged end of the last chunk: byte stores
+                    const u32 ww[4] = { v.x, v.y, v.z, v.w };
+                    for (u32 pos = p0; pos < len; pos++) dst[pos] = (u8)(ww[(pos - p0) >> 2] >> (8 * ((pos - p0) & 3u)));
+                }
+            }
+            pc0 = pc1; pc1 = pc2; pc2 = pc3; pc3 = v;
+        }
+        qout.put(0, pc0); qout.put(1, pc1); qout.put(2, pc2); qout.put(3, pc3);
+        qout.flush(wc, s * TRC_SEG);
+    }
+    u64 rawmask = __ballot(alive && cl == len && len != 0);
+    while (rawmask) {
+        const int k = __ffsll((long long)rawmask) - 1;
+        rawmask &= rawmask - 1;
+        const u32 olo = (u32)__shfl((int)(u32)off, k, 64), ohi = (u32)__shfl((int)(u32)(off >> 32), k, 64);
+        const u32 l = (u32)__shfl((int)len, k, 64);
+        trc_wave_copy(out + (u64)(wc.c0 + (u32)k) * chunk, payload + (((u64)ohi << 32) | olo), l);
+    }
+}
+
+// ------------------------------------------------------------------------------------- launch ---
+static void o1_fill(const TrcWork &w, hipStream_t s)
+{
+    const u64 nvec = (u64)w.nchunks * (O1_MODEL_BYTES / 16u);
+    hipLaunchKernelGGL(trc_o1_fill_kernel, dim3((u32)((nvec + 255) / 256)), dim3(256), 0, s, (uint4 *)w.model, nvec);
+}
+void trc_launch_anso1_model(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, hipStream_t s)
+{
+    o1_fill(w, s);
+    hipLaunchKernelGGL(trc_o1_model_kernel, dim3(w.ngroups), dim3(64), 0, s, d_in, (u64)n, chunk, w.nchunks, w.model, w.scratch2);
+}
+void trc_launch_anso1_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
+                          const TrcWork &w, uint8_t *d_out, hipStream_t s)
+{
+    o1_fill(w, s);
+    hipLaunchKernelGGL(trc_o1_dec_kernel, dim3(w.ngroups), dim3(64), 0, s,
+                       d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, w.model, d_out);
+}

@@ -63,12 +63,12 @@ extern "C" int trc_set_chunk(uint32_t chunk)
 #define TRC_INKERNEL_SCAN_MAX 8192u
 static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline bool is_static(int codec) { return codec == TRC_ANS4S || codec == TRC_RCS1 || codec == TRC_RCS2 || codec == TRC_RCSM; }
-static inline bool codec_ok(int codec) { return codec >= TRC_ANS4S && codec <= TRC_RCSM; }
+static inline bool codec_ok(int codec) { return codec >= TRC_ANS4S && codec <= TRC_ANSO1; }
 static inline bool two_streams(int codec) { return codec == TRC_RCS2 || codec == TRC_RCAI || codec == TRC_RCAI4; }
 // second scratch array: RCS2 stream 1 (same stride) or ANSA's record stack (8 B per input byte + one segment)
 static inline size_t scratch2_stride(int codec, uint32_t chunk)
 {
-    return two_streams(codec) ? chunk + 128 : codec == TRC_ANSA ? 8 * (size_t)chunk : codec == TRC_ANSA4 ? 4 * (size_t)chunk : 0;
+    return two_streams(codec) ? chunk + 128 : (codec == TRC_ANSA || codec == TRC_ANSO1) ? 8 * (size_t)chunk : codec == TRC_ANSA4 ? 4 * (size_t)chunk : 0;
 }
 
 static uint32_t scratch_stride(int codec, uint32_t chunk)
@@ -83,7 +83,8 @@ extern "C" size_t trc_work_bytes(int codec, size_t n, uint32_t chunk)
     if (!chunk_ok(chunk)) return 0;
     const size_t nchunks = (n + chunk - 1) / chunk, ngroups = (nchunks + 63) / 64;
     return up256(TRC_TAB_BYTES) + up256(4 * ngroups) + up256(8 * (ngroups + 1)) +
-           up256(nchunks * (size_t)scratch_stride(codec, chunk)) + up256(nchunks * scratch2_stride(codec, chunk) + 256) + 4096;
+           up256(nchunks * (size_t)scratch_stride(codec, chunk)) + up256(nchunks * scratch2_stride(codec, chunk) + 256) +
+           (codec == TRC_ANSO1 ? up256(nchunks * (size_t)TRC_O1_MODEL_BYTES) : 0) + 4096;
 }
 
 static int carve(int codec, size_t n, uint32_t chunk, void *d_work, size_t work_bytes, TrcWork &w)
@@ -101,6 +102,7 @@ static int carve(int codec, size_t n, uint32_t chunk, void *d_work, size_t work_
     w.stride = scratch_stride(codec, chunk);
     w.stride2 = (uint32_t)scratch2_stride(codec, chunk);
     w.scratch2 = p + up256(nchunks * (size_t)w.stride);
+    w.model = w.scratch2 + up256(nchunks * scratch2_stride(codec, chunk) + 256);
     w.nchunks = (uint32_t)nchunks; w.ngroups = (uint32_t)ngroups;
     return TRC_OK;
 }
@@ -209,6 +211,8 @@ extern "C" int trc_encode_dev(int codec, const void *d_in, size_t n, uint32_t ch
     case TRC_RCAI4: trc_launch_rca_enc(2, 1, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 2; break;
     case TRC_ANSA:  trc_launch_ansa_enc(0, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 1; break;
     case TRC_ANSA4: trc_launch_ansa_enc(1, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 1; break;
+    case TRC_ANSO1: trc_launch_anso1_model((const uint8_t *)d_in, n, chunk, w, s);
+                    trc_launch_ansa_code(0, n, chunk, w, d_clen, s); from_end = 1; break;
     }
     tm_end(0, tmi, s);
     if (w.goff) trc_launch_scan_groups(w.gsum, w.ngroups, w.goff, d_total, s);
@@ -245,6 +249,7 @@ extern "C" int trc_decode_dev(int codec, const uint32_t *d_clen, const void *d_p
     case TRC_RCAI4: trc_launch_rca_dec(2, 1, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     case TRC_ANSA:  trc_launch_ansa_dec(0, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     case TRC_ANSA4: trc_launch_ansa_dec(1, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
+    case TRC_ANSO1: trc_launch_anso1_dec((const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     }
     tm_end(1, tmi, s);
     HIPCHK(hipGetLastError());
@@ -259,6 +264,7 @@ extern "C" const char *trc_kernel_name(int codec, int decode)
     case TRC_RCB: return decode ? "trc_rcb_dec_kernel" : "trc_rcb_enc_kernel";
     case TRC_RCA: case TRC_RCAI: case TRC_RCA4: case TRC_RCAI4: return decode ? "trc_rca_dec_kernel" : "trc_rca_enc_kernel";
     case TRC_ANSA: case TRC_ANSA4: return decode ? "trc_ansa_dec_kernel" : "trc_ansa_model_kernel";
+    case TRC_ANSO1: return decode ? "trc_o1_dec_kernel" : "trc_o1_model_kernel";
     }
     return "";
 }
@@ -464,6 +470,15 @@ TRC_EXPORT_ANSA4()
 TRC_EXPORT_ANSA4(0)
 TRC_EXPORT_ANSA4(s)
 TRC_EXPORT_ANSA4(x)
+
+// order-1 adaptive-CDF byte rANS (reference anscdf.c:607-645, dispatch :818-819; turborc -e64) -- SURVEY 8f rank 2
+#define TRC_EXPORT_ANSO1(sfx) \
+    size_t anscdf1enc##sfx(unsigned char *in, size_t inlen, unsigned char *out) { return host_encode(TRC_ANSO1, in, inlen, out, nullptr, 0); } \
+    size_t anscdf1dec##sfx(unsigned char *in, size_t outlen, unsigned char *out) { return host_decode(TRC_ANSO1, in, outlen, out, nullptr, 0); }
+TRC_EXPORT_ANSO1()
+TRC_EXPORT_ANSO1(0)
+TRC_EXPORT_ANSO1(s)
+TRC_EXPORT_ANSO1(x)
 
 typedef size_t (*fanscdfenc)(unsigned char *in, size_t inlen, unsigned char *out);
 typedef size_t (*fanscdfdec)(unsigned char *in, size_t inlen, unsigned char *out);

@@ -14,7 +14,9 @@ struct TrcWork {
     uint8_t  *scratch2;  // second region array (RCS2: stream 1)
     uint32_t  stride2;
     uint32_t  nchunks, ngroups;
+    uint8_t  *model;     // ANSO1 only: one 136 KiB order-1 model per chunk
 };
+#define TRC_O1_MODEL_BYTES (256u * 17u * 32u)
 
 // table area layout (bytes from TrcWork::tables)
 #define TRC_TAB_ENC   0          // uint4[256]   encoder symbol table
@@ -64,6 +66,14 @@ void trc_launch_rca_dec(int nstreams, int nibble, const uint8_t *d_payload, cons
 void trc_launch_ansa_enc(int nibble, const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s);
 void trc_launch_ansa_dec(int nibble, const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                          const TrcWork &w, uint8_t *d_out, hipStream_t s);
+
+void trc_launch_ansa_code(int nibble, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s);   // pass 2 alone
+
+// ANSO1: order-1 adaptive-CDF byte rANS (anscdf1enc / anscdf1dec): pass 1 with the models in HBM (w.model), then
+// trc_launch_ansa_code(0, ...); scratch2 holds the same 8 B/byte record stack as ANSA
+void trc_launch_anso1_model(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, hipStream_t s);
+void trc_launch_anso1_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
+                          const TrcWork &w, uint8_t *d_out, hipStream_t s);
 
 // cdfini on device
 void trc_launch_hist(const uint8_t *d_in, size_t n, uint64_t *d_hist, hipStream_t s);
