@@ -1,7 +1,7 @@
 #!/bin/bash
-# rocprofv3 kernel stats for every coder at the bench configuration (chunk 1024) -> gpurun_out/r01_codecs_*.csv
+# rocprofv3 kernel stats + bench line for every secondary coder at the bench chunk -> gpurun_out/r01_codec_*
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
-for cdc in rccdfs rccdfs2 rccdf anscdf rcs; do
+for cdc in ${1:-rccdfs rccdfsm rccdfs2 rccdf rccdfi anscdf anscdf1 rcs rccdf4 rccdf4i anscdf4}; do
   rm -rf gpurun_out/prof_$cdc
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$cdc -o $cdc -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --steps 5 --warmup 1 --codec $cdc > $GRAFT_REPO_ROOT/gpurun_out/prof_$cdc.log 2>&1)
   cp gpurun_out/prof_$cdc/${cdc}_kernel_stats.csv gpurun_out/r01_codec_${cdc}_kernel_stats.csv

@@ -89,113 +89,96 @@ void trc_launch_scan_groups(const uint32_t *gsum, uint32_t ngroups, uint64_t *go
     hipLaunchKernelGGL(trc_scan_groups_kernel, dim3(1), dim3(1024), 0, s, gsum, ngroups, goff, d_total);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Gather: one workgroup (4 waves) per group of 64 chunks moves the group's payload bytes from the
-// per-chunk scratch regions (or from the input, for raw chunks) to payload + base(group).
-// The group's destination range is treated as ONE flat run of dst-aligned 16-byte vectors; every
-// thread finds the source chunk of its vector by binary search over the 64 prefix offsets (LDS), so
-// all loads of the group are independent and in flight together (the first version copied chunk after
-// chunk: ~6 dependent HBM round trips per 650-byte chunk, 55 us for 100 MB).
-// mode 0: payload at the START of the chunk's region; 1: at its END; 2: two-part RCS2 layout (per-chunk path).
-__device__ __forceinline__ const u8 *trc_gather_src(u32 k, u32 l, u32 c, u64 n, u32 chunk, const u8 *in,
-                                                    const u8 *scratch, u32 stride, int mode)
-{
-    const u64 cstart = (u64)c * chunk;
-    const u32 len = (u32)((n - cstart) < chunk ? (n - cstart) : chunk);
-    (void)k;
-    if (l == len) return in + cstart;
-    return mode == 1 ? scratch + (u64)(c + 1) * stride - l : scratch + (u64)c * stride;
-}
-
+// Payload gather: one workgroup per group of 64 chunks moves the group's bytes to payload + base as dst-aligned
+// 16-byte vectors.  A chunk contributes one PIECE (modes 0/1: its scratch region, start- or end-aligned; or the input
+// chunk itself when stored raw) or two (mode 2, the two-stream coders: [4 + len0 bytes at the start of region A]
+// [rest at the start of region B]).  A vector belongs to the piece that holds its FIRST byte and a fixed set of
+// threads walks the vectors of one piece, so nothing is searched: every load address follows from the prefix table
+// in LDS and a thread's loads are independent.  A vector that runs past its piece takes the rest from the next piece
+// (second load, merged by byte mask); if even the next piece ends inside it (tiny pieces) it is assembled byte by
+// byte.  (History, 100 MB / chunk 512: chunk-after-chunk copy 55 us, per-vector binary search 54 us, this walk 49 us;
+// the two-part layout went from a per-chunk wave copy, 152 us, to the same walk.)
+template <int PARTS>
 __global__ __launch_bounds__(256) void trc_gather_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks,
-                                                         const u8 *__restrict__ scratch, u32 stride, int mode,
+                                                         const u8 *__restrict__ scratch, u32 stride, int from_end,
                                                          const u8 *__restrict__ scratch2, u32 stride2,
                                                          const u32 *__restrict__ clen, const u64 *__restrict__ goff,
                                                          const u32 *__restrict__ gsum, u32 ngroups,
                                                          u8 *__restrict__ payload, u64 *__restrict__ total)
 {
-    __shared__ u32 ex_s[65];
-    __shared__ u64 base_s;
+    constexpr u32 NP = 64u * PARTS;                            // pieces per group
+    constexpr u32 TPP = 256u / NP;                             // threads per piece (4 or 2)
+    __shared__ u32 ex_s[NP + 1];                               // exclusive prefix of the piece lengths
+    __shared__ u64 src_s[NP];                                  // where piece p's bytes are
     const u32 g = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
-    const u32 c_l = g * 64 + lane;
-    const u32 l_l = c_l < nchunks ? clen[c_l] : 0u;
-    const u32 inc = trc_wave_incl_scan(l_l);
     const u64 base = trc_group_base(goff, gsum, g);
-    if (wid == 0) { ex_s[lane] = inc - l_l; if (lane == 63) { ex_s[64] = inc; base_s = base; } }
+    if (wid == 0) {
+        const u32 c = g * 64 + lane;
+        const u32 l = c < nchunks ? clen[c] : 0u;
+        const u64 cstart = (u64)c * chunk;
+        const u32 len = c < nchunks ? (u32)((n - cstart) < chunk ? (n - cstart) : chunk) : 0u;
+        const bool raw = l == len;
+        const u32 inc = trc_wave_incl_scan(l);
+        if (PARTS == 1) {
+            ex_s[lane] = inc - l;
+            src_s[lane] = (u64)(uintptr_t)(raw ? in + cstart : from_end ? scratch + (u64)(c + 1) * stride - l : scratch + (u64)c * stride);
+        } else {
+            const u8 *a = scratch + (u64)c * stride;
+            const u32 la = (raw || c >= nchunks) ? l : 4u + *(const u32 *)a;        // raw: the input chunk is piece 0, piece 1 is empty
+            ex_s[2 * lane] = inc - l; ex_s[2 * lane + 1] = inc - l + la;
+            src_s[2 * lane] = (u64)(uintptr_t)(raw ? in + cstart : a);
+            src_s[2 * lane + 1] = (u64)(uintptr_t)(scratch2 + (u64)c * stride2);
+        }
+        if (lane == 63) ex_s[NP] = inc;
+    }
     __syncthreads();
-    const u32 tot = ex_s[64];
+    const u32 tot = ex_s[NP];
     if (total && g == ngroups - 1 && tid == 0) *total = base + tot;
     u8 *dst0 = payload + base;
+    auto src_of = [&](u32 p) -> const u8 * { return (const u8 *)(uintptr_t)src_s[p]; };
 
-    if (mode == 2) {                                          // RCS2: [4 + len0 bytes of region A][stream 1 from region B]
-        const u32 ex_l = inc - l_l;
-        for (u32 k = wid; k < 64; k += 4) {
-            const u32 c = g * 64 + k;
-            if (c >= nchunks) break;
-            const u32 l = __shfl(l_l, k, 64), ex = __shfl(ex_l, k, 64);
-            const u64 cstart = (u64)c * chunk;
-            const u32 len = (u32)((n - cstart) < chunk ? (n - cstart) : chunk);
-            if (l == len) trc_wave_copy(dst0 + ex, in + cstart, l);
-            else {
-                const u8 *a = scratch + (u64)c * stride;
-                const u32 la = 4u + *(const u32 *)a;
-                trc_wave_copy(dst0 + ex, a, la);
-                trc_wave_copy(dst0 + ex + la, scratch2 + (u64)c * stride2, l - la);
-            }
-        }
-        return;
-    }
-    auto src_of = [&](u32 k) -> const u8 * {
-        return trc_gather_src(k, ex_s[k + 1] - ex_s[k], g * 64 + k, n, chunk, in, scratch, stride, mode);
-    };
-    // The group's bytes go out as dst-aligned 16-byte vectors.  Vector v (bytes [head + 16v, +16) of the group) belongs
-    // to the chunk that holds its FIRST byte; four threads walk the vectors of one chunk, so nothing has to be searched:
-    // every load address follows from the prefix table, and a thread's loads are all independent.  A vector that runs
-    // past its chunk's end takes the rest from the next chunk (second load, merged by byte mask); in the rare case that
-    // the next chunk is shorter than that rest (tiny chunks) the vector is assembled byte by byte.
     u32 head = (u32)((16u - ((uintptr_t)dst0 & 15u)) & 15u);
     if (head > tot) head = tot;
     const u32 nvec = (tot - head) >> 4;
     const u32 tail0 = head + (nvec << 4);
     for (u32 b = tid; b < head + (tot - tail0); b += 256) {     // bytes before the first / after the last aligned vector
         const u32 d = b < head ? b : tail0 + (b - head);
-        u32 lo = 0, hi = 64;
+        u32 lo = 0, hi = NP;
         while (lo + 1 < hi) { const u32 mid = (lo + hi) >> 1; if (ex_s[mid] <= d) lo = mid; else hi = mid; }
         dst0[d] = src_of(lo)[d - ex_s[lo]];
     }
     {
-        const u32 k = tid >> 2, sub = tid & 3u;
+        const u32 k = tid / TPP, sub = tid % TPP;
         const u32 e0 = ex_s[k], e1 = ex_s[k + 1];
         // vectors whose first byte lies in [e0, e1): first index = ceil((e0 - head)/16) (0 if e0 <= head), end likewise from e1
         const u32 v_lo = e0 <= head ? 0u : (e0 - head + 15u) >> 4;
         u32 v_hi = e1 <= head ? 0u : (e1 - head + 15u) >> 4;
         if (v_hi > nvec) v_hi = nvec;
         const u8 *sa = src_of(k);
-        const u8 *sb = k + 1 < 64 ? src_of(k + 1) : sa;
-        const u32 e2 = ex_s[k + 2 > 64 ? 64 : k + 2];
-        for (u32 v0 = v_lo + sub; v0 < v_hi; v0 += 16) {        // four vectors per thread per trip
+        const u8 *sb = k + 1 < NP ? src_of(k + 1) : sa;
+        const u32 e2 = ex_s[k + 2 > NP ? NP : k + 2];
+        const u32 vl = v_hi - 1u;                               // only the piece's last vector can straddle its end
+        for (u32 v0 = v_lo + sub; v0 < v_hi; v0 += 4u * TPP) {  // four vectors per thread per trip
             uint4 a[4], b[4];
             u32 d[4];
             bool ok[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const u32 v = v0 + 4u * (u32)j;
+                const u32 v = v0 + TPP * (u32)j;
                 ok[j] = v < v_hi;
                 d[j] = head + ((ok[j] ? v : v0) << 4);
                 a[j] = trc_ld16_a2(sa + (d[j] - e0));
                 b[j] = a[j];
             }
-            // only the chunk's last vector can straddle its end
-            const u32 vl = v_hi - 1u;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const u32 v = v0 + 4u * (u32)j;
+                const u32 v = v0 + TPP * (u32)j;
                 if (ok[j] && v == vl && d[j] + 16u > e1 && d[j] + 16u <= e2) b[j] = trc_ld16_a2(sb - (e1 - d[j]));
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 if (!ok[j]) continue;
-                const u32 sp = e1 - d[j];                       // bytes of this vector inside chunk k (>= 16: all)
+                const u32 sp = e1 - d[j];                       // bytes of this vector inside piece k (>= 16: all)
                 if (sp >= 16u) { *(uint4 *)(dst0 + d[j]) = a[j]; continue; }
                 if (d[j] + 16u <= e2) {
                     const u32 aw[4] = { a[j].x, a[j].y, a[j].z, a[j].w }, bw[4] = { b[j].x, b[j].y, b[j].z, b[j].w };
@@ -207,7 +190,7 @@ __global__ __launch_bounds__(256) void trc_gather_kernel(const u8 *__restrict__ 
                         r[q] = (aw[q] & m) | (bw[q] & ~m);
                     }
                     *(uint4 *)(dst0 + d[j]) = make_uint4(r[0], r[1], r[2], r[3]);
-                } else {                                       // three or more chunks inside 16 bytes: byte by byte
+                } else {                                       // three or more pieces inside 16 bytes: byte by byte
                     u32 kk = k;
                     const u8 *p = sa;
                     for (u32 q = 0; q < 16; q++) {
@@ -222,9 +205,14 @@ __global__ __launch_bounds__(256) void trc_gather_kernel(const u8 *__restrict__ 
 void trc_launch_gather(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, int from_end,
                        const uint32_t *d_clen, uint8_t *d_payload, uint64_t *d_total, hipStream_t s)
 {
-    hipLaunchKernelGGL(trc_gather_kernel, dim3(w.ngroups), dim3(256), 0, s, d_in, (u64)n, chunk, w.nchunks,
-                       w.scratch, w.stride, from_end, w.scratch2, w.stride2, d_clen, w.goff, w.gsum, w.ngroups,
-                       d_payload, w.goff ? (u64 *)nullptr : d_total);
+    if (from_end == 2)
+        hipLaunchKernelGGL(trc_gather_kernel<2>, dim3(w.ngroups), dim3(256), 0, s, d_in, (u64)n, chunk, w.nchunks,
+                           w.scratch, w.stride, 0, w.scratch2, w.stride2, d_clen, w.goff, w.gsum, w.ngroups,
+                           d_payload, w.goff ? (u64 *)nullptr : d_total);
+    else
+        hipLaunchKernelGGL(trc_gather_kernel<1>, dim3(w.ngroups), dim3(256), 0, s, d_in, (u64)n, chunk, w.nchunks,
+                           w.scratch, w.stride, from_end, w.scratch2, w.stride2, d_clen, w.goff, w.gsum, w.ngroups,
+                           d_payload, w.goff ? (u64 *)nullptr : d_total);
 }
 
 // ---------------------------------------------------------------------------------------------
