@@ -1,12 +1,13 @@
 // trc_io.h -- wave-cooperative chunk I/O shared by all coder kernels (gfx950, wave64).
 //
-// One LANE codes one CHUNK, but no lane ever talks to HBM on its own: PMC runs of the first
-// version showed ~5 TA cycles per scattered 16-byte lane access and every access becoming its own
-// L2 request (profiles/r01_notes.md).  All global traffic is therefore moved in 64-BYTE SEGMENTS by
-// QUADS of lanes (4 x 16 B contiguous), through LDS:
+// One LANE codes one CHUNK, but in the fast (static) coders no lane talks to HBM on its own: PMC runs of the
+// first version showed ~5 TA cycles per scattered 16-byte lane access and every access becoming its own
+// L2 request (profiles/r01_notes.md).  Their traffic is therefore moved in 64-BYTE SEGMENTS by QUADS of lanes
+// (4 x 16 B contiguous).  (The model-bound coders stream through per-lane register windows: trc_lane_io.h.)
 //
-//   TileIn     uniform-rate input  (chunk bytes at encode):  64 rows x 64 B tile, loaded ahead
-//   TileOut    uniform-rate output (chunk bytes at decode):  64 rows x 64 B tile
+//   TileIn     uniform-rate input through a 64 rows x 64 B LDS tile, loaded ahead (record stack of the adaptive rANS)
+//   QuadIn/QuadOut  uniform-rate chunk bytes in/out: the same 64-byte segments, transposed inside quads of lanes in
+//              registers instead of through an LDS tile
 //   StreamOut  variable-rate output (coded bytes at encode): 128-B ring per lane; lanes whose ring
 //              holds a full segment are ranked (ballot + mbcnt) and 16 of them are drained per
 //              round, each by one quad
@@ -84,26 +85,8 @@ struct TileIn {
     __device__ __forceinline__ uint4 read(u32 k) const { return *(const uint4 *)(tile + trc_lane() * TRC_TILE_STRIDE + (k << 4)); }
 };
 
-// ----------------------------------------------------------------------------------- TileOut ---
-struct TileOut {
-    u8 *tile;
-    u8 *base;            // global address of chunk c0 in the output
-    __device__ __forceinline__ void put(u32 k, uint4 v) { *(uint4 *)(tile + trc_lane() * TRC_TILE_STRIDE + (k << 4)) = v; }
-    // store the tile as the 64-byte segment at offset segoff of every chunk (whole 16-B pieces only)
-    __device__ __forceinline__ void flush(const WaveChunks &w, u32 segoff)
-    {
-        const u32 lane = trc_lane(), part = (lane & 3u) << 4;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const u32 row = (u32)j * 16u + (lane >> 2);
-            if (row < w.rows && segoff + part + 16u <= w.len_of(row))
-                *(uint4 *)(base + (size_t)row * w.chunk + segoff + part) = *(const uint4 *)(tile + row * TRC_TILE_STRIDE + part);
-        }
-    }
-};
-
 // ----------------------------------------------------------------------------------- QuadOut ---
-// TileOut without the LDS tile: every lane keeps its chunk's 64 output bytes in 4 x uint4 registers and
+// Uniform-rate output without an LDS tile: every lane keeps its chunk's 64 output bytes in 4 x uint4 registers and
 // the 4 lanes of a quad transpose their 4x4 blocks in registers (two DPP butterfly stages, quad_perm
 // xor-1 then xor-2, ~1 VALU per byte), after which lane i of quad q holds piece i of the chunks
 // 4q..4q+3 and every store instruction again writes whole 64-byte segments.  Frees 5 KiB of LDS per
