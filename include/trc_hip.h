@@ -101,6 +101,14 @@ int trc_hist_dev(const void *d_in, size_t n, uint64_t *d_hist, void *stream);
 int trc_cdf_from_hist_dev(const uint64_t *d_hist, size_t n_total, uint16_t *d_cdf, unsigned cdfnum,
                           int32_t *d_status, void *stream);
 
+/* Static coders derive their symbol tables (44 KiB at the start of the workspace) from the CDF at every
+ * trc_encode_dev / trc_decode_dev call.  A caller that codes many buffers against one CDF -- the reference harness
+ * builds its CDF once, untimed, before the timed calls (turborc.c:429-433) -- can build them once with
+ * trc_tables_dev and pass `codec | TRC_TABLES_READY` afterwards; the tables stay valid until the CDF or the
+ * workspace changes. */
+#define TRC_TABLES_READY 0x100
+int trc_tables_dev(const uint16_t *d_cdf, unsigned cdfnum, void *d_work, size_t work_bytes, void *stream);
+
 /* Encode n bytes at d_in with `codec`.
  *   d_cdf/cdfnum : static coders only (uint16[cdfnum+1], cdf[cdfnum] == 32768), else NULL/0
  *   d_clen       : uint32[nchunks]  <- per-chunk compressed length (== chunk length: raw)
@@ -117,10 +125,10 @@ int trc_decode_dev(int codec, const uint32_t *d_clen, const void *d_payload, siz
                    const uint16_t *d_cdf, unsigned cdfnum,
                    void *d_out, void *d_work, size_t work_bytes, void *stream);
 
-/* Optional per-launch timing of the dominant (coder) kernel with HIP events recorded on the caller's
- * stream immediately around that kernel.  enable(1) resets the counters; read() waits for the
- * recorded events and returns the summed duration and the number of launches measured
- * (at most 1024 per direction between two enable() calls). */
+/* Optional per-launch timing of the dominant (coder) kernel: its launch carries a HIP event pair
+ * (hipExtLaunchKernel start/stop events on the caller's stream), so the duration is the kernel's own.
+ * enable(1) resets the counters; read() waits for the recorded events and returns the summed
+ * duration and the number of launches measured (at most 1024 per direction between two enable() calls). */
 int trc_timing_enable(int on);
 int trc_timing_read(int decode, double *total_ms, int *launches);
 

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(64) void trc_ansa_dec_kernel(
 template <bool NIB>
 static void launch_ansa_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
 {
-    hipLaunchKernelGGL((trc_ansa_model_kernel<NIB>), dim3(w.ngroups), dim3(64), ANSA_MODEL_LDS(NIB), s, d_in, (u64)n, chunk, w.nchunks, w.scratch2);
+    TRC_LAUNCH_TIMED((trc_ansa_model_kernel<NIB>), dim3(w.ngroups), dim3(64), ANSA_MODEL_LDS(NIB), s, d_in, (u64)n, chunk, w.nchunks, w.scratch2);
     hipLaunchKernelGGL((trc_ansa_code_kernel<NIB>), dim3(w.ngroups), dim3(64), ANSA_CODE_LDS, s,
                        (const u8 *)w.scratch2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
 }
@@ -297,7 +297,7 @@ template <bool NIB>
 static void launch_ansa_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                             const TrcWork &w, uint8_t *d_out, hipStream_t s)
 {
-    hipLaunchKernelGGL((trc_ansa_dec_kernel<NIB>), dim3(w.ngroups), dim3(64), ANSA_MODEL_LDS(NIB), s,
+    TRC_LAUNCH_TIMED((trc_ansa_dec_kernel<NIB>), dim3(w.ngroups), dim3(64), ANSA_MODEL_LDS(NIB), s,
                        d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, d_out);
 }
 // pass 2 alone (the order-1 coder of trc_ans_o1.hip produces the same record stack with its own pass 1)

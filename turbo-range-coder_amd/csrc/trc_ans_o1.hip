@@ -242,12 +242,12 @@ static void o1_fill(const TrcWork &w, hipStream_t s)
 void trc_launch_anso1_model(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, hipStream_t s)
 {
     o1_fill(w, s);
-    hipLaunchKernelGGL(trc_o1_model_kernel, dim3(w.ngroups), dim3(64), 0, s, d_in, (u64)n, chunk, w.nchunks, w.model, w.scratch2);
+    TRC_LAUNCH_TIMED(trc_o1_model_kernel, dim3(w.ngroups), dim3(64), 0, s, d_in, (u64)n, chunk, w.nchunks, w.model, w.scratch2);
 }
 void trc_launch_anso1_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                           const TrcWork &w, uint8_t *d_out, hipStream_t s)
 {
     o1_fill(w, s);
-    hipLaunchKernelGGL(trc_o1_dec_kernel, dim3(w.ngroups), dim3(64), 0, s,
+    TRC_LAUNCH_TIMED(trc_o1_dec_kernel, dim3(w.ngroups), dim3(64), 0, s,
                        d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, w.model, d_out);
 }

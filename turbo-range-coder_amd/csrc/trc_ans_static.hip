@@ -212,11 +212,11 @@ void trc_launch_ans4s_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const T
     const u32 nwaves = w.ngroups;
     if (nwaves >= 2048) {        // 4 waves share one 4 KiB symbol table: 37 KiB per workgroup -> 16 waves per CU
         const size_t sm = 4096 + 4 * ENC_WAVE_LDS;
-        hipLaunchKernelGGL(trc_ans4s_enc_kernel<256>, dim3((nwaves + 3) / 4), dim3(256), sm, s,
+        TRC_LAUNCH_TIMED(trc_ans4s_enc_kernel<256>, dim3((nwaves + 3) / 4), dim3(256), sm, s,
                            d_in, (u64)n, chunk, w.nchunks, etab, w.scratch, w.stride, d_clen, w.gsum);
     } else {                     // few waves: one per workgroup so they spread over all CUs (12.4 KiB -> 12 per CU)
         const size_t sm = 4096 + ENC_WAVE_LDS;
-        hipLaunchKernelGGL(trc_ans4s_enc_kernel<64>, dim3(nwaves), dim3(64), sm, s,
+        TRC_LAUNCH_TIMED(trc_ans4s_enc_kernel<64>, dim3(nwaves), dim3(64), sm, s,
                            d_in, (u64)n, chunk, w.nchunks, etab, w.scratch, w.stride, d_clen, w.gsum);
     }
 }
@@ -239,6 +239,6 @@ void trc_launch_ans4s_dec(const uint8_t *d_payload, const uint32_t *d_clen, size
     wpb = wpb < 1u ? 1u : wpb > 12u ? 12u : wpb;
     if (const char *e = getenv("TRC_DEC_WPB")) { const u32 v = (u32)atoi(e); if (v >= 1 && v <= 12) wpb = v; }   // tuning aid
     const size_t sm = 32768 + 2048 + wpb * DEC_WAVE_LDS;
-    hipLaunchKernelGGL(trc_ans4s_dec_kernel, dim3((nwaves + wpb - 1) / wpb), dim3(64 * wpb), sm, s,
+    TRC_LAUNCH_TIMED(trc_ans4s_dec_kernel, dim3((nwaves + wpb - 1) / wpb), dim3(64 * wpb), sm, s,
                        d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, lut, dtab, d_out);
 }

@@ -124,7 +124,8 @@ extern "C" int trc_timing_enable(int on)
     g_tm.on = on != 0; g_tm.cnt[0] = g_tm.cnt[1] = 0;
     return TRC_OK;
 }
-static inline int tm_begin(int dec, hipStream_t s)
+thread_local hipEvent_t trc_tm_start = nullptr, trc_tm_stop = nullptr;      // armed pair, consumed by TRC_LAUNCH_TIMED (trc_launch.h)
+static inline int tm_begin(int dec)
 {
     if (!g_tm.on || g_tm.cnt[dec] >= TRC_TM_MAX) return -1;
     const int i = g_tm.cnt[dec];
@@ -132,14 +133,13 @@ static inline int tm_begin(int dec, hipStream_t s)
         if (hipEventCreate(&g_tm.ev[dec][i][0]) != hipSuccess || hipEventCreate(&g_tm.ev[dec][i][1]) != hipSuccess) return -1;
         g_tm.made[dec][i] = true;
     }
-    (void)hipEventRecord(g_tm.ev[dec][i][0], s);
+    trc_tm_start = g_tm.ev[dec][i][0]; trc_tm_stop = g_tm.ev[dec][i][1];
     return i;
 }
-static inline void tm_end(int dec, int i, hipStream_t s)
+static inline void tm_end(int dec, int i)
 {
-    if (i < 0) return;
-    (void)hipEventRecord(g_tm.ev[dec][i][1], s);
-    g_tm.cnt[dec] = i + 1;
+    trc_tm_start = trc_tm_stop = nullptr;
+    if (i >= 0) g_tm.cnt[dec] = i + 1;
 }
 extern "C" int trc_timing_read(int decode, double *total_ms, int *launches)
 {
@@ -183,11 +183,22 @@ extern "C" int trc_cdf_from_hist_dev(const uint64_t *d_hist, size_t n_total, uin
     return TRC_OK;
 }
 
+extern "C" int trc_tables_dev(const uint16_t *d_cdf, unsigned cdfnum, void *d_work, size_t work_bytes, void *stream)
+{
+    if (!d_cdf || cdfnum < 1 || cdfnum > 256) return fail(TRC_E_CDF, "tables: need a CDF with 1..256 symbols");
+    if (!d_work || work_bytes < up256(TRC_TAB_BYTES) || (((uintptr_t)d_work) & 255)) return fail(TRC_E_WORK, "tables: workspace too small or misaligned");
+    trc_launch_static_prep(d_cdf, cdfnum, (uint8_t *)d_work, (hipStream_t)stream);   // the table area opens the workspace (carve)
+    HIPCHK(hipGetLastError());
+    return TRC_OK;
+}
+
 extern "C" int trc_encode_dev(int codec, const void *d_in, size_t n, uint32_t chunk,
                               const uint16_t *d_cdf, unsigned cdfnum,
                               uint32_t *d_clen, void *d_payload, uint64_t *d_total,
                               void *d_work, size_t work_bytes, void *stream)
 {
+    const bool tables_ready = codec & TRC_TABLES_READY;
+    codec &= ~TRC_TABLES_READY;
     int rc = check_common(codec, n, chunk, d_cdf, cdfnum);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
@@ -196,9 +207,9 @@ extern "C" int trc_encode_dev(int codec, const void *d_in, size_t n, uint32_t ch
     if (n == 0) { HIPCHK(hipMemsetAsync(d_total, 0, 8, s)); return TRC_OK; }
     TrcWork w;
     if ((rc = carve(codec, n, chunk, d_work, work_bytes, w))) return rc;
-    if (is_static(codec)) trc_launch_static_prep(d_cdf, cdfnum, w.tables, s);
+    if (is_static(codec) && !tables_ready) trc_launch_static_prep(d_cdf, cdfnum, w.tables, s);
     int from_end = 0;
-    const int tmi = tm_begin(0, s);
+    const int tmi = tm_begin(0);
     switch (codec) {
     case TRC_ANS4S: trc_launch_ans4s_enc((const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 1; break;
     case TRC_RCS1:  trc_launch_rcs_enc(1, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 0; break;
@@ -214,7 +225,7 @@ extern "C" int trc_encode_dev(int codec, const void *d_in, size_t n, uint32_t ch
     case TRC_ANSO1: trc_launch_anso1_model((const uint8_t *)d_in, n, chunk, w, s);
                     trc_launch_ansa_code(0, n, chunk, w, d_clen, s); from_end = 1; break;
     }
-    tm_end(0, tmi, s);
+    tm_end(0, tmi);
     if (w.goff) trc_launch_scan_groups(w.gsum, w.ngroups, w.goff, d_total, s);
     trc_launch_gather((const uint8_t *)d_in, n, chunk, w, from_end, d_clen, (uint8_t *)d_payload, d_total, s);
     HIPCHK(hipGetLastError());
@@ -225,6 +236,8 @@ extern "C" int trc_decode_dev(int codec, const uint32_t *d_clen, const void *d_p
                               const uint16_t *d_cdf, unsigned cdfnum,
                               void *d_out, void *d_work, size_t work_bytes, void *stream)
 {
+    const bool tables_ready = codec & TRC_TABLES_READY;
+    codec &= ~TRC_TABLES_READY;
     int rc = check_common(codec, n, chunk, d_cdf, cdfnum);
     if (rc) return rc;
     if (n == 0) return TRC_OK;
@@ -233,10 +246,10 @@ extern "C" int trc_decode_dev(int codec, const uint32_t *d_clen, const void *d_p
     hipStream_t s = (hipStream_t)stream;
     TrcWork w;
     if ((rc = carve(codec, n, chunk, d_work, work_bytes, w))) return rc;
-    if (is_static(codec)) trc_launch_static_prep(d_cdf, cdfnum, w.tables, s);
+    if (is_static(codec) && !tables_ready) trc_launch_static_prep(d_cdf, cdfnum, w.tables, s);
     trc_launch_group_sums(d_clen, w.nchunks, w.gsum, s);
     if (w.goff) trc_launch_scan_groups(w.gsum, w.ngroups, w.goff, nullptr, s);
-    const int tmi = tm_begin(1, s);
+    const int tmi = tm_begin(1);
     switch (codec) {
     case TRC_ANS4S: trc_launch_ans4s_dec((const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     case TRC_RCS1:  trc_launch_rcs_dec(1, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
@@ -251,7 +264,7 @@ extern "C" int trc_decode_dev(int codec, const uint32_t *d_clen, const void *d_p
     case TRC_ANSA4: trc_launch_ansa_dec(1, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     case TRC_ANSO1: trc_launch_anso1_dec((const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     }
-    tm_end(1, tmi, s);
+    tm_end(1, tmi);
     HIPCHK(hipGetLastError());
     return TRC_OK;
 }

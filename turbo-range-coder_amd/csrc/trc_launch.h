@@ -1,8 +1,20 @@
 // trc_launch.h -- host-side launch entry points of the kernel translation units (internal).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stddef.h>
 #include <stdint.h>
+
+// Optional timing of the dominant (coder) kernel of a call: when the API layer has armed an event pair, the launch
+// of that kernel carries the pair itself (hipExtLaunchKernelGGL: timestamps of the dispatch, no extra barrier packets
+// in the queue -- separate hipEventRecord calls around the launch cost ~6 us of queue time each), else it is a plain
+// launch.  `kern` goes in parentheses when it is a template instance.
+extern thread_local hipEvent_t trc_tm_start, trc_tm_stop;
+#define TRC_LAUNCH_TIMED(kern, grid, block, lds, stream, ...)                                                      \
+    do {                                                                                                         \
+        if (trc_tm_start) hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)(lds), stream, trc_tm_start, trc_tm_stop, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                                    \
+    } while (0)
 
 // Workspace carve-up shared by encode and decode (all offsets 256-byte aligned).
 struct TrcWork {

@@ -245,14 +245,14 @@ __global__ __launch_bounds__(64) void trc_rca_dec_kernel(
 template <int NS, bool NIB>
 static void launch_rca_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
 {
-    hipLaunchKernelGGL((trc_rca_enc_kernel<NS, NIB>), dim3(w.ngroups), dim3(64), RCA_WAVE_LDS(NIB), s,
+    TRC_LAUNCH_TIMED((trc_rca_enc_kernel<NS, NIB>), dim3(w.ngroups), dim3(64), RCA_WAVE_LDS(NIB), s,
                        d_in, (u64)n, chunk, w.nchunks, w.scratch, w.stride, w.scratch2, w.stride2, d_clen, w.gsum);
 }
 template <int NS, bool NIB>
 static void launch_rca_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                            const TrcWork &w, uint8_t *d_out, hipStream_t s)
 {
-    hipLaunchKernelGGL((trc_rca_dec_kernel<NS, NIB>), dim3(w.ngroups), dim3(64), RCA_WAVE_LDS(NIB), s,
+    TRC_LAUNCH_TIMED((trc_rca_dec_kernel<NS, NIB>), dim3(w.ngroups), dim3(64), RCA_WAVE_LDS(NIB), s,
                        d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, d_out);
 }
 void trc_launch_rca_enc(int nstreams, int nibble, const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)

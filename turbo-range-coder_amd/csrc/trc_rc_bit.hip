@@ -215,7 +215,7 @@ void trc_launch_rcb_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const Trc
 {
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void *)trc_rcb_enc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RCB_WAVE_LDS); attr = true; }
-    hipLaunchKernelGGL(trc_rcb_enc_kernel, dim3(w.ngroups), dim3(64), RCB_WAVE_LDS, s,
+    TRC_LAUNCH_TIMED(trc_rcb_enc_kernel, dim3(w.ngroups), dim3(64), RCB_WAVE_LDS, s,
                        d_in, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
 }
 void trc_launch_rcb_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
@@ -223,6 +223,6 @@ void trc_launch_rcb_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t
 {
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void *)trc_rcb_dec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RCB_WAVE_LDS); attr = true; }
-    hipLaunchKernelGGL(trc_rcb_dec_kernel, dim3(w.ngroups), dim3(64), RCB_WAVE_LDS, s,
+    TRC_LAUNCH_TIMED(trc_rcb_dec_kernel, dim3(w.ngroups), dim3(64), RCB_WAVE_LDS, s,
                        d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, d_out);
 }

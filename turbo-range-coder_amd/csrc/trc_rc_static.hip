@@ -210,13 +210,13 @@ void trc_launch_rcs_enc(int nstreams, const uint8_t *d_in, size_t n, uint32_t ch
 {
     const u32 *tab = (const u32 *)(w.tables + TRC_TAB_DEC);
     if (nstreams == 1)
-        hipLaunchKernelGGL((trc_rcs_enc_kernel<1, 0>), dim3(w.ngroups), dim3(64), 1024 + RCS_WAVE_LDS(1), s,
+        TRC_LAUNCH_TIMED((trc_rcs_enc_kernel<1, 0>), dim3(w.ngroups), dim3(64), 1024 + RCS_WAVE_LDS(1), s,
                            d_in, (u64)n, chunk, w.nchunks, tab, w.scratch, w.stride, w.scratch, w.stride, d_clen, w.gsum);
     else if (nstreams == 2)
-        hipLaunchKernelGGL((trc_rcs_enc_kernel<2, 0>), dim3(w.ngroups), dim3(64), 1024 + RCS_WAVE_LDS(2), s,
+        TRC_LAUNCH_TIMED((trc_rcs_enc_kernel<2, 0>), dim3(w.ngroups), dim3(64), 1024 + RCS_WAVE_LDS(2), s,
                            d_in, (u64)n, chunk, w.nchunks, tab, w.scratch, w.stride, w.scratch2, w.stride2, d_clen, w.gsum);
     else                                                       // nstreams == -1: one stream, 32-bit range / 16-bit words (RCSM)
-        hipLaunchKernelGGL((trc_rcs_enc_kernel<1, 1>), dim3(w.ngroups), dim3(64), 1024 + RCS_WAVE_LDS(1), s,
+        TRC_LAUNCH_TIMED((trc_rcs_enc_kernel<1, 1>), dim3(w.ngroups), dim3(64), 1024 + RCS_WAVE_LDS(1), s,
                            d_in, (u64)n, chunk, w.nchunks, tab, w.scratch, w.stride, w.scratch, w.stride, d_clen, w.gsum);
 }
 
@@ -230,7 +230,7 @@ static void launch_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t 
     u32 wpb = (w.ngroups + 255u) / 256u;                       // just enough waves per workgroup to give every CU one
     wpb = wpb < 1u ? 1u : wpb > maxw ? maxw : wpb;
     const size_t sm = 32768 + 1024 + wpb * RCS_WAVE_LDS(NS);
-    hipLaunchKernelGGL((trc_rcs_dec_kernel<NS, GEO>), dim3((w.ngroups + wpb - 1) / wpb), dim3(64 * wpb), sm, s,
+    TRC_LAUNCH_TIMED((trc_rcs_dec_kernel<NS, GEO>), dim3((w.ngroups + wpb - 1) / wpb), dim3(64 * wpb), sm, s,
                        d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, w.tables + TRC_TAB_LUT,
                        (const u32 *)(w.tables + TRC_TAB_DEC), d_out);
 }

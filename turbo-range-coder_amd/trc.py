@@ -21,6 +21,7 @@ CODEC_NAMES = {ANS4S: "anscdf4s", RCS1: "rccdfs", RCS2: "rccdfs2", RCA: "rccdf",
                RCA4: "rccdf4", RCAI4: "rccdf4i", ANSA4: "anscdf4", RCSM: "rccdfsm", ANSO1: "anscdf1"}
 NIBBLE_CODECS = (RCA4, RCAI4, ANSA4)                           # `turborc -n` coders: input values 0..15
 STATIC = (ANS4S, RCS1, RCS2, RCSM)
+TABLES_READY = 0x100                                          # include/trc_hip.h
 AVAILABLE = (ANS4S, RCS1, RCS2, RCB, RCA, ANSA, RCAI, RCA4, RCAI4, ANSA4, RCSM, ANSO1)          # codecs with HIP kernels behind them (grows per round)
 PAD = 256
 HDR = 32
@@ -60,6 +61,8 @@ def lib():
         l.trc_cdf_from_hist_dev.restype = C.c_int; l.trc_cdf_from_hist_dev.argtypes = [_vp, _sz, _vp, C.c_uint, _vp, _vp]
         l.trc_encode_dev.restype = C.c_int
         l.trc_encode_dev.argtypes = [C.c_int, _vp, _sz, C.c_uint32, _vp, C.c_uint, _vp, _vp, _vp, _vp, _sz, _vp]
+        l.trc_tables_dev.restype = C.c_int
+        l.trc_tables_dev.argtypes = [_vp, C.c_uint, _vp, _sz, _vp]
         l.trc_decode_dev.restype = C.c_int
         l.trc_decode_dev.argtypes = [C.c_int, _vp, _vp, _sz, C.c_uint32, _vp, C.c_uint, _vp, _vp, _sz, _vp]
         l.trc_timing_enable.restype = C.c_int; l.trc_timing_enable.argtypes = [C.c_int]
@@ -115,20 +118,29 @@ class DeviceCoder:
         self.cdf = torch.zeros(264, dtype=torch.int16, device=self.dev)
         self.status = torch.zeros(4, dtype=torch.int32, device=self.dev)
         self.cdfnum = 0
+        self.tables_ready = 0                                  # TABLES_READY once trc_tables_dev ran for the current CDF
 
     def _stream(self):
         return self.torch.cuda.current_stream(self.dev).cuda_stream
+
+    def _tables(self):
+        """derive the coder tables from the current CDF once (enqueued), instead of at every encode/decode"""
+        if self.codec in STATIC:
+            _chk(lib().trc_tables_dev(self.cdf.data_ptr(), self.cdfnum, self.work.data_ptr(), self.work_bytes, self._stream()))
+            self.tables_ready = TABLES_READY
 
     def set_cdf(self, cdf_np, cdfnum):
         t = self.torch.from_numpy(np.ascontiguousarray(cdf_np[:cdfnum + 1]).view(np.int16))
         self.cdf[:cdfnum + 1].copy_(t)
         self.cdfnum = cdfnum
+        self._tables()
 
     def cdfini(self, d_in, n, cdfnum):
         """Device cdfini: histogram of d_in[:n] -> self.cdf (stays on device)."""
         _chk(lib().trc_cdfini_dev(d_in.data_ptr(), n, self.cdf.data_ptr(), cdfnum, self.status.data_ptr(),
                                   self.work.data_ptr(), self._stream()))
         self.cdfnum = cdfnum
+        self._tables()
 
     def hist(self, d_in, n, d_hist):
         """byte histogram of d_in[:n] into d_hist (int64[256] device tensor)"""
@@ -137,12 +149,13 @@ class DeviceCoder:
     def cdf_from_hist(self, d_hist, n_total, cdfnum):
         _chk(lib().trc_cdf_from_hist_dev(d_hist.data_ptr(), n_total, self.cdf.data_ptr(), cdfnum, self.status.data_ptr(), self._stream()))
         self.cdfnum = cdfnum
+        self._tables()
 
     def encode(self, d_in, n=None):
         """Enqueue encode of d_in[:n]; results in self.clen / self.payload / self.total (device)."""
         n = self.n if n is None else n
         st = self.codec in STATIC
-        _chk(lib().trc_encode_dev(self.codec, d_in.data_ptr(), n, self.chunk,
+        _chk(lib().trc_encode_dev(self.codec | self.tables_ready, d_in.data_ptr(), n, self.chunk,
                                   self.cdf.data_ptr() if st else None, self.cdfnum if st else 0,
                                   self.clen.data_ptr(), self.payload.data_ptr(), self.total.data_ptr(),
                                   self.work.data_ptr(), self.work_bytes, self._stream()))
@@ -152,7 +165,7 @@ class DeviceCoder:
         st = self.codec in STATIC
         clen = self.clen if clen is None else clen
         payload = self.payload if payload is None else payload
-        _chk(lib().trc_decode_dev(self.codec, clen.data_ptr(), payload.data_ptr(), n, self.chunk,
+        _chk(lib().trc_decode_dev(self.codec | self.tables_ready, clen.data_ptr(), payload.data_ptr(), n, self.chunk,
                                   self.cdf.data_ptr() if st else None, self.cdfnum if st else 0,
                                   d_out.data_ptr(), self.work.data_ptr(), self.work_bytes, self._stream()))
 
