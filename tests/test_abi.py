@@ -36,13 +36,16 @@ def test_expected_reference_names_present():
     names = set(declared("turborc.h")) | set(declared("anscdf.h"))
     for n in ("cdfini", "anscdf4senc", "anscdf4sdec", "anscdfini", "anscdfenc", "anscdfdec", "anscdfencs", "anscdfdecx",
               "rccdfsenc", "rccdfsbdec", "rccdfsldec", "rccdfsvbdec", "rccdfsvldec", "rccdfs2enc", "rccdfsb2dec", "rccdfsl2dec",
-              "rccdfenc", "rccdfdec", "rcsenc", "rcsdec"):
+              "rccdfenc", "rccdfdec", "rcsenc", "rcsdec",
+              # SURVEY 8f ranks 1-2
+              "rccdfienc", "rccdfidec", "rccdf4enc", "rccdf4dec", "rccdf4ienc", "rccdf4idec", "rccdfsmenc", "rccdfsmbdec", "rccdfsmldec",
+              "anscdf4enc", "anscdf4dec", "anscdf4encs", "anscdf4decx", "anscdf1enc", "anscdf1dec", "anscdf1encs", "anscdf1decx"):
         assert n in names
 
 
 def test_reference_dispatch_globals_exported(lib):
-    """include/anscdf.h declares the reference's dispatch globals (reference include/anscdf.h:32-33)"""
-    for g in ("_anscdfenc", "_anscdfdec"):
+    """include/anscdf.h declares the reference's dispatch globals (reference include/anscdf.h:32-35)"""
+    for g in ("_anscdfenc", "_anscdfdec", "_anscdf4enc", "_anscdf4dec"):
         assert ctypes.c_void_p.in_dll(lib, g).value, g
 
 
@@ -55,3 +58,21 @@ def test_config_calls_work_without_gpu(lib):
     assert lib.trc_set_chunk(100) != 0          # rejected: not a multiple of 64 in range
     lib.trc_last_error.restype = ctypes.c_char_p
     assert b"chunk" in lib.trc_last_error()
+
+
+def test_no_cpu_coding_path(lib):
+    """without a HIP device every coder entry point fails loudly (message + return 0) instead of coding on the CPU"""
+    import numpy as np
+    lib.trc_device_count.restype = ctypes.c_int
+    if lib.trc_device_count() > 0:
+        pytest.skip("a GPU is present")
+    lib.trc_last_error.restype = ctypes.c_char_p
+    d = np.arange(4096, dtype=np.uint8)
+    out = np.zeros(8192, dtype=np.uint8)
+    for name in ("rcsenc", "rccdfenc", "anscdfenc", "rccdf4enc", "anscdf1enc"):
+        f = getattr(lib, name)
+        f.restype = ctypes.c_size_t
+        f.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        assert f(d.ctypes.data, d.size, out.ctypes.data) == 0, name
+        assert b"no HIP device" in lib.trc_last_error(), name
+        assert not out.any(), name                           # nothing was written
