@@ -7,7 +7,9 @@
 A "step" = one encode pass + one decode pass of the hot path over this rank's 100 MB shard, inputs
 already resident in HBM (weak scaling: every rank codes its own 100 MB of independent chunks; for
 N > 1 the per-rank compressed payloads are gathered to rank 0 with RCCL inside the timed region --
-the path's only exchange step -- on a side stream, overlapped with the local decode).  value = bytes all ranks processed / max-over-ranks wall time, with
+the path's only exchange step -- on a side stream, double-buffered, so the transfer of step k overlaps
+the decode of step k and the coding of step k+1; all K transfers complete inside the timed region).
+value = bytes all ranks processed / max-over-ranks wall time, with
 MB = 10^6 (reference include_/time_.h:113,233), i.e. N / (t_enc + t_dec) per SURVEY 8d.
 
 Workload (configs[1]): "text100m" -- 100 000 000 i.i.d. bytes from an English-like order-0 table,
@@ -193,20 +195,34 @@ def main():
         shard.gather_to_root(dist, rank, world, dc.total[:1], dc.clen[:nch], dc.payload, recv_clen, recv_payload)
 
     side = torch.cuda.Stream(device=dev) if use_dist else None
+    # Two result buffers alternate, so that the gather of step k (side stream; one xGMI link per peer, ~C / 100 GB/s --
+    # several times the coding time of a step) runs while step k+1 is coded into the other buffer.  A buffer is
+    # reused only after its own gather has finished (event), gathers follow each other in order on the side stream.
+    bufs = [(dc.clen, dc.payload, dc.total)]
+    if use_dist:
+        bufs.append((torch.zeros_like(dc.clen), torch.zeros_like(dc.payload), torch.zeros_like(dc.total)))
+    gathered = [None, None]
+    stepno = [0]
 
     def step():
-        dc.encode(d_in, n)
-        if use_dist:
-            # the gather of the compressed results rides a side stream, concurrently with the local decode
-            # (the transfer needs one xGMI link per peer for ~C/150 GB/s; the decode is LDS-bound)
-            main = torch.cuda.current_stream(dev)
-            side.wait_stream(main)                             # side stream: starts once the encode is done
-            dc.decode(d_out, n)                                # main stream: local decode, enqueued first ...
-            with torch.cuda.stream(side):
-                exchange()                                     # ... so the host-side size sync in here overlaps it
-            main.wait_stream(side)
-        else:
+        b = stepno[0] % len(bufs)
+        stepno[0] += 1
+        if not use_dist:
+            dc.encode(d_in, n)
             dc.decode(d_out, n)
+            return
+        main = torch.cuda.current_stream(dev)
+        if gathered[b] is not None:
+            main.wait_event(gathered[b])                       # this buffer's previous gather is done
+        dc.clen, dc.payload, dc.total = bufs[b]
+        dc.encode(d_in, n)
+        side.wait_stream(main)                                 # side stream: starts once this encode is done
+        dc.decode(d_out, n)                                    # main stream: local decode, enqueued first ...
+        with torch.cuda.stream(side):
+            exchange()                                         # ... so the host-side size sync in here overlaps it
+            ev = torch.cuda.Event()
+            ev.record(side)
+            gathered[b] = ev
 
     for _ in range(args.warmup):
         step()
