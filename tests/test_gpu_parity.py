@@ -228,6 +228,48 @@ def test_max_rate_bursts(torch_cuda, codec):
     clen2, _ = device_roundtrip(torch_cuda, codec, d, 512, cdf, cdfnum)
 
 
+@pytest.mark.parametrize("codec", trc.AVAILABLE, ids=lambda c: trc.CODEC_NAMES[c])
+def test_corrupt_input_stays_in_bounds(torch_cuda, codec):
+    """The reference decoders are undefined on corrupt input; these must at least stay inside their buffers:
+    directory entries above the chunk length read as raw, two-stream headers are clamped to the chunk's payload,
+    stream fetches stop at the end of the chunk's payload.  Output is unspecified -- only survival is checked,
+    followed by a clean round trip on the same context."""
+    torch = torch_cuda
+    rng = np.random.default_rng(99 + codec)
+    n, chunk = 300007, 1024
+    d = fit(codec, gen("zipf", n, 12))
+    _, cdf, cdfnum = T.orc_cdfini(d)
+    dc = trc.DeviceCoder(codec, n, chunk, "cuda:0")
+    if codec in trc.STATIC:
+        dc.set_cdf(cdf, cdfnum)
+    d_in = to_dev(torch, d)
+    dc.encode(d_in, n)
+    clen, payload = dc.result(n)
+    nch = trc.nchunks(n, chunk)
+    d_out = torch.zeros(n + 512, dtype=torch.uint8, device="cuda:0")
+    for trial in range(6):
+        bad_clen = clen.copy().astype(np.uint32)
+        bad_pay = np.concatenate([payload, np.zeros(dc.payload.numel() - payload.size, np.uint8)])
+        idx = rng.integers(0, nch, 40)
+        kind = trial % 3
+        if kind == 0:
+            bad_clen[idx] = rng.integers(0, 1 << 32, idx.size, dtype=np.uint64).astype(np.uint32)   # absurd directory entries
+        elif kind == 1:
+            bad_clen[idx] = rng.integers(0, 12, idx.size).astype(np.uint32)                          # shorter than any header
+        else:
+            pos = rng.integers(0, payload.size, 3000)
+            bad_pay[pos] = rng.integers(0, 256, pos.size).astype(np.uint8)                           # flipped payload bytes
+            bad_pay[:64] = 0xFF
+        dc.clen[:nch].copy_(torch.from_numpy(bad_clen.view(np.int32)))
+        dc.payload.copy_(torch.from_numpy(bad_pay))
+        dc.decode(d_out, n)
+        torch.cuda.synchronize()
+    dc.encode(d_in, n)                                                   # the context still works
+    dc.decode(d_out, n)
+    torch.cuda.synchronize()
+    assert torch.equal(d_out[:n], d_in[:n])
+
+
 def test_device_layer_rejects_bad_arguments(torch_cuda):
     torch = torch_cuda
     l = trc.lib()

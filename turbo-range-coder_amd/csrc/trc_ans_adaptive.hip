@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64) void trc_ansa_dec_kernel(
     const bool alive = lane < wc.rows;
     const u32 c = wc.c0 + lane;
     const u32 len = alive ? wc.len_of(lane) : 0u;
-    const u32 cl = alive ? clen[c] : 0u;
+    const u32 cl = alive ? trc_min(clen[c], len) : 0u;        // a directory entry above the chunk length (corrupt input) reads as raw
     const u32 ex = trc_wave_incl_scan(cl) - cl;
     const u64 off = trc_group_base(goff, gsum, wc.c0 >> 6) + ex;
     const bool coded = alive && cl != len;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64) void trc_ansa_dec_kernel(
     constexpr u32 NST = NIB ? 2u : 4u;
     u32 st[4] = { TRC_ANS_LOW, TRC_ANS_LOW, TRC_ANS_LOW, TRC_ANS_LOW };
     if (coded) for (u32 k = 0; k < NST; k++) st[k] = trc_ld32_a2(payload + off + 4u * k);   // decoder st[i] = encoder st[NST-1-i] (mnfill)
-    LaneIn<2> si; si.prime(payload + off + 4u * NST, coded);   // words follow the states
+    LaneIn<2> si; si.prime(payload + off + 4u * NST, coded, trc_sub_sat(cl, 4u * NST));   // words follow the states
 
     // cdf16ansdec: search + state update + model update; the renorm comes separately (its order is the word order)
     auto get_nibble = [&](u32 &s, u8 *tb, bool act) -> u32 {

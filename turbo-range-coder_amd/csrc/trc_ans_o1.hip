@@ -155,7 +155,7 @@ __global__ __launch_bounds__(64) void trc_o1_dec_kernel(
     const bool alive = lane < wc.rows;
     const u32 c = wc.c0 + lane;
     const u32 len = alive ? wc.len_of(lane) : 0u;
-    const u32 cl = alive ? clen[c] : 0u;
+    const u32 cl = alive ? trc_min(clen[c], len) : 0u;        // a directory entry above the chunk length (corrupt input) reads as raw
     const u32 ex = trc_wave_incl_scan(cl) - cl;
     const u64 off = trc_group_base(goff, gsum, wc.c0 >> 6) + ex;
     const bool coded = alive && cl != len;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(64) void trc_o1_dec_kernel(
 
     u32 st[4] = { TRC_ANS_LOW, TRC_ANS_LOW, TRC_ANS_LOW, TRC_ANS_LOW };
     if (coded) for (u32 k = 0; k < 4; k++) st[k] = trc_ld32_a2(payload + off + 4u * k);   // decoder st[i] = encoder st[3-i] (mnfill)
-    LaneIn<2> si; si.prime(payload + off + 16u, coded);
+    LaneIn<2> si; si.prime(payload + off + 16u, coded, trc_sub_sat(cl, 16u));
     u32 cx = 0;
 
     // cdf16ansdec on a table in HBM (only lanes with act touch memory)

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(768) void trc_ans4s_dec_kernel(
     const bool alive = lane < wc.rows;
     const u32 c = wc.c0 + lane;
     const u32 len = alive ? wc.len_of(lane) : 0u;
-    const u32 cl = alive ? clen[c] : 0u;
+    const u32 cl = alive ? trc_min(clen[c], len) : 0u;        // a directory entry above the chunk length (corrupt input) reads as raw
     const u32 ex = trc_wave_incl_scan(cl) - cl;
     const u64 off = trc_group_base(goff, gsum, wc.c0 >> 6) + ex;
     const bool coded = alive && cl != len;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(768) void trc_ans4s_dec_kernel(
     QuadOut tout; tout.base = out + (u64)wc.c0 * chunk;        // output leaves through an in-register quad transpose
     StreamIn si;
     si.rings = wbase; si.sel = wbase + TRC_SRING_BYTES;
-    si.gbase = payload; si.soff = off + 8;                    // words follow the two states
+    si.gbase = payload; si.soff = off + 8; si.lim = trc_sub_sat(cl, 8u);   // words follow the two states
     u32 sa = 0, sb = 0;
     if (coded) { sa = trc_ld32_a2(payload + off); sb = trc_ld32_a2(payload + off + 4); }   // sa = enc state 1, sb = enc state 0
     si.prime(coded);

@@ -247,7 +247,7 @@ extern "C" int trc_decode_dev(int codec, const uint32_t *d_clen, const void *d_p
     TrcWork w;
     if ((rc = carve(codec, n, chunk, d_work, work_bytes, w))) return rc;
     if (is_static(codec) && !tables_ready) trc_launch_static_prep(d_cdf, cdfnum, w.tables, s);
-    trc_launch_group_sums(d_clen, w.nchunks, w.gsum, s);
+    trc_launch_group_sums(d_clen, w.nchunks, n, chunk, w.gsum, s);
     if (w.goff) trc_launch_scan_groups(w.gsum, w.ngroups, w.goff, nullptr, s);
     const int tmi = tm_begin(1);
     switch (codec) {

@@ -4,8 +4,8 @@
 //   * one LANE codes one CHUNK (64 chunks per wave); the coder state lives in VGPRs;
 //   * symbol/probability tables live in LDS, staged once per workgroup from a tiny global table
 //     that a prep kernel derived from the caller's CDF;
-//   * variable-rate coder output goes through a per-lane LDS ring (64 B, stride 68 B so that lanes
-//     at the same ring position hit 32 distinct banks) and leaves the CU as whole 16-byte stores.
+//   * chunk bytes and coded streams move as described in trc_io.h (static coders) and trc_lane_io.h
+//     (model-bound coders).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -16,8 +16,6 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 
 #define TRC_WAVE        64
-#define TRC_RING        64u          // bytes of LDS ring per lane (4 x 16 B blocks)
-#define TRC_RING_STRIDE 68u          // bytes between the rings of adjacent lanes (17 dwords: conflict-free)
 #define TRC_PROB_BITS   15u
 #define TRC_PROB_ONE    (1u << TRC_PROB_BITS)
 #define TRC_ANS_LOW     (1u << 15)   // rANS state lower bound (anscdf_.h:41)
@@ -33,6 +31,9 @@ __device__ __forceinline__ uint4 trc_ld16_a2(const u8 *p)
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ u32 trc_ld32_a2(const u8 *p) { return *(const u32_a2 *)p; }
+
+__device__ __forceinline__ u32 trc_min(u32 a, u32 b) { return a < b ? a : b; }
+__device__ __forceinline__ u32 trc_sub_sat(u32 a, u32 b) { return a > b ? a - b : 0u; }
 
 // ---- wave64 helpers -----------------------------------------------------------------------------
 __device__ __forceinline__ u32 trc_lane() { return threadIdx.x & 63u; }

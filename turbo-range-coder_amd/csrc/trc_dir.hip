@@ -46,16 +46,18 @@ void trc_launch_static_prep(const uint16_t *d_cdf, unsigned cdfnum, uint8_t *tab
 
 // ---------------------------------------------------------------------------------------------
 // Directory: gsum[g] = sum of clen over the 64 chunks of group g
-__global__ __launch_bounds__(256) void trc_group_sums_kernel(const u32 *__restrict__ clen, u32 nchunks,
+__global__ __launch_bounds__(256) void trc_group_sums_kernel(const u32 *__restrict__ clen, u32 nchunks, u64 n, u32 chunk,
                                                              u32 *__restrict__ gsum)
 {
     const u32 c = blockIdx.x * 256 + threadIdx.x;
-    const u32 v = trc_wave_sum(c < nchunks ? clen[c] : 0u);
+    const u64 cstart = (u64)c * chunk;
+    const u32 len = c < nchunks ? (u32)((n - cstart) < chunk ? (n - cstart) : chunk) : 0u;
+    const u32 v = trc_wave_sum(c < nchunks ? trc_min(clen[c], len) : 0u);      // same clamp as the decoders
     if (trc_lane() == 0 && (c >> 6) < ((nchunks + 63) >> 6)) gsum[c >> 6] = v;
 }
-void trc_launch_group_sums(const uint32_t *d_clen, uint32_t nchunks, uint32_t *gsum, hipStream_t s)
+void trc_launch_group_sums(const uint32_t *d_clen, uint32_t nchunks, size_t n, uint32_t chunk, uint32_t *gsum, hipStream_t s)
 {
-    hipLaunchKernelGGL(trc_group_sums_kernel, dim3((nchunks + 255) / 256), dim3(256), 0, s, d_clen, nchunks, gsum);
+    hipLaunchKernelGGL(trc_group_sums_kernel, dim3((nchunks + 255) / 256), dim3(256), 0, s, d_clen, nchunks, (u64)n, chunk, gsum);
 }
 
 // exclusive scan of gsum -> goff (u64), single workgroup (ngroups = nchunks/64 is small: 382 for

@@ -254,6 +254,8 @@ struct StreamIn {
     u8 *sel;
     const u8 *gbase;     // payload base (kernel argument: keeps the loads in the global address space)
     u64 soff;            // this lane's stream start, bytes from gbase (2-byte aligned)
+    u32 lim;             // no segment is fetched from beyond this stream offset (a valid stream never consumes from
+                         // there; a corrupt one re-reads its last segment instead of running off the payload buffer)
     u32 rpos;            // bytes consumed
     u32 lbytes;          // bytes committed to the ring
     u32 infl;            // segments requested for this lane and not yet committed (0..2)
@@ -315,10 +317,11 @@ struct StreamIn {
         const u32 j = sel[q];
         const u32 nx = lbytes + TRC_SEG * infl;                 // stream offset of this lane's next segment
         const u32 nx_j = (u32)__shfl((int)nx, (int)j, 64);
+        const u32 src_j = (u32)__shfl((int)trc_min(nx, lim), (int)j, 64);     // where the bytes come from (ring slot: from nx_j)
         const u32 lo = (u32)__shfl((int)(u32)soff, (int)j, 64);
         const u32 hi = (u32)__shfl((int)(u32)(soff >> 32), (int)j, 64);
         if (q < cnt && q < 16u) {
-            const u8 *s = gbase + ((((u64)hi) << 32) | lo) + nx_j + part;
+            const u8 *s = gbase + ((((u64)hi) << 32) | lo) + src_j + part;
             const uint4 v = trc_ld16_a2(s);
             const u32 dd = (j << 8) | ((nx_j & (TRC_SRING - 1)) + part);
             if (par == 0) { hvA = v; hdA = dd; hokA = true; } else { hvB = v; hdB = dd; hokB = true; }

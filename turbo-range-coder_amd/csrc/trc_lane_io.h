@@ -51,11 +51,13 @@ template <int UNIT>
 struct LaneIn {
     const u8 *src;       // this lane's stream (2-byte aligned; the payload buffer carries TRC_PAD bytes of slack)
     u32 rpos;            // bytes consumed
+    u32 lim;             // no window is fetched from beyond this stream offset (a valid stream never gets there; a corrupt
+                         // one re-reads the last window instead of running off the payload buffer)
     uint4 cur, nxt;      // stream bytes [16*(rpos/16), +16) and the 16 after them
 
-    __device__ __forceinline__ void prime(const u8 *s, bool alive)
+    __device__ __forceinline__ void prime(const u8 *s, bool alive, u32 limit)
     {
-        src = s; rpos = 0;
+        src = s; rpos = 0; lim = limit;
         cur = nxt = make_uint4(0, 0, 0, 0);
         if (alive) { cur = trc_ld16_a2(src); nxt = trc_ld16_a2(src + 16); }
     }
@@ -70,6 +72,6 @@ struct LaneIn {
     __device__ __forceinline__ void skip_if(bool take)
     {
         rpos += take ? (u32)UNIT : 0u;
-        if (take && (rpos & 15u) == 0u) { cur = nxt; nxt = trc_ld16_a2(src + rpos + 16u); }
+        if (take && (rpos & 15u) == 0u) { cur = nxt; nxt = trc_ld16_a2(src + trc_min(rpos + 16u, lim)); }
     }
 };

@@ -41,7 +41,7 @@ struct TrcWork {
 void trc_launch_static_prep(const uint16_t *d_cdf, unsigned cdfnum, uint8_t *tables, hipStream_t s);
 
 // directory scan + payload gather
-void trc_launch_group_sums(const uint32_t *d_clen, uint32_t nchunks, uint32_t *gsum, hipStream_t s);
+void trc_launch_group_sums(const uint32_t *d_clen, uint32_t nchunks, size_t n, uint32_t chunk, uint32_t *gsum, hipStream_t s);
 void trc_launch_scan_groups(const uint32_t *gsum, uint32_t ngroups, uint64_t *goff, uint64_t *d_total, hipStream_t s);
 // mode 0: payload at the START of the chunk's scratch region; mode 1: at the END of it;
 // mode 2: [4 + len0 bytes at the start of region A][rest at the start of region B] (RCS2), len0 = u32 at region A.

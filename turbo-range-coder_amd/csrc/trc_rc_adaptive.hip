@@ -157,15 +157,15 @@ __global__ __launch_bounds__(64) void trc_rca_dec_kernel(
     const bool alive = lane < wc.rows;
     const u32 c = wc.c0 + lane;
     const u32 len = alive ? wc.len_of(lane) : 0u;
-    const u32 cl = alive ? clen[c] : 0u;
+    const u32 cl = alive ? trc_min(clen[c], len) : 0u;        // a directory entry above the chunk length (corrupt input) reads as raw
     const u32 ex = trc_wave_incl_scan(cl) - cl;
     const u64 off = trc_group_base(goff, gsum, wc.c0 >> 6) + ex;
     const bool coded = alive && cl != len;
 
     LaneIn<4> s0, s1;
-    const u32 len0 = (NS == 2 && coded) ? trc_ld32_a2(payload + off) : 0u;
-    s0.prime(payload + off + (NS == 2 ? 4u : 0u), coded);
-    s1.prime(payload + off + 4u + len0, NS == 2 && coded);
+    const u32 len0 = (NS == 2 && coded) ? trc_min(trc_ld32_a2(payload + off), trc_sub_sat(cl, 4u)) : 0u;   // a corrupt header cannot point outside the chunk's payload
+    s0.prime(payload + off + (NS == 2 ? 4u : 0u), coded, NS == 2 ? len0 : cl);
+    s1.prime(payload + off + 4u + len0, NS == 2 && coded, trc_sub_sat(cl, 4u + len0));
     RcDec d0, d1;
     { const u32 a = s0.peek32(); s0.skip_if(coded); const u32 b = s0.peek32(); s0.skip_if(coded); d0.start(a, b); }
     { const u32 a = s1.peek32(); s1.skip_if(NS == 2 && coded); const u32 b = s1.peek32(); s1.skip_if(NS == 2 && coded); d1.start(a, b); }

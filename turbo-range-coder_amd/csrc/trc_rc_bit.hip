@@ -133,12 +133,12 @@ __global__ __launch_bounds__(64) void trc_rcb_dec_kernel(
     const bool alive = lane < wc.rows;
     const u32 c = wc.c0 + lane;
     const u32 len = alive ? wc.len_of(lane) : 0u;
-    const u32 cl = alive ? clen[c] : 0u;
+    const u32 cl = alive ? trc_min(clen[c], len) : 0u;        // a directory entry above the chunk length (corrupt input) reads as raw
     const u32 ex = trc_wave_incl_scan(cl) - cl;
     const u64 off = trc_group_base(goff, gsum, wc.c0 >> 6) + ex;
     const bool coded = alive && cl != len;
 
-    LaneIn<4> si; si.prime(payload + off, coded);
+    LaneIn<4> si; si.prime(payload + off, coded, cl);
     RcDec dc;
     { const u32 a = si.peek32(); si.skip_if(coded); const u32 b = si.peek32(); si.skip_if(coded); dc.start(a, b); }
 

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(768) void trc_rcs_dec_kernel(
     const bool alive = lane < wc.rows;
     const u32 c = wc.c0 + lane;
     const u32 len = alive ? wc.len_of(lane) : 0u;
-    const u32 cl = alive ? clen[c] : 0u;
+    const u32 cl = alive ? trc_min(clen[c], len) : 0u;        // a directory entry above the chunk length (corrupt input) reads as raw
     const u32 ex = trc_wave_incl_scan(cl) - cl;
     const u64 off = trc_group_base(goff, gsum, wc.c0 >> 6) + ex;
     const bool coded = alive && cl != len;
@@ -148,11 +148,12 @@ __global__ __launch_bounds__(768) void trc_rcs_dec_kernel(
     QuadOut tout; tout.base = out + (u64)wc.c0 * chunk;
     StreamIn s0, s1;
     s0.rings = wbase; s0.sel = wbase + NS * TRC_SRING_BYTES;
-    s0.gbase = payload; s0.soff = off + (NS == 2 ? 4u : 0u);
+    const u32 len0 = (NS == 2 && coded) ? trc_min(trc_ld32_a2(payload + off), trc_sub_sat(cl, 4u)) : 0u;   // a corrupt header cannot point outside the chunk's payload
+    s0.gbase = payload; s0.soff = off + (NS == 2 ? 4u : 0u); s0.lim = NS == 2 ? len0 : cl;
     s1 = s0;
     if (NS == 2) {
         s1.rings = s0.rings + TRC_SRING_BYTES;
-        s1.soff = off + 4u + (coded ? trc_ld32_a2(payload + off) : 0u);
+        s1.soff = off + 4u + len0; s1.lim = trc_sub_sat(cl, 4u + len0);
     }
     s0.prime(coded);
     if (NS == 2) s1.prime(coded);
