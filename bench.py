@@ -57,6 +57,11 @@ CODEC_INFO = {
 }
 
 
+# chunk size with the best throughput at 100 MB per GPU where it is not 512 (one residency round of the waves:
+# rccdfs2 keeps two rings per lane, 9 waves per CU; the order-1 coder needs room for its context statistics)
+BEST_CHUNK = {"rccdfs2": 896, "anscdf1": 4096}
+
+
 def make_input(n, rank, kind="text"):
     import trc_testlib as T
     path = os.environ.get("ENWIK8")
@@ -133,8 +138,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=100 * 1000 * 1000, help="bytes per GPU")
-    ap.add_argument("--chunk", type=int, default=int(os.environ.get("TRC_BENCH_CHUNK", "512")),
-                    help="chunk bytes (parallel unit); 512 = 12 resident waves per CU at 100 MB; payload ratio cost vs 4096: +1.6 %% (DESIGN.md)")
+    ap.add_argument("--chunk", type=int, default=int(os.environ.get("TRC_BENCH_CHUNK", "0")),
+                    help="chunk bytes (parallel unit); default: the coder's throughput optimum at 100 MB per GPU -- 512 = 12 resident "
+                         "waves per CU for the static rANS; payload ratio cost vs 4096: +1.6 %% (DESIGN.md)")
     ap.add_argument("--codec", default="anscdf4s")
     ap.add_argument("--cpu-sample", type=int, default=32 * 1000 * 1000)
     ap.add_argument("--no-cpu", action="store_true")
@@ -165,7 +171,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     codec = {v: k for k, v in trc.CODEC_NAMES.items()}[args.codec]
-    n, chunk = args.size, args.chunk
+    n, chunk = args.size, args.chunk or BEST_CHUNK.get(args.codec, 512)
     d, wname = make_input(n, rank, CODEC_INFO[args.codec][1])
     d_in = torch.from_numpy(np.concatenate([d, np.zeros(512, np.uint8)])).to(dev)
     dc = trc.DeviceCoder(codec, n, chunk, dev)
