@@ -110,10 +110,12 @@ __global__ __launch_bounds__(256) void trc_gather_kernel(const u8 *__restrict__ 
 {
     constexpr u32 NP = 64u * PARTS;                            // pieces per group
     constexpr u32 TPP = 256u / NP;                             // threads per piece (4 or 2)
+    constexpr u32 VPT = 6;                                     // vectors per thread per trip: 4 x 6 x 16 B covers a 384-byte piece in one trip
     __shared__ u32 ex_s[NP + 1];                               // exclusive prefix of the piece lengths
     __shared__ u64 src_s[NP];                                  // where piece p's bytes are
+    __shared__ u64 base_s;
     const u32 g = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
-    const u64 base = trc_group_base(goff, gsum, g);
+    if (wid == 1 || blockDim.x == 64) { const u64 b = trc_group_base(goff, gsum, g); if (lane == 0) base_s = b; }   // one wave sums, the next builds the table
     if (wid == 0) {
         const u32 c = g * 64 + lane;
         const u32 l = c < nchunks ? clen[c] : 0u;
@@ -134,6 +136,7 @@ __global__ __launch_bounds__(256) void trc_gather_kernel(const u8 *__restrict__ 
         if (lane == 63) ex_s[NP] = inc;
     }
     __syncthreads();
+    const u64 base = base_s;
     const u32 tot = ex_s[NP];
     if (total && g == ngroups - 1 && tid == 0) *total = base + tot;
     u8 *dst0 = payload + base;
@@ -160,12 +163,12 @@ __global__ __launch_bounds__(256) void trc_gather_kernel(const u8 *__restrict__ 
         const u8 *sb = k + 1 < NP ? src_of(k + 1) : sa;
         const u32 e2 = ex_s[k + 2 > NP ? NP : k + 2];
         const u32 vl = v_hi - 1u;                               // only the piece's last vector can straddle its end
-        for (u32 v0 = v_lo + sub; v0 < v_hi; v0 += 4u * TPP) {  // four vectors per thread per trip
-            uint4 a[4], b[4];
-            u32 d[4];
-            bool ok[4];
+        for (u32 v0 = v_lo + sub; v0 < v_hi; v0 += VPT * TPP) {  // VPT vectors per thread per trip
+            uint4 a[VPT], b[VPT];
+            u32 d[VPT];
+            bool ok[VPT];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < (int)VPT; j++) {
                 const u32 v = v0 + TPP * (u32)j;
                 ok[j] = v < v_hi;
                 d[j] = head + ((ok[j] ? v : v0) << 4);
@@ -173,12 +176,12 @@ __global__ __launch_bounds__(256) void trc_gather_kernel(const u8 *__restrict__ 
                 b[j] = a[j];
             }
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < (int)VPT; j++) {
                 const u32 v = v0 + TPP * (u32)j;
                 if (ok[j] && v == vl && d[j] + 16u > e1 && d[j] + 16u <= e2) b[j] = trc_ld16_a2(sb - (e1 - d[j]));
             }
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < (int)VPT; j++) {
                 if (!ok[j]) continue;
                 const u32 sp = e1 - d[j];                       // bytes of this vector inside piece k (>= 16: all)
                 if (sp >= 16u) { *(uint4 *)(dst0 + d[j]) = a[j]; continue; }
