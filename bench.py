@@ -51,6 +51,7 @@ CODEC_INFO = {
     "rccdfi":   ("adaptive-CDF byte range coder, 2 streams (rccdfienc/rccdfidec per chunk), 544 B CDF16 model per lane in LDS", "bwt"),
     "anscdf":   ("adaptive-CDF byte rANS, 4 states (anscdfenc/anscdfdec per chunk), 544 B CDF16 model per lane in LDS", "bwt"),
     "anscdf1":  ("order-1 adaptive-CDF byte rANS, 4 states (anscdf1enc/anscdf1dec per chunk), 136 KiB model per chunk in HBM", "bwt"),
+    "ansb":     ("bitwise order-0 rANS, 4 states (ansbc/ansbd per chunk), 512 B bit model per lane in LDS", "text"),
     "rccdf4":   ("adaptive-CDF nibble range coder (rccdf4enc/rccdf4dec per chunk), one CDF16 table per lane in LDS", "nib"),
     "rccdf4i":  ("adaptive-CDF nibble range coder, 2 streams (rccdf4ienc/rccdf4idec per chunk), one CDF16 table per lane in LDS", "nib"),
     "anscdf4":  ("adaptive-CDF nibble rANS, 2 states (anscdf4enc/anscdf4dec per chunk), one CDF16 table per lane in LDS", "nib"),

@@ -83,6 +83,7 @@ static int bench(unsigned char *in, size_t n, unsigned char *out, unsigned char 
     case 58: name = "ans x (anscdfencx/anscdfdecx)"; e3 = anscdfencx; d3 = anscdfdecx; break;
     case 64: name = "ans o1 (anscdf1enc/anscdf1dec)"; e3 = anscdf1enc; d3 = anscdf1dec; break;
     case 65: name = "ans static (anscdf4senc/anscdf4sdec)"; e4 = anscdf4senc; d4 = anscdf4sdec; break;
+    case 66: name = "ansb bitwise ans (ansbc/ansbd)"; e3 = ansbc; d3 = ansbd; break;
     case 79: name = "memcpy"; break;
     default: return 0;
     }

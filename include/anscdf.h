@@ -57,6 +57,11 @@ LIBAPI size_t anscdf1decs(unsigned char *in, size_t outlen, unsigned char *out);
 LIBAPI size_t anscdf1encx(unsigned char *in, size_t inlen, unsigned char *out);
 LIBAPI size_t anscdf1decx(unsigned char *in, size_t outlen, unsigned char *out);
 
+/* bitwise order-0 rANS, 4 states (reference anscdf.c:672-731; `turborc -e66`).  The reference keeps these two
+ * prototypes commented out in its header (include/anscdf.h:140-141) and calls them from turborc.c:536. */
+LIBAPI size_t ansbc(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t ansbd(unsigned char *in, size_t outlen, unsigned char *out);
+
 /* adaptive-CDF nibble rANS on values 0..15, 2 states (reference include/anscdf.h:44-45,70-75; anscdf.c:87-133;
  * `turborc -n -e56/57/58`).  The decoder takes the n%4 tail from the state the encoder used (the reference's
  * decoder does not round-trip such lengths). */

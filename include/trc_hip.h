@@ -46,14 +46,17 @@ enum trc_codec {
     TRC_RCAI4 = 9,  /* rccdf4ienc  / rccdf4idec    ... on 2 interleaved streams   rccdf.c:277-323  (-n -e47) */
     TRC_ANSA4 = 10, /* anscdf4enc  / anscdf4dec    adaptive-CDF nibble rANS, 2 st. anscdf.c:87-133 (-n -e56) */
     TRC_RCSM  = 11, /* rccdfsmenc  / rccdfsm*dec   static-CDF RC, 32-bit range, 16-bit I/O rccdf.c:648-694 (-e44) */
-    TRC_ANSO1 = 12  /* anscdf1enc  / anscdf1dec    order-1 adaptive-CDF byte rANS  anscdf.c:607-645 (-e64); 136 KiB of
+    TRC_ANSO1 = 12, /* anscdf1enc  / anscdf1dec    order-1 adaptive-CDF byte rANS  anscdf.c:607-645 (-e64); 136 KiB of
                        model per chunk in the workspace: use chunks of 4 KiB and more */
+    TRC_ANSB  = 13  /* ansbc       / ansbd         bitwise order-0 rANS, 4 states  anscdf.c:672-731 (-e66); chunk <= 8192
+                       (one reference block) */
 };
 
 #define TRC_MAGIC        0x31435254u   /* "TRC1" */
 #define TRC_CHUNK_MIN    256u
 #define TRC_CHUNK_MAX    65536u        /* chunk must be a multiple of 64 in [MIN, MAX] */
 #define TRC_CHUNK_DEFAULT 4096u
+#define TRC_ANSB_CHUNK_MAX 8192u       /* TRC_ANSB only: one 8192-byte block of the reference per chunk */
 #define TRC_PAD          256u          /* readable slack the device entry points need after every buffer */
 
 typedef struct trc_container_hdr {

@@ -742,6 +742,75 @@ size_t orc_anscdf1dec(const uint8_t *in, size_t outlen, uint8_t *out)
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* ansbc / ansbd (anscdf.c:672-731; ecbe/ecbd anscdf.c:659-668), `turborc -e66`: bitwise order-0  */
+/* rANS.  255-node bit tree of 15-bit probabilities P(bit=1) (init 2^14; bit 1: p += (2^15-p)>>5, bit 0: p -= p>>5),  */
+/* kept across blocks; blocks of 8192 bytes: forward pass records {bit<<15 | p} per bit, backward pass codes them   */
+/* on 4 states (last bit first; a byte's bits b0..b7 go to states 0,1,2,3,0,1,2,3), states restart at every block.  */
+/* Block payload [st3][st2][st1][st0][u16 words in decode order].  The decoder renormalises BEFORE each bit.        */
+/* Raw rule: the reference tests op+l > out+inlen after each block, so a total of exactly inlen comes back as a     */
+/* coded stream that its caller then treats as raw (it cannot round-trip); here totals >= inlen are stored raw.     */
+#define ANSB_BLOCK 8192u
+size_t orc_ansbc(const uint8_t *in, size_t inlen, uint8_t *out)
+{
+    uint16_t mb[256], *rec = (uint16_t *)malloc(ANSB_BLOCK * 8 * sizeof(uint16_t));
+    uint8_t *tmp = (uint8_t *)malloc(2 * ANSB_BLOCK * 8 + 64), *op = out;
+    if (!rec || !tmp) { free(rec); free(tmp); return 0; }
+    for (int i = 0; i < 256; i++) mb[i] = PROB_ONE >> 1;
+    for (size_t pos = 0; pos < inlen; pos += ANSB_BLOCK) {
+        size_t len = inlen - pos < ANSB_BLOCK ? inlen - pos : ANSB_BLOCK, nr = 0;
+        for (size_t k = 0; k < len; k++) {
+            unsigned cx = 0x100u | in[pos + k];
+            for (int s = 8; s >= 1; s--) {
+                uint16_t *m = &mb[cx >> s];
+                unsigned q = *m, b = (cx >> (s - 1)) & 1;
+                rec[nr++] = (uint16_t)(b << PROB_BITS | q);
+                *m = (uint16_t)(b ? q + ((PROB_ONE - q) >> 5) : q - (q >> 5));
+            }
+        }
+        uint32_t st[4] = { ANS_LO, ANS_LO, ANS_LO, ANS_LO };
+        uint8_t *eend = tmp + 2 * ANSB_BLOCK * 8 + 64, *ep = eend;
+        unsigned si = 0;
+        while (nr) {
+            unsigned r = rec[--nr], b = r >> PROB_BITS, p0 = r & (PROB_ONE - 1);
+            uint32_t ls = b ? p0 : PROB_ONE - p0, s = st[si];
+            if (s >= (ls << 16)) { ep -= 2; st16(ep, (uint16_t)s); s >>= 16; }
+            st[si] = s + (s / ls) * (PROB_ONE - ls) + (b ? 0 : p0);
+            si = (si + 1) & 3;
+        }
+        for (int k = 0; k < 4; k++) { ep -= 4; st32(ep, st[k]); }
+        size_t l = (size_t)(eend - ep);
+        if ((size_t)(op - out) + l >= inlen) { free(rec); free(tmp); memcpy(out, in, inlen); return inlen; }
+        memcpy(op, ep, l); op += l;
+    }
+    free(rec); free(tmp);
+    return (size_t)(op - out);
+}
+size_t orc_ansbd(const uint8_t *in, size_t outlen, uint8_t *out)
+{
+    uint16_t mb[256];
+    const uint8_t *ip = in;
+    for (int i = 0; i < 256; i++) mb[i] = PROB_ONE >> 1;
+    for (size_t pos = 0; pos < outlen; pos += ANSB_BLOCK) {
+        size_t len = outlen - pos < ANSB_BLOCK ? outlen - pos : ANSB_BLOCK;
+        uint32_t st[4];
+        for (int k = 0; k < 4; k++) { st[k] = ld32(ip); ip += 4; }
+        for (size_t k = 0; k < len; k++) {
+            unsigned cx = 1;
+            for (int j = 0; j < 8; j++) {
+                uint32_t *s = &st[j & 3];
+                if (*s < ANS_LO) { *s = *s << 16 | ld16(ip); ip += 2; }
+                uint16_t *m = &mb[cx];
+                uint32_t p0 = *m, r = *s & (PROB_ONE - 1), rcx = (*s >> PROB_BITS) * p0;
+                if (r < p0) { *s = rcx + r; *m = (uint16_t)(p0 + ((PROB_ONE - p0) >> 5)); cx = cx * 2 + 1; }
+                else { *s -= rcx + p0; *m = (uint16_t)(p0 - (p0 >> 5)); cx = cx * 2; }
+            }
+            out[pos + k] = (uint8_t)cx;
+        }
+    }
+    return outlen;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* M9  rcsenc / rcsdec  (rc_.c:37-58, mb_o0.h:27-41,89-112, turborc_.h:417-452, mbc_s.h:53-55)  */
 static inline uint16_t bit_adapt(uint32_t p, uint32_t bit)
 {
@@ -804,6 +873,7 @@ static size_t enc_one(int codec, const uint8_t *in, size_t n, uint8_t *out, cons
     case ORC_ANSA4: return orc_anscdf4enc(in, n, out);
     case ORC_RCSM:  return orc_rccdfsmenc(in, n, out, cdf, cdfnum);
     case ORC_ANSO1: return orc_anscdf1enc(in, n, out);
+    case ORC_ANSB:  return orc_ansbc(in, n, out);
     }
     return 0;
 }
@@ -822,6 +892,7 @@ static void dec_one(int codec, const uint8_t *in, size_t n, uint8_t *out, const 
     case ORC_ANSA4: orc_anscdf4dec(in, n, out); break;
     case ORC_RCSM:  orc_rccdfsmdec(in, n, out, cdf, cdfnum); break;
     case ORC_ANSO1: orc_anscdf1dec(in, n, out); break;
+    case ORC_ANSB:  orc_ansbd(in, n, out); break;
     }
 }
 size_t orc_chunked_enc(int codec, const uint8_t *in, size_t n, size_t chunk,

@@ -45,7 +45,7 @@ SMALL_SIZES = [1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 12, 15, 16, 17, 31, 32, 33, 63, 6
 MID = [(k, n) for k in ("zipf", "runs") for n in (16384, 65536)] + [("text", 65535), ("uniform", 8192), ("const", 5000)]
 LARGE = [("zipf", 10**6, 1), ("text", 10**6, 7), ("runs", 10**6, 3), ("uniform", 10**6, 1),
          ("zipf", (1 << 22) + 1, 5), ("runs", 9 * (1 << 20) + 3, 5)]
-CODECS = [T.ANS4S, T.RCS1, T.RCS2, T.RCA, T.ANSA, T.RCB, T.RCAI, T.RCSM, T.ANSO1]
+CODECS = [T.ANS4S, T.RCS1, T.RCS2, T.RCA, T.ANSA, T.RCB, T.RCAI, T.RCSM, T.ANSO1, T.ANSB]
 # `turborc -n` coders: own fixture file so that vectors.npz stays byte-stable
 NIB_SIZES = [1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 16, 17, 33, 63, 64, 65, 66, 67, 100, 255, 256, 257, 1000, 1001, 1002, 1003,
              4096, 4097, 4098, 4099, 16384, 65535]
@@ -98,7 +98,9 @@ def main():
             o = T.ref_enc(codec, d, cdf, cdfnum)
             for v in ("s", "x") if codec in (T.ANS4S, T.ANSA, T.ANSO1) else ():
                 assert np.array_equal(o, T.ref_enc(codec, d, cdf, cdfnum, v)), "s/x builds differ"
-            rd = T.ref_dec(codec, o, n, cdf, cdfnum)
+            # (ansbc returning exactly n hands back a CODED stream -- its raw test is `>` -- which its caller then treats
+            # as raw: the one input class it cannot round-trip; the oracle stores those raw, see oracle/trc_oracle.c)
+            rd = None if (codec == T.ANSB and o.size == n) else T.ref_dec(codec, o, n, cdf, cdfnum)
             assert rd is None or np.array_equal(rd, d)
             name = T.CODEC_NAMES[codec]
             ent["out"][name] = int(o.size)

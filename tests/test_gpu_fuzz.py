@@ -19,6 +19,8 @@ def test_random_configurations(seed):
     for _it in range(20):
         codec = int(rng.choice(trc.AVAILABLE))
         chunk = int(rng.choice([256, 320, 512, 1024, 1984, 4096, 16384, 65536]))
+        if codec == trc.ANSB:
+            chunk = min(chunk, 8192)                         # one reference block per chunk
         n = int(rng.choice([int(rng.integers(1, 300)), int(rng.integers(300, 70000)), int(rng.integers(70000, 1500000))]))
         kind = str(rng.choice(KINDS))
         d = gen(kind, n, int(rng.integers(1, 1 << 30)))

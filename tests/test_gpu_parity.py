@@ -33,6 +33,11 @@ def fit(codec, d):
     return (d & 15).astype(np.uint8) if codec in trc.NIBBLE_CODECS else d
 
 
+def cap(codec, chunk):
+    """the bitwise rANS takes chunks of at most one reference block (8192 bytes)"""
+    return min(chunk, 8192) if codec == trc.ANSB else chunk
+
+
 def to_dev(torch, a):
     return torch.from_numpy(np.concatenate([a, np.zeros(512, np.uint8)])).to("cuda:0")
 
@@ -64,7 +69,7 @@ def test_device_layer_matches_oracle(torch_cuda, codec, kind):
                      (300007, 4096), (1 << 20, 65536), (999999, 2048)]:
         d = fit(codec, gen(kind, n, 4000 + n))
         _, cdf, cdfnum = T.orc_cdfini(d)
-        device_roundtrip(torch_cuda, codec, d, chunk, cdf, cdfnum)
+        device_roundtrip(torch_cuda, codec, d, cap(codec, chunk), cdf, cdfnum)
 
 
 @pytest.mark.parametrize("codec", trc.AVAILABLE, ids=lambda c: trc.CODEC_NAMES[c])
@@ -89,7 +94,7 @@ def test_golden_vectors_single_chunk(torch_cuda, codec):
     name = trc.CODEC_NAMES[codec]
     done = 0
     for ent in index:
-        if name not in ent["out"] or ent["n"] > 65536:
+        if name not in ent["out"] or ent["n"] > cap(codec, 65536):
             continue
         d = z["in_%d" % ent["case"]]
         n = ent["n"]
@@ -107,6 +112,12 @@ def test_golden_vectors_single_chunk(torch_cuda, codec):
         assert np.array_equal(payload, exp), (ent["kind"], n)
         done += 1
     assert done > (45 if nib else 100)
+
+
+def test_bitwise_rans_rejects_multi_block_chunks(torch_cuda):
+    dc = trc.DeviceCoder(trc.ANSB, 100000, 16384, "cuda:0")
+    with pytest.raises(trc.TrcError):
+        dc.encode(to_dev(torch_cuda, gen("zipf", 100000, 1)), 100000)
 
 
 def test_cdfini_on_device(torch_cuda):
@@ -293,8 +304,8 @@ def test_c_harness_links_and_roundtrips(torch_cuda):
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-s", "-C", os.path.join(root, "harness")])
     for args in (["--zipf", "3000001"], ["--text", "1000000", "-c", "1024"], ["--uniform", "500000"], ["--nibble", "2000003"]):
-        r = subprocess.run([exe, "-I", "1", "-e", "1,42,43,44,45,46,47,56,57,58,64,65,79"] + args, capture_output=True, text=True, timeout=300)
+        r = subprocess.run([exe, "-I", "1", "-e", "1,42,43,44,45,46,47,56,57,58,64,65,66,79"] + args, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         assert "MISMATCH" not in r.stdout and "failed" not in r.stdout, r.stdout
-        assert r.stdout.count(":") >= 14, r.stdout            # every requested id printed its row
+        assert r.stdout.count(":") >= 15, r.stdout            # every requested id printed its row
         assert ("nibble" in r.stdout) == (args[0] == "--nibble")   # values 0..15 route ids 46/47/56-58 to the one-table coders

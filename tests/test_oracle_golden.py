@@ -11,7 +11,7 @@ import trc_testlib as T
 from golden.make_golden import gen
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CODECS = [T.ANS4S, T.RCS1, T.RCS2, T.RCA, T.ANSA, T.RCB, T.RCAI, T.RCSM, T.ANSO1]
+CODECS = [T.ANS4S, T.RCS1, T.RCS2, T.RCA, T.ANSA, T.RCB, T.RCAI, T.RCSM, T.ANSO1, T.ANSB]
 
 
 @pytest.fixture(scope="module")

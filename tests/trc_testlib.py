@@ -18,14 +18,14 @@ ORACLE_SO = os.path.join(ORACLE_DIR, "libtrc_oracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libtrc_ref.so")
 
 # codec ids == include/trc_hip.h == oracle/trc_oracle.h
-ANS4S, RCS1, RCS2, RCA, ANSA, RCB, RCAI, RCA4, RCAI4, ANSA4, RCSM, ANSO1 = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
+ANS4S, RCS1, RCS2, RCA, ANSA, RCB, RCAI, RCA4, RCAI4, ANSA4, RCSM, ANSO1, ANSB = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13
 CODEC_NAMES = {ANS4S: "anscdf4s", RCS1: "rccdfs", RCS2: "rccdfs2", RCA: "rccdf", ANSA: "anscdf", RCB: "rcs", RCAI: "rccdfi",
-               RCA4: "rccdf4", RCAI4: "rccdf4i", ANSA4: "anscdf4", RCSM: "rccdfsm", ANSO1: "anscdf1"}
+               RCA4: "rccdf4", RCAI4: "rccdf4i", ANSA4: "anscdf4", RCSM: "rccdfsm", ANSO1: "anscdf1", ANSB: "ansb"}
 NIBBLE_CODECS = (RCA4, RCAI4, ANSA4)          # `turborc -n` coders: input values 0..15
 # adaptive coders: (oracle encoder, oracle decoder, reference encoder, reference decoder); ANS ones take a variant suffix
 _ADAPTIVE = {RCA: ("rccdfenc", "rccdfdec"), ANSA: ("anscdfenc", "anscdfdec"), RCB: ("rcsenc", "rcsdec"),
              RCAI: ("rccdfienc", "rccdfidec"), RCA4: ("rccdf4enc", "rccdf4dec"), RCAI4: ("rccdf4ienc", "rccdf4idec"),
-             ANSA4: ("anscdf4enc", "anscdf4dec"), ANSO1: ("anscdf1enc", "anscdf1dec")}
+             ANSA4: ("anscdf4enc", "anscdf4dec"), ANSO1: ("anscdf1enc", "anscdf1dec"), ANSB: ("ansbc", "ansbd")}
 STATIC_CODECS = (ANS4S, RCS1, RCS2, RCSM)
 
 _u8p = C.POINTER(C.c_uint8)

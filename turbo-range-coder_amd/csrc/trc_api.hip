@@ -63,12 +63,12 @@ extern "C" int trc_set_chunk(uint32_t chunk)
 #define TRC_INKERNEL_SCAN_MAX 8192u
 static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline bool is_static(int codec) { return codec == TRC_ANS4S || codec == TRC_RCS1 || codec == TRC_RCS2 || codec == TRC_RCSM; }
-static inline bool codec_ok(int codec) { return codec >= TRC_ANS4S && codec <= TRC_ANSO1; }
+static inline bool codec_ok(int codec) { return codec >= TRC_ANS4S && codec <= TRC_ANSB; }
 static inline bool two_streams(int codec) { return codec == TRC_RCS2 || codec == TRC_RCAI || codec == TRC_RCAI4; }
 // second scratch array: RCS2 stream 1 (same stride) or ANSA's record stack (8 B per input byte + one segment)
 static inline size_t scratch2_stride(int codec, uint32_t chunk)
 {
-    return two_streams(codec) ? chunk + 128 : (codec == TRC_ANSA || codec == TRC_ANSO1) ? 8 * (size_t)chunk : codec == TRC_ANSA4 ? 4 * (size_t)chunk : 0;
+    return two_streams(codec) ? chunk + 128 : (codec == TRC_ANSA || codec == TRC_ANSO1) ? 8 * (size_t)chunk : codec == TRC_ANSB ? 16 * (size_t)chunk : codec == TRC_ANSA4 ? 4 * (size_t)chunk : 0;
 }
 
 static uint32_t scratch_stride(int codec, uint32_t chunk)
@@ -112,6 +112,7 @@ static int check_common(int codec, size_t n, uint32_t chunk, const uint16_t *d_c
     if (!codec_ok(codec)) return fail(TRC_E_ARG, "codec %d not available", codec);
     if (!chunk_ok(chunk)) return fail(TRC_E_ARG, "chunk %u: must be a multiple of 64 in [%u,%u]", chunk, TRC_CHUNK_MIN, TRC_CHUNK_MAX);
     if ((n + chunk - 1) / chunk > 0x7fffffffu) return fail(TRC_E_ARG, "too many chunks");
+    if (codec == TRC_ANSB && chunk > TRC_ANSB_CHUNK_MAX) return fail(TRC_E_ARG, "bitwise rANS: chunk %u exceeds one reference block (%u)", chunk, TRC_ANSB_CHUNK_MAX);
     if (is_static(codec) && (!d_cdf || cdfnum < 1 || cdfnum > 256)) return fail(TRC_E_CDF, "static coder needs a CDF with 1..256 symbols");
     return TRC_OK;
 }
@@ -222,6 +223,7 @@ extern "C" int trc_encode_dev(int codec, const void *d_in, size_t n, uint32_t ch
     case TRC_RCAI4: trc_launch_rca_enc(2, 1, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 2; break;
     case TRC_ANSA:  trc_launch_ansa_enc(0, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 1; break;
     case TRC_ANSA4: trc_launch_ansa_enc(1, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 1; break;
+    case TRC_ANSB:  trc_launch_ansb_enc((const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 1; break;
     case TRC_ANSO1: trc_launch_anso1_model((const uint8_t *)d_in, n, chunk, w, s);
                     trc_launch_ansa_code(0, n, chunk, w, d_clen, s); from_end = 1; break;
     }
@@ -263,6 +265,7 @@ extern "C" int trc_decode_dev(int codec, const uint32_t *d_clen, const void *d_p
     case TRC_ANSA:  trc_launch_ansa_dec(0, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     case TRC_ANSA4: trc_launch_ansa_dec(1, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     case TRC_ANSO1: trc_launch_anso1_dec((const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
+    case TRC_ANSB:  trc_launch_ansb_dec((const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     }
     tm_end(1, tmi);
     HIPCHK(hipGetLastError());
@@ -278,6 +281,7 @@ extern "C" const char *trc_kernel_name(int codec, int decode)
     case TRC_RCA: case TRC_RCAI: case TRC_RCA4: case TRC_RCAI4: return decode ? "trc_rca_dec_kernel" : "trc_rca_enc_kernel";
     case TRC_ANSA: case TRC_ANSA4: return decode ? "trc_ansa_dec_kernel" : "trc_ansa_model_kernel";
     case TRC_ANSO1: return decode ? "trc_o1_dec_kernel" : "trc_o1_model_kernel";
+    case TRC_ANSB: return decode ? "trc_ansb_dec_kernel" : "trc_ansb_model_kernel";
     }
     return "";
 }
@@ -337,7 +341,8 @@ static size_t host_encode(int codec, const unsigned char *in, size_t inlen, unsi
     std::lock_guard<std::mutex> lk(c.mu);
     if (inlen == 0) return 0;
     if (ctx_init(c)) return 0;
-    const uint32_t chunk = trc_get_chunk();
+    uint32_t chunk = trc_get_chunk();
+    if (codec == TRC_ANSB && chunk > TRC_ANSB_CHUNK_MAX) chunk = TRC_ANSB_CHUNK_MAX;
     const size_t nchunks = (inlen + chunk - 1) / chunk, dir = 4 * nchunks, hdrsz = sizeof(trc_container_hdr);
     if (is_static(codec)) {
         if (cdfnum <= 0) cdfnum = host_cdfnum(cdf);
@@ -492,6 +497,11 @@ TRC_EXPORT_ANSO1()
 TRC_EXPORT_ANSO1(0)
 TRC_EXPORT_ANSO1(s)
 TRC_EXPORT_ANSO1(x)
+
+// bitwise order-0 rANS (reference anscdf.c:672-731; turborc -e66) -- SURVEY 8f rank 2.  Chunks above one reference
+// block (8192 bytes) are not supported by the kernels: the call uses min(configured chunk, 8192).
+size_t ansbc(unsigned char *in, size_t inlen, unsigned char *out) { return host_encode(TRC_ANSB, in, inlen, out, nullptr, 0); }
+size_t ansbd(unsigned char *in, size_t outlen, unsigned char *out) { return host_decode(TRC_ANSB, in, outlen, out, nullptr, 0); }
 
 typedef size_t (*fanscdfenc)(unsigned char *in, size_t inlen, unsigned char *out);
 typedef size_t (*fanscdfdec)(unsigned char *in, size_t inlen, unsigned char *out);

@@ -87,6 +87,12 @@ void trc_launch_anso1_model(const uint8_t *d_in, size_t n, uint32_t chunk, const
 void trc_launch_anso1_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                           const TrcWork &w, uint8_t *d_out, hipStream_t s);
 
+// ANSB: bitwise order-0 rANS (ansbc / ansbd); chunks of at most 8192 bytes (one reference block); scratch2 holds the
+// 16 B/byte record stack
+void trc_launch_ansb_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s);
+void trc_launch_ansb_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
+                         const TrcWork &w, uint8_t *d_out, hipStream_t s);
+
 // cdfini on device
 void trc_launch_hist(const uint8_t *d_in, size_t n, uint64_t *d_hist, hipStream_t s);
 void trc_launch_cdf_build(const uint64_t *d_hist, size_t n_total, uint16_t *d_cdf, unsigned cdfnum, int32_t *d_status, hipStream_t s);
