@@ -1,5 +1,7 @@
 """GPU (-m gpu): randomized parity sweep -- random codec / length / chunk size / data kind, device layer,
 bit-exact against the oracle per chunk.  Seeds are fixed, so a failure is reproducible."""
+import os
+
 import numpy as np
 import pytest
 
@@ -11,7 +13,8 @@ pytestmark = pytest.mark.gpu
 KINDS = ["zipf", "text", "runs", "uniform", "nibble", "binary", "const"]
 
 
-@pytest.mark.parametrize("seed", range(6))
+# TRC_FUZZ_SEEDS=N widens the sweep for a soak run (default 6 seeds x 20 configurations)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TRC_FUZZ_SEEDS", "6"))))
 def test_random_configurations(seed):
     import torch
     assert torch.cuda.is_available()
