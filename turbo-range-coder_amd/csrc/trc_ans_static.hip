@@ -132,7 +132,7 @@ __device__ __forceinline__ u32 ans_get(u32 &st, const u8 *lut, const uint2 *dtab
     return x;
 }
 
-__global__ __launch_bounds__(768) void trc_ans4s_dec_kernel(
+__global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
     const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
     u64 n, u32 chunk, u32 nchunks,
     const u8 *__restrict__ lut_g, const u32 *__restrict__ dtab_g, u8 *__restrict__ out)
@@ -230,14 +230,14 @@ void trc_launch_ans4s_dec(const uint8_t *d_payload, const uint32_t *d_clen, size
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)trc_ans4s_dec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  32768 + 2048 + 12 * DEC_WAVE_LDS);
+                                  32768 + 2048 + 14 * DEC_WAVE_LDS);
         attr_set = true;
     }
     // the 34 KiB of tables are per workgroup, so waves share a workgroup -- but no more than it takes to
-    // give every one of the 256 CUs a workgroup (1526 waves: 6 per workgroup -> 255 workgroups); up to 12 fit
+    // give every one of the 256 CUs a workgroup (1526 waves: 6 per workgroup -> 255 workgroups); up to 14 fit
     u32 wpb = (nwaves + 255u) / 256u;
-    wpb = wpb < 1u ? 1u : wpb > 12u ? 12u : wpb;
-    if (const char *e = getenv("TRC_DEC_WPB")) { const u32 v = (u32)atoi(e); if (v >= 1 && v <= 12) wpb = v; }   // tuning aid
+    wpb = wpb < 1u ? 1u : wpb > 14u ? 14u : wpb;               // 34 KiB + 14 x 8.3 KiB = 150 KiB of the CU's 160
+    if (const char *e = getenv("TRC_DEC_WPB")) { const u32 v = (u32)atoi(e); if (v >= 1 && v <= 14) wpb = v; }   // tuning aid
     const size_t sm = 32768 + 2048 + wpb * DEC_WAVE_LDS;
     TRC_LAUNCH_TIMED(trc_ans4s_dec_kernel, dim3((nwaves + wpb - 1) / wpb), dim3(64 * wpb), sm, s,
                        d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, lut, dtab, d_out);
