@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64) void trc_rcs_enc_kernel(
 }
 
 template <int NS, int GEO>
-__global__ __launch_bounds__(768) void trc_rcs_dec_kernel(
+__global__ __launch_bounds__(896) void trc_rcs_dec_kernel(
     const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
     u64 n, u32 chunk, u32 nchunks, const u8 *__restrict__ lut_g, const u32 *__restrict__ tab_g, u8 *__restrict__ out)
 {
@@ -225,7 +225,7 @@ template <int NS, int GEO>
 static void launch_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                        const TrcWork &w, uint8_t *d_out, hipStream_t s)
 {
-    const u32 maxw = NS == 1 ? 12u : 7u;                       // 34 KiB tables + waves x (NS rings) must fit 160 KiB
+    const u32 maxw = NS == 1 ? 14u : 7u;                       // 34 KiB tables + waves x (NS rings) must fit 160 KiB
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void *)trc_rcs_dec_kernel<NS, GEO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(32768 + 1024 + maxw * RCS_WAVE_LDS(NS))); attr = true; }
     u32 wpb = (w.ngroups + 255u) / 256u;                       // just enough waves per workgroup to give every CU one
