@@ -811,6 +811,106 @@ size_t orc_ansbd(const uint8_t *in, size_t outlen, uint8_t *out)
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* Turbo-VLC integer coders over the adaptive CDF range coder (rccdf.c:391-632; cdfe7/cdfd7,       */
+/* cdfe6/cdfd6 rccdf_.h:100-123; vlcenc/vlcdec/bitvrput/bitvrget include_/vlcbit.h:24-63; reverse bit I/O             */
+/* rcutil_.h:163-189; zigzag rcutil_.h:142-149): 16- or 32-bit integers, `turborc -e50/52/53`.                        */
+/*   u (vn = 1, "vlc6") / v (vn = 2, "vlc7") / vz (v on the zigzag of the delta to the previous element).             */
+/* An element x >= 2^(vn+1) is split into an exponent symbol and f = bsr(x) - vn mantissa bits:                       */
+/*   expo = ((f+1) << vn) + bits [f, f+vn) of x;  mantissa = low f bits of x.                                         */
+/* The (small) value or the exponent is coded with two CDF16 tables: below T (8 for vn = 2, 12 for vn = 1) one symbol */
+/* with table 0, else symbol ((x-T)>>4)+T with table 0 and (x-T)&15 with table 1.  Mantissas go MSB-first into a bit  */
+/* string that grows DOWN from the end of the output (byte k of the string at out+inlen-1-k), the range coder grows up */
+/* from out+4; raw as soon as the two come within 8 bytes of each other (test after every element, with the bit side  */
+/* at out+inlen-8-floor(bits/8)).  Result [u32 total][range-coder words][bit bytes], OVERFLOW on the total.           */
+/* A trailing partial element is zero-extended here; the reference reads the bytes that follow its input (and its      */
+/* decoder writes a whole element): callers pass multiples of the element size, and that is where parity is pinned.  */
+static inline unsigned bsr32(uint32_t x) { return 31u - (unsigned)__builtin_clz(x); }
+static size_t vlc_enc(const uint8_t *in, size_t inlen, uint8_t *out, unsigned es, unsigned vn, int zz)
+{
+    const unsigned T = vn == 2 ? 8u : 12u;
+    size_t nel = (inlen + es - 1) / es, bits = 0, nbytes;
+    uint8_t *bitbuf = (uint8_t *)calloc(nel * 4 + 16, 1);      /* the bit string, byte k = bits 8k .. 8k+7 */
+    uint8_t *rcbuf = (uint8_t *)malloc(2 * inlen + 64);
+    nibmodel_t m; nib_reset(&m);                               /* tables 0 and 1 = m.hi and m.lo[0] */
+    rce_t e; uint32_t prev = 0;
+    if (!bitbuf || !rcbuf) { free(bitbuf); free(rcbuf); return 0; }
+    rce_start(&e, rcbuf);
+    for (size_t i = 0; i < nel; i++) {
+        uint32_t v = 0, x;
+        memcpy(&v, in + i * es, inlen - i * es < es ? inlen - i * es : es);
+        if (zz) {
+            uint32_t d = v - prev;
+            x = es == 2 ? (uint16_t)(((int16_t)d << 1) ^ ((int16_t)d >> 15)) : (uint32_t)(((int32_t)d << 1) ^ ((int32_t)d >> 31));
+            prev = v;
+        } else x = v;
+        if (x >= (1u << (vn + 1))) {
+            unsigned f = bsr32(x) - vn, expo = ((f + 1) << vn) + ((x >> f) & ((1u << vn) - 1));
+            uint32_t ma = x & ((1u << f) - 1);
+            for (unsigned k = 0; k < f; k++, bits++)           /* MSB first */
+                if ((ma >> (f - 1 - k)) & 1) bitbuf[bits >> 3] |= (uint8_t)(0x80u >> (bits & 7));
+            x = expo;
+        }
+        if (x < T) { rce_sym(&e, m.hi[x], m.hi[x + 1]); nib_adapt(m.hi, x); }
+        else {
+            unsigned y = ((x - T) >> 4) + T, z = (x - T) & 15;
+            rce_sym(&e, m.hi[y], m.hi[y + 1]); nib_adapt(m.hi, y);
+            rce_sym(&e, m.lo[0][z], m.lo[0][z + 1]); nib_adapt(m.lo[0], z);
+        }
+        if ((int64_t)(4 + (e.op - rcbuf)) + 8 >= (int64_t)inlen - 8 - (int64_t)(bits >> 3)) goto raw;
+    }
+    rce_finish(&e);
+    nbytes = (bits + 7) >> 3;
+    {
+        size_t rc = (size_t)(e.op - rcbuf), total = 4 + rc + nbytes;
+        if (rc_overflow(total, inlen)) goto raw;
+        st32(out, (uint32_t)total);
+        memcpy(out + 4, rcbuf, rc);
+        for (size_t k = 0; k < nbytes; k++) out[total - 1 - k] = bitbuf[k];
+        free(bitbuf); free(rcbuf);
+        return total;
+    }
+raw:
+    free(bitbuf); free(rcbuf);
+    memcpy(out, in, inlen);
+    return inlen;
+}
+static size_t vlc_dec(const uint8_t *in, size_t outlen, uint8_t *out, unsigned es, unsigned vn, int zz)
+{
+    const unsigned T = vn == 2 ? 8u : 12u;
+    size_t nel = (outlen + es - 1) / es, bits = 0, total = ld32(in);
+    nibmodel_t m; nib_reset(&m);
+    rcd_t d; rcd_start(&d, in + 4);
+    uint32_t prev = 0;
+    for (size_t i = 0; i < nel; i++) {
+        uint32_t x = rcd_nibble(&d, m.hi), v;
+        if (x >= T) { unsigned z = rcd_nibble(&d, m.lo[0]); x = ((x - T) << 4 | z) + T; }
+        if (x >= (1u << (vn + 1))) {
+            unsigned f = (x >> vn) - 1;
+            uint32_t ma = 0;
+            for (unsigned k = 0; k < f; k++, bits++)
+                ma = ma << 1 | ((in[total - 1 - (bits >> 3)] >> (7 - (bits & 7))) & 1);
+            x = (((1u << vn) + (x & ((1u << vn) - 1))) << f) + ma;
+        }
+        if (zz) {
+            v = es == 2 ? (uint16_t)(prev + (uint16_t)((x >> 1) ^ (0u - (x & 1)))) : prev + ((x >> 1) ^ (0u - (x & 1)));
+            prev = v;
+        } else v = x;
+        size_t nb = outlen - i * es < es ? outlen - i * es : es;   /* a partial last element: only its valid bytes */
+        memcpy(out + i * es, &v, nb);
+    }
+    return outlen;
+}
+#define VLC_PAIR(name, es, vn, zz) \
+    size_t orc_##name##enc##es(const uint8_t *in, size_t inlen, uint8_t *out) { return vlc_enc(in, inlen, out, es / 8, vn, zz); } \
+    size_t orc_##name##dec##es(const uint8_t *in, size_t outlen, uint8_t *out) { return vlc_dec(in, outlen, out, es / 8, vn, zz); }
+VLC_PAIR(rccdfu, 16, 1, 0)
+VLC_PAIR(rccdfu, 32, 1, 0)
+VLC_PAIR(rccdfv, 16, 2, 0)
+VLC_PAIR(rccdfv, 32, 2, 0)
+VLC_PAIR(rccdfvz, 16, 2, 1)
+VLC_PAIR(rccdfvz, 32, 2, 1)
+
+/* ------------------------------------------------------------------------------------------ */
 /* M9  rcsenc / rcsdec  (rc_.c:37-58, mb_o0.h:27-41,89-112, turborc_.h:417-452, mbc_s.h:53-55)  */
 static inline uint16_t bit_adapt(uint32_t p, uint32_t bit)
 {

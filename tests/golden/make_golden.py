@@ -80,6 +80,34 @@ def main_nibble():
     print("wrote", len(index), "nibble cases")
 
 
+def main_vlc():
+    """Turbo-VLC integer coders: 16/32-bit series, sizes that are multiples of the element size"""
+    arrays, index = {}, []
+    ci = 0
+    for kind in ("small", "walk", "mixed", "wide"):
+        for ne in (1, 2, 3, 5, 8, 16, 17, 64, 100, 255, 1000, 4096, 16384):
+            for es in (2, 4):
+                n, seed = ne * es, 5000 + ci
+                d = T.int_bytes(n, es, kind, seed)
+                arrays["in_%d" % ci] = d
+                ent = dict(case=ci, kind=kind, n=n, es=es, seed=seed, out={})
+                for codec in T.VLC_CODECS:
+                    if T.VLC_ELEM[codec] != es:
+                        continue
+                    o = T.ref_enc(codec, d)
+                    if o.size != n:
+                        assert np.array_equal(T.ref_dec(codec, o, n), d)
+                    name = T.CODEC_NAMES[codec]
+                    ent["out"][name] = int(o.size)
+                    if o.size != n:
+                        arrays["out_%d_%s" % (ci, name)] = o
+                index.append(ent)
+                ci += 1
+    arrays["index"] = np.frombuffer(json.dumps(index).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "vlc_vectors.npz"), **arrays)
+    print("wrote", len(index), "vlc cases")
+
+
 def main():
     assert T.have_ref(), "reference build missing: make -C oracle"
     arrays, index = {}, []
@@ -136,6 +164,8 @@ def main():
 
 
 if __name__ == "__main__":
-    if "--nibble-only" not in sys.argv:
+    if "--nibble-only" not in sys.argv and "--vlc-only" not in sys.argv:
         main()
-    main_nibble()
+    if "--vlc-only" not in sys.argv:
+        main_nibble()
+    main_vlc()

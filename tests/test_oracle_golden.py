@@ -101,3 +101,23 @@ def test_nibble_encode_matches_golden_and_roundtrips(nibble_vectors, codec):
         assert np.array_equal(o, exp), (ent["kind"], ent["n"], name)
         seen += 1
     assert seen >= 45
+
+
+# ---------------------------------------------------------------- Turbo-VLC integer coders ---
+@pytest.mark.parametrize("codec", T.VLC_CODECS, ids=lambda c: T.CODEC_NAMES[c])
+def test_vlc_encode_matches_golden_and_roundtrips(codec):
+    z = np.load(os.path.join(GOLD, "vlc_vectors.npz"))
+    index = json.loads(bytes(z["index"]).decode())
+    name, seen = T.CODEC_NAMES[codec], 0
+    for ent in index:
+        if name not in ent["out"]:
+            continue
+        d = z["in_%d" % ent["case"]]
+        assert np.array_equal(T.int_bytes(ent["n"], ent["es"], ent["kind"], ent["seed"]), d)
+        o = T.orc_enc(codec, d)
+        assert o.size == ent["out"][name], (ent["kind"], ent["n"], name)
+        exp = d if o.size == ent["n"] else z["out_%d_%s" % (ent["case"], name)]
+        assert np.array_equal(o, exp), (ent["kind"], ent["n"], name)
+        assert np.array_equal(T.orc_dec(codec, o, ent["n"]), d)
+        seen += 1
+    assert seen == 52

@@ -86,3 +86,22 @@ def test_multiblock_nibble_rans():
     assert np.array_equal(a, T.ref_enc(T.ANSA4, d, variant="x"))
     assert np.array_equal(T.orc_dec(T.ANSA4, a, n), d)
     assert np.array_equal(T.ref_dec(T.ANSA4, a, n, variant="s"), d)
+
+
+@pytest.mark.parametrize("codec", T.VLC_CODECS, ids=lambda c: T.CODEC_NAMES[c])
+def test_vlc_integer_coders_against_reference(codec):
+    """Turbo-VLC coders on 16/32-bit series (sizes = multiples of the element size, where the reference is defined)"""
+    es = T.VLC_ELEM[codec]
+    rng = np.random.default_rng(4242)
+    for kind in ("small", "walk", "mixed", "wide"):
+        for ne in [1, 2, 3, 7, 8, 9, 63, 64, 65, 1023, 1024] + [int(x) for x in rng.integers(1025, 120000, 6)]:
+            n = ne * es
+            d = T.int_bytes(n, es, kind, 100 + ne)
+            a = T.orc_enc(codec, d)
+            assert np.array_equal(a, T.ref_enc(codec, d)), (T.CODEC_NAMES[codec], kind, n)
+            assert np.array_equal(T.orc_dec(codec, a, n), d)
+            if a.size != n:
+                assert np.array_equal(T.ref_dec(codec, a, n), d)
+    for n in (1, 3, 5, 7, 4097):                                 # partial last element: zero-extended, self-consistent
+        d = T.int_bytes(n + 8, es, "small", n)[:n]
+        assert np.array_equal(T.orc_dec(codec, T.orc_enc(codec, d), n), d)

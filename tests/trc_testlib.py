@@ -19,13 +19,20 @@ REF_SO = os.path.join(ORACLE_DIR, "_ref", "libtrc_ref.so")
 
 # codec ids == include/trc_hip.h == oracle/trc_oracle.h
 ANS4S, RCS1, RCS2, RCA, ANSA, RCB, RCAI, RCA4, RCAI4, ANSA4, RCSM, ANSO1, ANSB = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13
+VLCU16, VLCU32, VLCV16, VLCV32, VLCVZ16, VLCVZ32 = 14, 15, 16, 17, 18, 19   # Turbo-VLC integer coders
 CODEC_NAMES = {ANS4S: "anscdf4s", RCS1: "rccdfs", RCS2: "rccdfs2", RCA: "rccdf", ANSA: "anscdf", RCB: "rcs", RCAI: "rccdfi",
-               RCA4: "rccdf4", RCAI4: "rccdf4i", ANSA4: "anscdf4", RCSM: "rccdfsm", ANSO1: "anscdf1", ANSB: "ansb"}
+               RCA4: "rccdf4", RCAI4: "rccdf4i", ANSA4: "anscdf4", RCSM: "rccdfsm", ANSO1: "anscdf1", ANSB: "ansb",
+               VLCU16: "rccdfu16", VLCU32: "rccdfu32", VLCV16: "rccdfv16", VLCV32: "rccdfv32", VLCVZ16: "rccdfvz16", VLCVZ32: "rccdfvz32"}
+VLC_CODECS = (VLCU16, VLCU32, VLCV16, VLCV32, VLCVZ16, VLCVZ32)
+VLC_ELEM = {VLCU16: 2, VLCU32: 4, VLCV16: 2, VLCV32: 4, VLCVZ16: 2, VLCVZ32: 4}   # element bytes
 NIBBLE_CODECS = (RCA4, RCAI4, ANSA4)          # `turborc -n` coders: input values 0..15
 # adaptive coders: (oracle encoder, oracle decoder, reference encoder, reference decoder); ANS ones take a variant suffix
 _ADAPTIVE = {RCA: ("rccdfenc", "rccdfdec"), ANSA: ("anscdfenc", "anscdfdec"), RCB: ("rcsenc", "rcsdec"),
              RCAI: ("rccdfienc", "rccdfidec"), RCA4: ("rccdf4enc", "rccdf4dec"), RCAI4: ("rccdf4ienc", "rccdf4idec"),
-             ANSA4: ("anscdf4enc", "anscdf4dec"), ANSO1: ("anscdf1enc", "anscdf1dec"), ANSB: ("ansbc", "ansbd")}
+             ANSA4: ("anscdf4enc", "anscdf4dec"), ANSO1: ("anscdf1enc", "anscdf1dec"), ANSB: ("ansbc", "ansbd"),
+             VLCU16: ("rccdfuenc16", "rccdfudec16"), VLCU32: ("rccdfuenc32", "rccdfudec32"),
+             VLCV16: ("rccdfvenc16", "rccdfvdec16"), VLCV32: ("rccdfvenc32", "rccdfvdec32"),
+             VLCVZ16: ("rccdfvzenc16", "rccdfvzdec16"), VLCVZ32: ("rccdfvzenc32", "rccdfvzdec32")}
 STATIC_CODECS = (ANS4S, RCS1, RCS2, RCSM)
 
 _u8p = C.POINTER(C.c_uint8)
@@ -101,6 +108,26 @@ def nibble_bytes(n, seed=5, kind="geo"):
         while v.size < n:
             v = np.concatenate([v, v])
     return v[:n].copy()
+
+
+def int_bytes(n, es, kind="walk", seed=9):
+    """16/32-bit integer series as bytes (n a multiple of es) for the Turbo-VLC coders.
+    small: mostly tiny values; walk: slow random walk around mid-range (what the zigzag-delta coders are for);
+    mixed: tiny values with rare large ones; wide: uniform over the whole range (incompressible)."""
+    ne = n // es
+    u = splitmix64(ne, seed)
+    f = (u >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+    top = 1 << (8 * es)
+    if kind == "small":
+        v = np.minimum(np.floor(np.log1p(-f) / np.log(0.8)), 60000).astype(np.uint64)
+    elif kind == "walk":
+        v = (np.cumsum((u % np.uint64(61)).astype(np.int64) - 30) + (top >> 2)).astype(np.uint64)
+    elif kind == "mixed":
+        big = (splitmix64(ne, seed + 1) % np.uint64(top >> 1))
+        v = np.where(f < 0.9, u % np.uint64(20), big).astype(np.uint64)
+    else:
+        v = u % np.uint64(top)
+    return (v % np.uint64(top)).astype(np.uint16 if es == 2 else np.uint32).view(np.uint8).copy()
 
 
 def fnv1a64(b):
