@@ -52,6 +52,12 @@ CODEC_INFO = {
     "anscdf":   ("adaptive-CDF byte rANS, 4 states (anscdfenc/anscdfdec per chunk), 544 B CDF16 model per lane in LDS", "bwt"),
     "anscdf1":  ("order-1 adaptive-CDF byte rANS, 4 states (anscdf1enc/anscdf1dec per chunk), 136 KiB model per chunk in HBM", "bwt"),
     "ansb":     ("bitwise order-0 rANS, 4 states (ansbc/ansbd per chunk), 512 B bit model per lane in LDS", "text"),
+    "rccdfu16": ("Turbo-VLC (6-bit exponent) over the adaptive CDF range coder, 16-bit elements (rccdfuenc16/rccdfudec16 per chunk)", "i16"),
+    "rccdfu32": ("Turbo-VLC (6-bit exponent) over the adaptive CDF range coder, 32-bit elements (rccdfuenc32/rccdfudec32 per chunk)", "i32"),
+    "rccdfv16": ("Turbo-VLC (7-bit exponent) over the adaptive CDF range coder, 16-bit elements (rccdfvenc16/rccdfvdec16 per chunk)", "i16"),
+    "rccdfv32": ("Turbo-VLC (7-bit exponent) over the adaptive CDF range coder, 32-bit elements (rccdfvenc32/rccdfvdec32 per chunk)", "i32"),
+    "rccdfvz16": ("Turbo-VLC on zigzag deltas over the adaptive CDF range coder, 16-bit elements (rccdfvzenc16/rccdfvzdec16 per chunk)", "i16"),
+    "rccdfvz32": ("Turbo-VLC on zigzag deltas over the adaptive CDF range coder, 32-bit elements (rccdfvzenc32/rccdfvzdec32 per chunk)", "i32"),
     "rccdf4":   ("adaptive-CDF nibble range coder (rccdf4enc/rccdf4dec per chunk), one CDF16 table per lane in LDS", "nib"),
     "rccdf4i":  ("adaptive-CDF nibble range coder, 2 streams (rccdf4ienc/rccdf4idec per chunk), one CDF16 table per lane in LDS", "nib"),
     "anscdf4":  ("adaptive-CDF nibble rANS, 2 states (anscdf4enc/anscdf4dec per chunk), one CDF16 table per lane in LDS", "nib"),
@@ -72,6 +78,8 @@ def make_input(n, rank, kind="text"):
         return np.tile(d, reps)[:n].copy(), "enwik8"
     if kind == "bwt":
         return T.runs_bytes(n, 3 + rank), "bwt%dm" % (n // 1000000)
+    if kind in ("i16", "i32"):                               # slow random walk: what the zigzag-delta coders are for
+        return T.int_bytes(n, 2 if kind == "i16" else 4, "walk", 9 + rank), "walk%dm-%s" % (n // 1000000, kind)
     if kind == "nib":
         return T.nibble_bytes(n, 5 + rank, "runs"), "nib%dm" % (n // 1000000)
     return T.text_bytes(n, 7 + rank), "text%dm" % (n // 1000000)

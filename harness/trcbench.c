@@ -8,7 +8,7 @@
  * The timed calls take HOST pointers, so these numbers include PCIe both ways; the
  * device-resident numbers come from bench.py.
  *
- *   trcbench [-e id[,id..]] [-I runs] [-c chunk] (file | --zipf N | --text N | --uniform N | --nibble N)
+ *   trcbench [-e id[,id..]] [-I runs] [-c chunk] (file | --zipf N | --text N | --uniform N | --nibble N | --int16 N | --int32 N)
  * ids: 1 rcs | 42 cdfsb | 43 cdfsv | 45 cdfs2 | 46 cdf | 47 cdfi | 56 ans | 57 ans(s) | 58 ans(x) | 65 ans4s | 79 memcpy
  */
 #include <math.h>
@@ -22,6 +22,7 @@
 int trc_set_chunk(unsigned chunk);           /* from include/trc_hip.h */
 const char *trc_last_error(void);
 
+static int g_elem = 0;      /* element bytes of integer input (2 / 4), 0 = bytes */
 static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 static unsigned long long sm64(unsigned long long *s)
 {
@@ -34,6 +35,14 @@ static unsigned long long sm64(unsigned long long *s)
 static void gen(unsigned char *p, size_t n, int kind)
 {
     unsigned long long s = 12345;
+    if (kind == 4) {                                   /* slow random walk of 16/32-bit integers (N bytes) */
+        unsigned v = 1u << (8 * g_elem - 2);
+        for (size_t k = 0; k + g_elem <= n; k += g_elem) {
+            v += (unsigned)(sm64(&s) % 61) - 30;
+            memcpy(p + k, &v, g_elem);
+        }
+        return;
+    }
     double cum[256], tot = 0;
     int nsym = kind == 1 ? 96 : kind == 3 ? 16 : 256;
     for (int i = 0; i < nsym; i++) { tot += kind == 2 ? 1.0 : 1.0 / pow(i + 1.0, kind == 1 ? 1.6 : 1.1); cum[i] = tot; }
@@ -69,6 +78,15 @@ static int bench(unsigned char *in, size_t n, unsigned char *out, unsigned char 
     case 56: name = "ans auto nibble (anscdf4enc/anscdf4dec)"; e3 = anscdf4enc; d3 = anscdf4dec; break;
     case 57: name = "ans s nibble (anscdf4encs/anscdf4decs)"; e3 = anscdf4encs; d3 = anscdf4decs; break;
     case 58: name = "ans x nibble (anscdf4encx/anscdf4decx)"; e3 = anscdf4encx; d3 = anscdf4decx; break;
+    }
+    /* 16/32-bit integer input (`turborc -Os2 / -Os4` style, here: --int16 / --int32): ids 50/52/53 are the Turbo-VLC coders */
+    if (!e3 && g_elem) switch (id) {
+    case 50: name = g_elem == 2 ? "cdf-16 Turbo vlc6 (rccdfuenc16/rccdfudec16)" : "cdf-32 Turbo vlc6 (rccdfuenc32/rccdfudec32)";
+             e3 = g_elem == 2 ? rccdfuenc16 : rccdfuenc32; d3 = g_elem == 2 ? rccdfudec16 : rccdfudec32; break;
+    case 52: name = g_elem == 2 ? "cdf-16 Turbo vlc7 (rccdfvenc16/rccdfvdec16)" : "cdf-32 Turbo vlc7 (rccdfvenc32/rccdfvdec32)";
+             e3 = g_elem == 2 ? rccdfvenc16 : rccdfvenc32; d3 = g_elem == 2 ? rccdfvdec16 : rccdfvdec32; break;
+    case 53: name = g_elem == 2 ? "cdf-16 Turbo vlc7 zigzag (rccdfvzenc16/rccdfvzdec16)" : "cdf-32 Turbo vlc7 zigzag (rccdfvzenc32/rccdfvzdec32)";
+             e3 = g_elem == 2 ? rccdfvzenc16 : rccdfvzenc32; d3 = g_elem == 2 ? rccdfvzdec16 : rccdfvzdec32; break;
     }
     if (!e3) switch (id) {
     case 1:  name = "rc o0 (rcsenc/rcsdec)"; e3 = rcsenc; d3 = rcsdec; break;
@@ -128,6 +146,8 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "--text") && i + 1 < argc) { kind = 1; n = strtoull(argv[++i], 0, 10); }
         else if (!strcmp(argv[i], "--uniform") && i + 1 < argc) { kind = 2; n = strtoull(argv[++i], 0, 10); }
         else if (!strcmp(argv[i], "--nibble") && i + 1 < argc) { kind = 3; n = strtoull(argv[++i], 0, 10); }
+        else if (!strcmp(argv[i], "--int16") && i + 1 < argc) { kind = 4; g_elem = 2; n = strtoull(argv[++i], 0, 10) & ~(size_t)1; }
+        else if (!strcmp(argv[i], "--int32") && i + 1 < argc) { kind = 4; g_elem = 4; n = strtoull(argv[++i], 0, 10) & ~(size_t)3; }
         else file = argv[i];
     }
     if (file) {
@@ -144,7 +164,7 @@ int main(int argc, char **argv)
         for (char *t = strtok_r(s, ",", &sv); t; t = strtok_r(0, ",", &sv)) bad |= bench(in, n, out, cpy, atoi(t), runs);
         return bad;
     }
-    if (kind < 0 || !n) { fprintf(stderr, "usage: trcbench [-e ids] [-I runs] [-c chunk] (file | --zipf N | --text N | --uniform N | --nibble N)\n"); return 2; }
+    if (kind < 0 || !n) { fprintf(stderr, "usage: trcbench [-e ids] [-I runs] [-c chunk] (file | --zipf N | --text N | --uniform N | --nibble N | --int16 N | --int32 N)\n"); return 2; }
     unsigned char *in = malloc(n * 4 / 3 + 1024), *out = malloc(n * 4 / 3 + 1024), *cpy = malloc(n * 4 / 3 + 1024);
     gen(in, n, kind);
     printf("synthetic kind %d: %zu bytes\n      C Size  ratio%%    E MB/s     D MB/s   Name (host pointers: PCIe included)\n", kind, n);

@@ -48,8 +48,12 @@ enum trc_codec {
     TRC_RCSM  = 11, /* rccdfsmenc  / rccdfsm*dec   static-CDF RC, 32-bit range, 16-bit I/O rccdf.c:648-694 (-e44) */
     TRC_ANSO1 = 12, /* anscdf1enc  / anscdf1dec    order-1 adaptive-CDF byte rANS  anscdf.c:607-645 (-e64); 136 KiB of
                        model per chunk in the workspace: use chunks of 4 KiB and more */
-    TRC_ANSB  = 13  /* ansbc       / ansbd         bitwise order-0 rANS, 4 states  anscdf.c:672-731 (-e66); chunk <= 8192
+    TRC_ANSB  = 13, /* ansbc       / ansbd         bitwise order-0 rANS, 4 states  anscdf.c:672-731 (-e66); chunk <= 8192
                        (one reference block) */
+    /* Turbo-VLC integer coders over the adaptive CDF range coder, 16- / 32-bit elements (rccdf.c:391-632; -e50/52/53) */
+    TRC_VLCU16 = 14,  TRC_VLCU32 = 15,   /* rccdfuenc16/32, rccdfudec16/32     6-bit exponent */
+    TRC_VLCV16 = 16,  TRC_VLCV32 = 17,   /* rccdfvenc16/32, rccdfvdec16/32     7-bit exponent */
+    TRC_VLCVZ16 = 18, TRC_VLCVZ32 = 19   /* rccdfvzenc16/32, rccdfvzdec16/32   7-bit exponent on zigzag deltas */
 };
 
 #define TRC_MAGIC        0x31435254u   /* "TRC1" */

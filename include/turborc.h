@@ -71,6 +71,16 @@ size_t rccdf4dec(unsigned char *in, size_t outlen, unsigned char *out);
 size_t rccdf4ienc(unsigned char *in, size_t inlen, unsigned char *out);
 size_t rccdf4idec(unsigned char *in, size_t outlen, unsigned char *out);
 
+/* Turbo-VLC integer coders over the adaptive CDF range coder (reference rccdf.c:391-632, include/turborc.h:536-549;
+ * `turborc -e50/52/53` on 16- or 32-bit input): u = 6-bit exponent, v = 7-bit exponent, vz = v on the zigzag of the
+ * delta to the previous element.  inlen/outlen are BYTES (multiples of the element size). */
+size_t rccdfuenc16(unsigned char *in, size_t inlen, unsigned char *out);   size_t rccdfudec16(unsigned char *in, size_t outlen, unsigned char *out);
+size_t rccdfuenc32(unsigned char *in, size_t inlen, unsigned char *out);   size_t rccdfudec32(unsigned char *in, size_t outlen, unsigned char *out);
+size_t rccdfvenc16(unsigned char *in, size_t inlen, unsigned char *out);   size_t rccdfvdec16(unsigned char *in, size_t outlen, unsigned char *out);
+size_t rccdfvenc32(unsigned char *in, size_t inlen, unsigned char *out);   size_t rccdfvdec32(unsigned char *in, size_t outlen, unsigned char *out);
+size_t rccdfvzenc16(unsigned char *in, size_t inlen, unsigned char *out);  size_t rccdfvzdec16(unsigned char *in, size_t outlen, unsigned char *out);
+size_t rccdfvzenc32(unsigned char *in, size_t inlen, unsigned char *out);  size_t rccdfvzdec32(unsigned char *in, size_t outlen, unsigned char *out);
+
 /* bitwise order-0 range coder, "s" predictor (reference rc_.c:37-58; `turborc -e1`, file codec 1) */
 size_t rcsenc(unsigned char *in, size_t inlen, unsigned char *out);
 size_t rcsdec(unsigned char *in, size_t outlen, unsigned char *out);

@@ -974,6 +974,12 @@ static size_t enc_one(int codec, const uint8_t *in, size_t n, uint8_t *out, cons
     case ORC_RCSM:  return orc_rccdfsmenc(in, n, out, cdf, cdfnum);
     case ORC_ANSO1: return orc_anscdf1enc(in, n, out);
     case ORC_ANSB:  return orc_ansbc(in, n, out);
+    case ORC_VLCU16:  return orc_rccdfuenc16(in, n, out);
+    case ORC_VLCU32:  return orc_rccdfuenc32(in, n, out);
+    case ORC_VLCV16:  return orc_rccdfvenc16(in, n, out);
+    case ORC_VLCV32:  return orc_rccdfvenc32(in, n, out);
+    case ORC_VLCVZ16: return orc_rccdfvzenc16(in, n, out);
+    case ORC_VLCVZ32: return orc_rccdfvzenc32(in, n, out);
     }
     return 0;
 }
@@ -993,6 +999,12 @@ static void dec_one(int codec, const uint8_t *in, size_t n, uint8_t *out, const 
     case ORC_RCSM:  orc_rccdfsmdec(in, n, out, cdf, cdfnum); break;
     case ORC_ANSO1: orc_anscdf1dec(in, n, out); break;
     case ORC_ANSB:  orc_ansbd(in, n, out); break;
+    case ORC_VLCU16:  orc_rccdfudec16(in, n, out); break;
+    case ORC_VLCU32:  orc_rccdfudec32(in, n, out); break;
+    case ORC_VLCV16:  orc_rccdfvdec16(in, n, out); break;
+    case ORC_VLCV32:  orc_rccdfvdec32(in, n, out); break;
+    case ORC_VLCVZ16: orc_rccdfvzdec16(in, n, out); break;
+    case ORC_VLCVZ32: orc_rccdfvzdec32(in, n, out); break;
     }
 }
 size_t orc_chunked_enc(int codec, const uint8_t *in, size_t n, size_t chunk,

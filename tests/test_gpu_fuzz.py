@@ -32,6 +32,10 @@ def test_random_configurations(seed):
             d = d.copy(); d[a:b] = T.uniform_bytes(b - a, seed) if rng.random() < 0.5 else 7
         if codec in trc.NIBBLE_CODECS:
             d = (d & 15).astype(np.uint8)
+        if codec in trc.VLC_CODECS and rng.random() < 0.7:    # 16/32-bit series (else: arbitrary bytes read as integers)
+            es = trc.VLC_ELEM[codec]
+            d = np.concatenate([T.int_bytes(n // es * es, es, str(rng.choice(["small", "walk", "mixed", "wide"])), int(rng.integers(1, 1 << 30))),
+                                d[:n % es]]).astype(np.uint8)
         r, cdf, cdfnum = T.orc_cdfini(d)
         if r < 0:                                            # distribution the reference's cdfini cannot normalise
             continue

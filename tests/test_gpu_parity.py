@@ -29,8 +29,19 @@ def torch_cuda():
 
 
 def fit(codec, d):
-    """the `turborc -n` coders take values 0..15 (harness gate m<16): fold any test input into that range"""
-    return (d & 15).astype(np.uint8) if codec in trc.NIBBLE_CODECS else d
+    """the `turborc -n` coders take values 0..15 (harness gate m<16): fold any test input into that range; the Turbo-VLC
+    coders take 16/32-bit elements: every input byte becomes one (small) element, leftover bytes stay as they are"""
+    if codec in trc.NIBBLE_CODECS:
+        return (d & 15).astype(np.uint8)
+    if codec in trc.VLC_CODECS:
+        es = trc.VLC_ELEM[codec]
+        ne = d.size // es
+        body = d[:ne].astype(np.uint16 if es == 2 else np.uint32).view(np.uint8)
+        return np.concatenate([body, d[:d.size - ne * es]]).astype(np.uint8)
+    return d
+
+
+SMALL_ALPHABET = trc.NIBBLE_CODECS + trc.VLC_CODECS          # inputs that always compress: nothing is stored raw
 
 
 def cap(codec, chunk):
@@ -79,8 +90,8 @@ def test_mixed_raw_and_coded_chunks(torch_cuda, codec):
     d = fit(codec, np.concatenate(parts))
     _, cdf, cdfnum = T.orc_cdfini(d)
     clen, _ = device_roundtrip(torch_cuda, codec, d, 4096, cdf, cdfnum)
-    if codec in trc.NIBBLE_CODECS:
-        return                                                        # 4-bit values always compress: nothing is stored raw
+    if codec in SMALL_ALPHABET:
+        return                                                        # small values always compress: nothing is stored raw
     assert clen[2] == 4096 and clen[4] == 4096 and clen[5] == 4096      # the uniform slices are stored raw
     assert clen[3] < 4096                                             # the constant slice is coded
 
@@ -88,8 +99,8 @@ def test_mixed_raw_and_coded_chunks(torch_cuda, codec):
 @pytest.mark.parametrize("codec", trc.AVAILABLE, ids=lambda c: trc.CODEC_NAMES[c])
 def test_golden_vectors_single_chunk(torch_cuda, codec):
     """n <= 65536 with chunk >= n: the one payload must equal the reference's whole-buffer output"""
-    nib = codec in trc.NIBBLE_CODECS
-    z = np.load(os.path.join(GOLD, "nibble_vectors.npz" if nib else "vectors.npz"))
+    nib = codec in SMALL_ALPHABET
+    z = np.load(os.path.join(GOLD, "vlc_vectors.npz" if codec in trc.VLC_CODECS else "nibble_vectors.npz" if nib else "vectors.npz"))
     index = json.loads(bytes(z["index"]).decode())
     name = trc.CODEC_NAMES[codec]
     done = 0
@@ -111,7 +122,18 @@ def test_golden_vectors_single_chunk(torch_cuda, codec):
         exp = d if ent["out"][name] == n else z["out_%d_%s" % (ent["case"], name)]
         assert np.array_equal(payload, exp), (ent["kind"], n)
         done += 1
-    assert done > (45 if nib else 100)
+    assert done > (40 if nib else 100)
+
+
+@pytest.mark.parametrize("codec", trc.VLC_CODECS, ids=lambda c: trc.CODEC_NAMES[c])
+def test_vlc_tiny_payloads(torch_cuda, codec):
+    """a few small elements code to 8 bytes (header + one range-coder word, no mantissa bits): the smallest coded chunk"""
+    es = trc.VLC_ELEM[codec]
+    for nel_last in (1, 2, 5, 6, 9):
+        n = 30 * 1984 + nel_last * es
+        d = T.int_bytes(n, es, "small", 77 + nel_last)
+        clen, _ = device_roundtrip(torch_cuda, codec, d, 1984, None, 0)
+        assert clen[-1] <= nel_last * es
 
 
 def test_bitwise_rans_rejects_multi_block_chunks(torch_cuda):
@@ -150,7 +172,7 @@ def test_host_pointer_layer(torch_cuda, codec):
             assert np.array_equal(clen, exp_clen) and np.array_equal(payload, exp_payload)
             assert comp.size == 32 + 4 * clen.size + payload.size
             assert np.array_equal(trc.host_decode(codec, comp, n, cdf, cdfnum), d)
-        if codec not in trc.NIBBLE_CODECS:
+        if codec not in SMALL_ALPHABET:
             d = gen("uniform", 100000, 9)                  # incompressible: returns n, out == in
             _, cdf, cdfnum = T.orc_cdfini(d)
             comp = trc.host_encode(codec, d, cdf, cdfnum)
@@ -168,7 +190,8 @@ def test_baseline_size_properties(torch_cuda, codec):
     torch = torch_cuda
     n, chunk = 100 * 1000 * 1000, 4096
     kind = "runs" if codec in (trc.RCA, trc.ANSA) else "text"
-    d = T.nibble_bytes(n, 7, "runs") if codec in trc.NIBBLE_CODECS else gen(kind, n, 7)
+    d = (T.nibble_bytes(n, 7, "runs") if codec in trc.NIBBLE_CODECS else
+         T.int_bytes(n, trc.VLC_ELEM[codec], "walk", 7) if codec in trc.VLC_CODECS else gen(kind, n, 7))
     _, cdf, cdfnum = T.orc_cdfini(d)
     dc = trc.DeviceCoder(codec, n, chunk, "cuda:0")
     if codec in trc.STATIC:
@@ -309,3 +332,7 @@ def test_c_harness_links_and_roundtrips(torch_cuda):
         assert "MISMATCH" not in r.stdout and "failed" not in r.stdout, r.stdout
         assert r.stdout.count(":") >= 15, r.stdout            # every requested id printed its row
         assert ("nibble" in r.stdout) == (args[0] == "--nibble")   # values 0..15 route ids 46/47/56-58 to the one-table coders
+    for args in (["--int16", "2000000"], ["--int32", "4000000"]):        # integer series: the Turbo-VLC coders
+        r = subprocess.run([exe, "-I", "1", "-e", "50,52,53"] + args, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "MISMATCH" not in r.stdout and "failed" not in r.stdout, r.stdout + r.stderr
+        assert r.stdout.count("Turbo vlc") == 3, r.stdout

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(64) void trc_ansa_model_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const u32 lane = threadIdx.x;
-    NibModel<!NIB> m; m.init(smem);
+    NibModel<NIB ? 1 : 17> m; m.init(smem);
 
     WaveChunks wc;
     wc.c0 = blockIdx.x * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(64) void trc_ansa_dec_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const u32 lane = threadIdx.x;
-    NibModel<!NIB> m; m.init(smem);
+    NibModel<NIB ? 1 : 17> m; m.init(smem);
 
     WaveChunks wc;
     wc.c0 = blockIdx.x * 64u; wc.chunk = chunk; wc.nchunks = nchunks;

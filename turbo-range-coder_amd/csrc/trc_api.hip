@@ -63,11 +63,15 @@ extern "C" int trc_set_chunk(uint32_t chunk)
 #define TRC_INKERNEL_SCAN_MAX 8192u
 static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline bool is_static(int codec) { return codec == TRC_ANS4S || codec == TRC_RCS1 || codec == TRC_RCS2 || codec == TRC_RCSM; }
-static inline bool codec_ok(int codec) { return codec >= TRC_ANS4S && codec <= TRC_ANSB; }
+static inline bool codec_ok(int codec) { return codec >= TRC_ANS4S && codec <= TRC_VLCVZ32; }
+static inline bool is_vlc(int codec) { return codec >= TRC_VLCU16 && codec <= TRC_VLCVZ32; }
+static inline int vlc_variant(int codec) { return (codec - TRC_VLCU16) >> 1; }      // 0 u, 1 v, 2 vz
+static inline int vlc_elem(int codec) { return ((codec - TRC_VLCU16) & 1) ? 4 : 2; }
 static inline bool two_streams(int codec) { return codec == TRC_RCS2 || codec == TRC_RCAI || codec == TRC_RCAI4; }
 // second scratch array: RCS2 stream 1 (same stride) or ANSA's record stack (8 B per input byte + one segment)
 static inline size_t scratch2_stride(int codec, uint32_t chunk)
 {
+    if (codec >= TRC_VLCU16 && codec <= TRC_VLCVZ32) return 4;       // u32 per chunk: length of the range-coder piece
     return two_streams(codec) ? chunk + 128 : (codec == TRC_ANSA || codec == TRC_ANSO1) ? 8 * (size_t)chunk : codec == TRC_ANSB ? 16 * (size_t)chunk : codec == TRC_ANSA4 ? 4 * (size_t)chunk : 0;
 }
 
@@ -224,6 +228,7 @@ extern "C" int trc_encode_dev(int codec, const void *d_in, size_t n, uint32_t ch
     case TRC_ANSA:  trc_launch_ansa_enc(0, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 1; break;
     case TRC_ANSA4: trc_launch_ansa_enc(1, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 1; break;
     case TRC_ANSB:  trc_launch_ansb_enc((const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 1; break;
+    default:        if (is_vlc(codec)) { trc_launch_vlc_enc(vlc_variant(codec), vlc_elem(codec), (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 3; } break;
     case TRC_ANSO1: trc_launch_anso1_model((const uint8_t *)d_in, n, chunk, w, s);
                     trc_launch_ansa_code(0, n, chunk, w, d_clen, s); from_end = 1; break;
     }
@@ -266,6 +271,7 @@ extern "C" int trc_decode_dev(int codec, const uint32_t *d_clen, const void *d_p
     case TRC_ANSA4: trc_launch_ansa_dec(1, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     case TRC_ANSO1: trc_launch_anso1_dec((const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     case TRC_ANSB:  trc_launch_ansb_dec((const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
+    default:        if (is_vlc(codec)) trc_launch_vlc_dec(vlc_variant(codec), vlc_elem(codec), (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     }
     tm_end(1, tmi);
     HIPCHK(hipGetLastError());
@@ -282,6 +288,7 @@ extern "C" const char *trc_kernel_name(int codec, int decode)
     case TRC_ANSA: case TRC_ANSA4: return decode ? "trc_ansa_dec_kernel" : "trc_ansa_model_kernel";
     case TRC_ANSO1: return decode ? "trc_o1_dec_kernel" : "trc_o1_model_kernel";
     case TRC_ANSB: return decode ? "trc_ansb_dec_kernel" : "trc_ansb_model_kernel";
+    default: if (is_vlc(codec)) return decode ? "trc_vlc_dec_kernel" : "trc_vlc_enc_kernel";
     }
     return "";
 }
@@ -502,6 +509,17 @@ TRC_EXPORT_ANSO1(x)
 // block (8192 bytes) are not supported by the kernels: the call uses min(configured chunk, 8192).
 size_t ansbc(unsigned char *in, size_t inlen, unsigned char *out) { return host_encode(TRC_ANSB, in, inlen, out, nullptr, 0); }
 size_t ansbd(unsigned char *in, size_t outlen, unsigned char *out) { return host_decode(TRC_ANSB, in, outlen, out, nullptr, 0); }
+
+// Turbo-VLC integer coders over the adaptive CDF range coder (reference rccdf.c:391-632; turborc -e50/52/53 with 16- or
+// 32-bit input) -- SURVEY 8f rank 3.  Lengths are byte counts, as in the reference.
+#define TRC_EXPORT_VLC(name, codec) \
+    size_t name##enc16(unsigned char *in, size_t inlen, unsigned char *out) { return host_encode(codec##16, in, inlen, out, nullptr, 0); } \
+    size_t name##dec16(unsigned char *in, size_t outlen, unsigned char *out) { return host_decode(codec##16, in, outlen, out, nullptr, 0); } \
+    size_t name##enc32(unsigned char *in, size_t inlen, unsigned char *out) { return host_encode(codec##32, in, inlen, out, nullptr, 0); } \
+    size_t name##dec32(unsigned char *in, size_t outlen, unsigned char *out) { return host_decode(codec##32, in, outlen, out, nullptr, 0); }
+TRC_EXPORT_VLC(rccdfu, TRC_VLCU)
+TRC_EXPORT_VLC(rccdfv, TRC_VLCV)
+TRC_EXPORT_VLC(rccdfvz, TRC_VLCVZ)
 
 typedef size_t (*fanscdfenc)(unsigned char *in, size_t inlen, unsigned char *out);
 typedef size_t (*fanscdfdec)(unsigned char *in, size_t inlen, unsigned char *out);

@@ -93,6 +93,12 @@ void trc_launch_ansb_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const Tr
 void trc_launch_ansb_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                          const TrcWork &w, uint8_t *d_out, hipStream_t s);
 
+// Turbo-VLC integer coders (rccdf{u,v,vz}{enc,dec}{16,32}): variant 0 = u, 1 = v, 2 = vz; elem = 2 or 4 bytes;
+// scratch2 is a u32 per chunk (length of the range-coder piece, for gather mode 3)
+void trc_launch_vlc_enc(int variant, int elem, const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s);
+void trc_launch_vlc_dec(int variant, int elem, const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
+                        const TrcWork &w, uint8_t *d_out, hipStream_t s);
+
 // cdfini on device
 void trc_launch_hist(const uint8_t *d_in, size_t n, uint64_t *d_hist, hipStream_t s);
 void trc_launch_cdf_build(const uint64_t *d_hist, size_t n_total, uint16_t *d_cdf, unsigned cdfnum, int32_t *d_status, hipStream_t s);

@@ -25,8 +25,10 @@ typedef short trc_s2 __attribute__((ext_vector_type(2)));
 #define TRC_NIBK_BYTES  512u                      // K table, per wave
 #define TRC_NIB_ROW     560u                      // bytes per lane, byte model (17 tables)
 #define TRC_NIB1_ROW    48u                       // bytes per lane, single table
+#define TRC_NIB2_ROW    80u                       // bytes per lane, two tables (Turbo-VLC coders): 20 dwords, conflict free like the others
 #define TRC_NIB_BYTES   (TRC_NIBK_BYTES + 64u * TRC_NIB_ROW)      // 36352 per wave
 #define TRC_NIB1_BYTES  (TRC_NIBK_BYTES + 64u * TRC_NIB1_ROW)     // 3584 per wave
+#define TRC_NIB2_BYTES  (TRC_NIBK_BYTES + 64u * TRC_NIB2_ROW)     // 5632 per wave
 
 struct NibTable { u32 d[8]; };                    // 16 x u16, entry 2k in the low half of d[k]
 
@@ -34,8 +36,10 @@ __device__ __forceinline__ u32 trc_pk(u32 lo, u32 hi) { return (lo & 0xffffu) | 
 __device__ __forceinline__ trc_s2 trc_as_s2(u32 v) { return __builtin_bit_cast(trc_s2, v); }
 __device__ __forceinline__ u32 trc_as_u32(trc_s2 v) { return __builtin_bit_cast(u32, v); }
 
-template <bool BYTE>
+// NT = tables per lane: 17 (byte model), 1 (nibble coders), 2 (Turbo-VLC coders)
+template <int NT>
 struct NibModel {
+    static constexpr u32 ROW = NT == 17 ? TRC_NIB_ROW : NT == 1 ? TRC_NIB1_ROW : TRC_NIB2_ROW;
     u8 *kb;                                       // this wave's K table
     u8 *row;                                      // this lane's tables
     // smem = this wave's model area (TRC_NIB_BYTES / TRC_NIB1_BYTES); every lane of the wave must call
@@ -43,14 +47,14 @@ struct NibModel {
     {
         const u32 lane = trc_lane();
         kb = smem;
-        row = smem + TRC_NIBK_BYTES + lane * (BYTE ? TRC_NIB_ROW : TRC_NIB1_ROW);
+        row = smem + TRC_NIBK_BYTES + lane * ROW;
 #pragma unroll
         for (u32 j = 0; j < 2; j++) {             // 128 dwords of K, two per lane
             const u32 idx = lane * 2u + j, x = idx >> 3, k = idx & 7u;
             const u32 e0 = 2u * k, e1 = 2u * k + 1u;
             ((u32 *)kb)[idx] = trc_pk(10u * e0 + (e0 > x ? 32736u : 0u), 10u * e1 + (e1 > x ? 32736u : 0u));
         }
-        for (u32 t = 0; t < (BYTE ? 17u : 1u); t++)
+        for (u32 t = 0; t < (u32)NT; t++)
 #pragma unroll
             for (u32 k = 0; k < 8; k++) ((u32 *)(row + t * 32u))[k] = trc_pk((2 * k) << 11, (2 * k + 1) << 11);
         __syncthreads();                          // one wave per workgroup: orders the K writes before other lanes' reads

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(64) void trc_rca_enc_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const u32 lane = threadIdx.x;
-    NibModel<!NIB> m; m.init(smem);
+    NibModel<NIB ? 1 : 17> m; m.init(smem);
 
     WaveChunks wc;
     wc.c0 = blockIdx.x * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64) void trc_rca_dec_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const u32 lane = threadIdx.x;
-    NibModel<!NIB> m; m.init(smem);
+    NibModel<NIB ? 1 : 17> m; m.init(smem);
 
     WaveChunks wc;
     wc.c0 = blockIdx.x * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
