@@ -911,6 +911,124 @@ VLC_PAIR(rccdfvz, 16, 2, 1)
 VLC_PAIR(rccdfvz, 32, 2, 1)
 
 /* ------------------------------------------------------------------------------------------ */
+/* SURVEY 8f rank 3, second half: the same Turbo-VLC integer coders over the adaptive CDF rANS (anscdf.c:139-483;     */
+/* cdfenc6/7, cdfdec6/7 anscdf_.h:205-230; mnflush :128-138), `turborc -e60..63`: anscdfu/uz (vn = 1) on 16-bit,       */
+/* anscdfv/vz (vn = 2) on 16- and 32-bit elements; "z" = zigzag of the delta to the previous element.                 */
+/* Per block of 4 Mi ELEMENTS: tables reset, a forward pass appends the mantissas to the bit string (which, like the   */
+/* previous element of the z variants, runs on across blocks) and records one or two symbols per element -- the first */
+/* on rANS state 1, the second on state 0 -- then the records are coded backwards, words growing down from 16 bytes    */
+/* below the bit string's current end, and the block payload [st1][st0][u16 words] is moved up behind the previous     */
+/* one.  Result [u32 total][block payloads][bit bytes].  Raw rules (all pointer tests of the reference, as offsets):   */
+/* before every record words + 30 + floor(bits/8) >= inlen; after a block 4 + payloads + 16 + floor(bits/8) >= inlen;  */
+/* at the end total >= inlen.  A trailing partial element is zero-extended (cf. vlc_enc).                             */
+static size_t vlca_enc(const uint8_t *in, size_t inlen, uint8_t *out, unsigned es, unsigned vn, int zz)
+{
+    const unsigned T = vn == 2 ? 8u : 12u;
+    size_t nel = (inlen + es - 1) / es, blk = nel < ANS_BLOCK ? nel : ANS_BLOCK, bits = 0, op = 4, nbytes;
+    uint8_t *bitbuf = (uint8_t *)calloc(nel * 4 + 16, 1);
+    uint8_t *body = (uint8_t *)malloc(inlen + 64), *tmp = (uint8_t *)malloc(4 * blk + 64);
+    uint32_t *stack = (uint32_t *)malloc((2 * blk + 2) * sizeof(uint32_t)), prev = 0;
+    if (!bitbuf || !body || !tmp || !stack) { free(bitbuf); free(body); free(tmp); free(stack); return 0; }
+    for (size_t pos = 0; pos < nel; pos += blk) {
+        size_t cnt = nel - pos < blk ? nel - pos : blk, ns = 0;
+        nibmodel_t m; nib_reset(&m);                               /* tables 0 and 1 = m.hi and m.lo[0] */
+        for (size_t i = pos; i < pos + cnt; i++) {
+            uint32_t v = 0, x;
+            memcpy(&v, in + i * es, inlen - i * es < es ? inlen - i * es : es);
+            if (zz) {
+                uint32_t d = v - prev;
+                x = es == 2 ? (uint16_t)(((int16_t)d << 1) ^ ((int16_t)d >> 15)) : (uint32_t)(((int32_t)d << 1) ^ ((int32_t)d >> 31));
+                prev = v;
+            } else x = v;
+            if (x >= (1u << (vn + 1))) {
+                unsigned f = bsr32(x) - vn, expo = ((f + 1) << vn) + ((x >> f) & ((1u << vn) - 1));
+                uint32_t ma = x & ((1u << f) - 1);
+                for (unsigned k = 0; k < f; k++, bits++)
+                    if ((ma >> (f - 1 - k)) & 1) bitbuf[bits >> 3] |= (uint8_t)(0x80u >> (bits & 7));
+                x = expo;
+            }
+            if (x < T) { stack[ns++] = 1u << 30 | (uint32_t)m.hi[x] << 15 | (uint32_t)(m.hi[x + 1] - m.hi[x]); nib_adapt(m.hi, x); }
+            else {
+                unsigned y = ((x - T) >> 4) + T, z = (x - T) & 15;
+                stack[ns++] = 1u << 30 | (uint32_t)m.hi[y] << 15 | (uint32_t)(m.hi[y + 1] - m.hi[y]); nib_adapt(m.hi, y);
+                stack[ns++] = (uint32_t)m.lo[0][z] << 15 | (uint32_t)(m.lo[0][z + 1] - m.lo[0][z]); nib_adapt(m.lo[0], z);
+            }
+        }
+        /* mnflush(op, bp - 8, ...) with bp = out + inlen - 8 - floor(bits/8): everything as offsets from out */
+        int64_t top = (int64_t)inlen - 16 - (int64_t)(bits >> 3), ep = top;
+        uint32_t st[2] = { ANS_LO, ANS_LO };
+        uint8_t *tend = tmp + 4 * blk + 64, *tp = tend;
+        while (ns) {
+            uint32_t r = stack[--ns];
+            if (ep <= (int64_t)op + 2 + 8) goto raw;
+            uint8_t *before = tp;
+            ans_put(&st[r >> 30], (r >> 15) & 0x7fff, r & 0x7fff, &tp);
+            ep -= before - tp;
+        }
+        for (int k = 0; k < 2; k++) { tp -= 4; st32(tp, st[k]); ep -= 4; }
+        if (ep <= (int64_t)op) goto raw;
+        size_t l = (size_t)(tend - tp);
+        if ((int64_t)op + (int64_t)l >= top) goto raw;
+        memcpy(body + op, tp, l); op += l;
+    }
+    nbytes = (bits + 7) >> 3;
+    if (op + nbytes >= inlen) goto raw;
+    {
+        size_t total = op + nbytes;
+        memcpy(out + 4, body + 4, op - 4);
+        st32(out, (uint32_t)total);
+        for (size_t k = 0; k < nbytes; k++) out[total - 1 - k] = bitbuf[k];
+        free(bitbuf); free(body); free(tmp); free(stack);
+        return total;
+    }
+raw:
+    free(bitbuf); free(body); free(tmp); free(stack);
+    memcpy(out, in, inlen);
+    return inlen;
+}
+static size_t vlca_dec(const uint8_t *in, size_t outlen, uint8_t *out, unsigned es, unsigned vn, int zz)
+{
+    const unsigned T = vn == 2 ? 8u : 12u;
+    size_t nel = (outlen + es - 1) / es, blk = nel < ANS_BLOCK ? nel : ANS_BLOCK, bits = 0, total = ld32(in);
+    const uint8_t *ip = in + 4;
+    uint32_t prev = 0;
+    for (size_t pos = 0; pos < nel; pos += blk) {
+        size_t cnt = nel - pos < blk ? nel - pos : blk;
+        nibmodel_t m; nib_reset(&m);
+        uint32_t sa = ld32(ip), sb = ld32(ip + 4);                 /* sa = encoder state 1 (first symbols), sb = state 0 */
+        ip += 8;
+        for (size_t i = pos; i < pos + cnt; i++) {
+            uint32_t x = ansd_nibble(&sa, m.hi), v;
+            ansd_renorm(&sa, &ip);
+            if (x >= T) { unsigned z = ansd_nibble(&sb, m.lo[0]); ansd_renorm(&sb, &ip); x = ((x - T) << 4 | z) + T; }
+            if (x >= (1u << (vn + 1))) {
+                unsigned f = (x >> vn) - 1;
+                uint32_t ma = 0;
+                for (unsigned k = 0; k < f; k++, bits++)
+                    ma = ma << 1 | ((in[total - 1 - (bits >> 3)] >> (7 - (bits & 7))) & 1);
+                x = (((1u << vn) + (x & ((1u << vn) - 1))) << f) + ma;
+            }
+            if (zz) {
+                v = es == 2 ? (uint16_t)(prev + (uint16_t)((x >> 1) ^ (0u - (x & 1)))) : prev + ((x >> 1) ^ (0u - (x & 1)));
+                prev = v;
+            } else v = x;
+            size_t nb = outlen - i * es < es ? outlen - i * es : es;
+            memcpy(out + i * es, &v, nb);
+        }
+    }
+    return outlen;
+}
+#define VLCA_PAIR(name, es, vn, zz) \
+    size_t orc_##name##enc##es(const uint8_t *in, size_t inlen, uint8_t *out) { return vlca_enc(in, inlen, out, es / 8, vn, zz); } \
+    size_t orc_##name##dec##es(const uint8_t *in, size_t outlen, uint8_t *out) { return vlca_dec(in, outlen, out, es / 8, vn, zz); }
+VLCA_PAIR(anscdfu, 16, 1, 0)
+VLCA_PAIR(anscdfuz, 16, 1, 1)
+VLCA_PAIR(anscdfv, 16, 2, 0)
+VLCA_PAIR(anscdfvz, 16, 2, 1)
+VLCA_PAIR(anscdfv, 32, 2, 0)
+VLCA_PAIR(anscdfvz, 32, 2, 1)
+
+/* ------------------------------------------------------------------------------------------ */
 /* M9  rcsenc / rcsdec  (rc_.c:37-58, mb_o0.h:27-41,89-112, turborc_.h:417-452, mbc_s.h:53-55)  */
 static inline uint16_t bit_adapt(uint32_t p, uint32_t bit)
 {
@@ -980,6 +1098,12 @@ static size_t enc_one(int codec, const uint8_t *in, size_t n, uint8_t *out, cons
     case ORC_VLCV32:  return orc_rccdfvenc32(in, n, out);
     case ORC_VLCVZ16: return orc_rccdfvzenc16(in, n, out);
     case ORC_VLCVZ32: return orc_rccdfvzenc32(in, n, out);
+    case ORC_VLAU16:  return orc_anscdfuenc16(in, n, out);
+    case ORC_VLAUZ16: return orc_anscdfuzenc16(in, n, out);
+    case ORC_VLAV16:  return orc_anscdfvenc16(in, n, out);
+    case ORC_VLAVZ16: return orc_anscdfvzenc16(in, n, out);
+    case ORC_VLAV32:  return orc_anscdfvenc32(in, n, out);
+    case ORC_VLAVZ32: return orc_anscdfvzenc32(in, n, out);
     }
     return 0;
 }
@@ -1005,6 +1129,12 @@ static void dec_one(int codec, const uint8_t *in, size_t n, uint8_t *out, const 
     case ORC_VLCV32:  orc_rccdfvdec32(in, n, out); break;
     case ORC_VLCVZ16: orc_rccdfvzdec16(in, n, out); break;
     case ORC_VLCVZ32: orc_rccdfvzdec32(in, n, out); break;
+    case ORC_VLAU16:  orc_anscdfudec16(in, n, out); break;
+    case ORC_VLAUZ16: orc_anscdfuzdec16(in, n, out); break;
+    case ORC_VLAV16:  orc_anscdfvdec16(in, n, out); break;
+    case ORC_VLAVZ16: orc_anscdfvzdec16(in, n, out); break;
+    case ORC_VLAV32:  orc_anscdfvdec32(in, n, out); break;
+    case ORC_VLAVZ32: orc_anscdfvzdec32(in, n, out); break;
     }
 }
 size_t orc_chunked_enc(int codec, const uint8_t *in, size_t n, size_t chunk,

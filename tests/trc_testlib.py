@@ -20,11 +20,15 @@ REF_SO = os.path.join(ORACLE_DIR, "_ref", "libtrc_ref.so")
 # codec ids == include/trc_hip.h == oracle/trc_oracle.h
 ANS4S, RCS1, RCS2, RCA, ANSA, RCB, RCAI, RCA4, RCAI4, ANSA4, RCSM, ANSO1, ANSB = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13
 VLCU16, VLCU32, VLCV16, VLCV32, VLCVZ16, VLCVZ32 = 14, 15, 16, 17, 18, 19   # Turbo-VLC integer coders
+VLAU16, VLAUZ16, VLAV16, VLAVZ16, VLAV32, VLAVZ32 = 20, 21, 22, 23, 24, 25   # ... over the CDF rANS
 CODEC_NAMES = {ANS4S: "anscdf4s", RCS1: "rccdfs", RCS2: "rccdfs2", RCA: "rccdf", ANSA: "anscdf", RCB: "rcs", RCAI: "rccdfi",
                RCA4: "rccdf4", RCAI4: "rccdf4i", ANSA4: "anscdf4", RCSM: "rccdfsm", ANSO1: "anscdf1", ANSB: "ansb",
-               VLCU16: "rccdfu16", VLCU32: "rccdfu32", VLCV16: "rccdfv16", VLCV32: "rccdfv32", VLCVZ16: "rccdfvz16", VLCVZ32: "rccdfvz32"}
-VLC_CODECS = (VLCU16, VLCU32, VLCV16, VLCV32, VLCVZ16, VLCVZ32)
-VLC_ELEM = {VLCU16: 2, VLCU32: 4, VLCV16: 2, VLCV32: 4, VLCVZ16: 2, VLCVZ32: 4}   # element bytes
+               VLCU16: "rccdfu16", VLCU32: "rccdfu32", VLCV16: "rccdfv16", VLCV32: "rccdfv32", VLCVZ16: "rccdfvz16", VLCVZ32: "rccdfvz32",
+               VLAU16: "anscdfu16", VLAUZ16: "anscdfuz16", VLAV16: "anscdfv16", VLAVZ16: "anscdfvz16", VLAV32: "anscdfv32", VLAVZ32: "anscdfvz32"}
+VLA_CODECS = (VLAU16, VLAUZ16, VLAV16, VLAVZ16, VLAV32, VLAVZ32)
+VLC_CODECS = (VLCU16, VLCU32, VLCV16, VLCV32, VLCVZ16, VLCVZ32) + VLA_CODECS
+VLC_ELEM = {VLCU16: 2, VLCU32: 4, VLCV16: 2, VLCV32: 4, VLCVZ16: 2, VLCVZ32: 4,
+            VLAU16: 2, VLAUZ16: 2, VLAV16: 2, VLAVZ16: 2, VLAV32: 4, VLAVZ32: 4}   # element bytes
 NIBBLE_CODECS = (RCA4, RCAI4, ANSA4)          # `turborc -n` coders: input values 0..15
 # adaptive coders: (oracle encoder, oracle decoder, reference encoder, reference decoder); ANS ones take a variant suffix
 _ADAPTIVE = {RCA: ("rccdfenc", "rccdfdec"), ANSA: ("anscdfenc", "anscdfdec"), RCB: ("rcsenc", "rcsdec"),
@@ -32,7 +36,10 @@ _ADAPTIVE = {RCA: ("rccdfenc", "rccdfdec"), ANSA: ("anscdfenc", "anscdfdec"), RC
              ANSA4: ("anscdf4enc", "anscdf4dec"), ANSO1: ("anscdf1enc", "anscdf1dec"), ANSB: ("ansbc", "ansbd"),
              VLCU16: ("rccdfuenc16", "rccdfudec16"), VLCU32: ("rccdfuenc32", "rccdfudec32"),
              VLCV16: ("rccdfvenc16", "rccdfvdec16"), VLCV32: ("rccdfvenc32", "rccdfvdec32"),
-             VLCVZ16: ("rccdfvzenc16", "rccdfvzdec16"), VLCVZ32: ("rccdfvzenc32", "rccdfvzdec32")}
+             VLCVZ16: ("rccdfvzenc16", "rccdfvzdec16"), VLCVZ32: ("rccdfvzenc32", "rccdfvzdec32"),
+             VLAU16: ("anscdfuenc16", "anscdfudec16"), VLAUZ16: ("anscdfuzenc16", "anscdfuzdec16"),
+             VLAV16: ("anscdfvenc16", "anscdfvdec16"), VLAVZ16: ("anscdfvzenc16", "anscdfvzdec16"),
+             VLAV32: ("anscdfvenc32", "anscdfvdec32"), VLAVZ32: ("anscdfvzenc32", "anscdfvzdec32")}
 STATIC_CODECS = (ANS4S, RCS1, RCS2, RCSM)
 
 _u8p = C.POINTER(C.c_uint8)
@@ -276,6 +283,7 @@ def ref():
             f = getattr(lib, name); f.restype = sz; f.argtypes = [_u8p, sz, _u8p, _u16p]
         names = [n for pair in _ADAPTIVE.values() for n in pair]
         names += [n + v for n in ("anscdfenc", "anscdfdec", "anscdf4enc", "anscdf4dec", "anscdf1enc", "anscdf1dec") for v in ("s", "x")]
+        names += [n + v for c in VLA_CODECS for n in _ADAPTIVE[c] for v in ("s", "x")]
         for name in names:
             f = getattr(lib, name); f.restype = sz; f.argtypes = [_u8p, sz, _u8p]
         _ref = lib
@@ -307,7 +315,7 @@ def ref_enc(codec, data, cdf=None, cdfnum=256, variant=""):
     elif codec == RCSM:
         l = r.rccdfsmenc(pin, n, pout, _p16(cdf), cdfnum)
     elif codec in _ADAPTIVE:
-        l = getattr(r, _ADAPTIVE[codec][0] + (variant if codec in (ANSA, ANSA4, ANSO1) else ""))(pin, n, pout)
+        l = getattr(r, _ADAPTIVE[codec][0] + (variant if codec in (ANSA, ANSA4, ANSO1) + VLA_CODECS else ""))(pin, n, pout)
     else:
         raise ValueError(codec)
     return buf[oo:oo + l].copy()
@@ -330,7 +338,7 @@ def ref_dec(codec, comp, n, cdf=None, cdfnum=256, variant="", search="b"):
     elif codec == RCSM:
         getattr(r, "rccdfsm%sdec" % search)(_p8(src), n, _p8(out), _p16(cdf), cdfnum)
     elif codec in _ADAPTIVE:
-        getattr(r, _ADAPTIVE[codec][1] + (variant if codec in (ANSA, ANSA4, ANSO1) else ""))(_p8(src), n, _p8(out))
+        getattr(r, _ADAPTIVE[codec][1] + (variant if codec in (ANSA, ANSA4, ANSO1) + VLA_CODECS else ""))(_p8(src), n, _p8(out))
     return out[:n].copy()
 
 
