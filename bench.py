@@ -58,6 +58,12 @@ CODEC_INFO = {
     "rccdfv32": ("Turbo-VLC (7-bit exponent) over the adaptive CDF range coder, 32-bit elements (rccdfvenc32/rccdfvdec32 per chunk)", "i32"),
     "rccdfvz16": ("Turbo-VLC on zigzag deltas over the adaptive CDF range coder, 16-bit elements (rccdfvzenc16/rccdfvzdec16 per chunk)", "i16"),
     "rccdfvz32": ("Turbo-VLC on zigzag deltas over the adaptive CDF range coder, 32-bit elements (rccdfvzenc32/rccdfvzdec32 per chunk)", "i32"),
+    "anscdfu16": ("Turbo-VLC (6-bit exponent) over the adaptive CDF rANS, 16-bit elements (anscdfuenc16/anscdfudec16 per chunk)", "i16"),
+    "anscdfuz16": ("Turbo-VLC (6-bit exponent) on zigzag deltas over the adaptive CDF rANS, 16-bit elements (anscdfuzenc16/anscdfuzdec16 per chunk)", "i16"),
+    "anscdfv16": ("Turbo-VLC (7-bit exponent) over the adaptive CDF rANS, 16-bit elements (anscdfvenc16/anscdfvdec16 per chunk)", "i16"),
+    "anscdfvz16": ("Turbo-VLC (7-bit exponent) on zigzag deltas over the adaptive CDF rANS, 16-bit elements (anscdfvzenc16/anscdfvzdec16 per chunk)", "i16"),
+    "anscdfv32": ("Turbo-VLC (7-bit exponent) over the adaptive CDF rANS, 32-bit elements (anscdfvenc32/anscdfvdec32 per chunk)", "i32"),
+    "anscdfvz32": ("Turbo-VLC (7-bit exponent) on zigzag deltas over the adaptive CDF rANS, 32-bit elements (anscdfvzenc32/anscdfvzdec32 per chunk)", "i32"),
     "rccdf4":   ("adaptive-CDF nibble range coder (rccdf4enc/rccdf4dec per chunk), one CDF16 table per lane in LDS", "nib"),
     "rccdf4i":  ("adaptive-CDF nibble range coder, 2 streams (rccdf4ienc/rccdf4idec per chunk), one CDF16 table per lane in LDS", "nib"),
     "anscdf4":  ("adaptive-CDF nibble rANS, 2 states (anscdf4enc/anscdf4dec per chunk), one CDF16 table per lane in LDS", "nib"),

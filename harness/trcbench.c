@@ -87,6 +87,13 @@ static int bench(unsigned char *in, size_t n, unsigned char *out, unsigned char 
              e3 = g_elem == 2 ? rccdfvenc16 : rccdfvenc32; d3 = g_elem == 2 ? rccdfvdec16 : rccdfvdec32; break;
     case 53: name = g_elem == 2 ? "cdf-16 Turbo vlc7 zigzag (rccdfvzenc16/rccdfvzdec16)" : "cdf-32 Turbo vlc7 zigzag (rccdfvzenc32/rccdfvzdec32)";
              e3 = g_elem == 2 ? rccdfvzenc16 : rccdfvzenc32; d3 = g_elem == 2 ? rccdfvzdec16 : rccdfvzdec32; break;
+    /* ... over rANS (the reference has the 6-bit forms for 16-bit input only: turborc.c:526-529) */
+    case 60: if (g_elem == 2) { name = "anscdf-16 Turbo vlc6 (anscdfuenc16/anscdfudec16)"; e3 = anscdfuenc16; d3 = anscdfudec16; } break;
+    case 61: if (g_elem == 2) { name = "anscdf-16 Turbo vlc6 zigzag (anscdfuzenc16/anscdfuzdec16)"; e3 = anscdfuzenc16; d3 = anscdfuzdec16; } break;
+    case 62: name = g_elem == 2 ? "anscdf-16 Turbo vlc7 (anscdfvenc16/anscdfvdec16)" : "anscdf-32 Turbo vlc7 (anscdfvenc32/anscdfvdec32)";
+             e3 = g_elem == 2 ? anscdfvenc16 : anscdfvenc32; d3 = g_elem == 2 ? anscdfvdec16 : anscdfvdec32; break;
+    case 63: name = g_elem == 2 ? "anscdf-16 Turbo vlc7 zigzag (anscdfvzenc16/anscdfvzdec16)" : "anscdf-32 Turbo vlc7 zigzag (anscdfvzenc32/anscdfvzdec32)";
+             e3 = g_elem == 2 ? anscdfvzenc16 : anscdfvzenc32; d3 = g_elem == 2 ? anscdfvzdec16 : anscdfvzdec32; break;
     }
     if (!e3) switch (id) {
     case 1:  name = "rc o0 (rcsenc/rcsdec)"; e3 = rcsenc; d3 = rcsdec; break;

@@ -62,6 +62,59 @@ LIBAPI size_t anscdf1decx(unsigned char *in, size_t outlen, unsigned char *out);
 LIBAPI size_t ansbc(unsigned char *in, size_t inlen, unsigned char *out);
 LIBAPI size_t ansbd(unsigned char *in, size_t outlen, unsigned char *out);
 
+/* Turbo-VLC integer coders over the adaptive CDF rANS (reference include/anscdf.h:53-68,97-139; anscdf.c:139-483;
+ * `turborc -e60..63` on 16/32-bit input): u/uz = 6-bit exponent (16-bit elements), v/vz = 7-bit exponent, "z" = on the
+ * zigzag of the delta to the previous element.  inlen/outlen are BYTES.  The reference decoders return the compressed
+ * size + 4 (its harness ignores it); these return outlen like every other decoder. */
+LIBAPI size_t anscdfuenc16(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdfudec16(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdfuenc160(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdfudec160(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdfuenc16s(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdfudec16s(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdfuenc16x(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdfudec16x(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdfuzenc16(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdfuzdec16(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdfuzenc160(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdfuzdec160(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdfuzenc16s(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdfuzdec16s(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdfuzenc16x(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdfuzdec16x(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdfvenc16(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdfvdec16(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdfvenc160(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdfvdec160(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdfvenc16s(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdfvdec16s(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdfvenc16x(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdfvdec16x(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdfvzenc16(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdfvzdec16(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdfvzenc160(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdfvzdec160(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdfvzenc16s(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdfvzdec16s(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdfvzenc16x(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdfvzdec16x(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdfvenc32(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdfvdec32(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdfvenc320(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdfvdec320(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdfvenc32s(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdfvdec32s(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdfvenc32x(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdfvdec32x(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdfvzenc32(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdfvzdec32(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdfvzenc320(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdfvzdec320(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdfvzenc32s(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdfvzdec32s(unsigned char *in, size_t outlen, unsigned char *out);
+LIBAPI size_t anscdfvzenc32x(unsigned char *in, size_t inlen, unsigned char *out);
+LIBAPI size_t anscdfvzdec32x(unsigned char *in, size_t outlen, unsigned char *out);
+
 /* adaptive-CDF nibble rANS on values 0..15, 2 states (reference include/anscdf.h:44-45,70-75; anscdf.c:87-133;
  * `turborc -n -e56/57/58`).  The decoder takes the n%4 tail from the state the encoder used (the reference's
  * decoder does not round-trip such lengths). */

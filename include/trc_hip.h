@@ -53,7 +53,11 @@ enum trc_codec {
     /* Turbo-VLC integer coders over the adaptive CDF range coder, 16- / 32-bit elements (rccdf.c:391-632; -e50/52/53) */
     TRC_VLCU16 = 14,  TRC_VLCU32 = 15,   /* rccdfuenc16/32, rccdfudec16/32     6-bit exponent */
     TRC_VLCV16 = 16,  TRC_VLCV32 = 17,   /* rccdfvenc16/32, rccdfvdec16/32     7-bit exponent */
-    TRC_VLCVZ16 = 18, TRC_VLCVZ32 = 19   /* rccdfvzenc16/32, rccdfvzdec16/32   7-bit exponent on zigzag deltas */
+    TRC_VLCVZ16 = 18, TRC_VLCVZ32 = 19,  /* rccdfvzenc16/32, rccdfvzdec16/32   7-bit exponent on zigzag deltas */
+    /* ... and over the adaptive CDF rANS (anscdf.c:139-483; -e60..63) */
+    TRC_VLAU16 = 20,  TRC_VLAUZ16 = 21,  /* anscdfuenc16 / anscdfuzenc16 (+dec)        6-bit exponent, plain / zigzag deltas */
+    TRC_VLAV16 = 22,  TRC_VLAVZ16 = 23,  /* anscdfvenc16 / anscdfvzenc16 (+dec)        7-bit exponent */
+    TRC_VLAV32 = 24,  TRC_VLAVZ32 = 25   /* anscdfvenc32 / anscdfvzenc32 (+dec) */
 };
 
 #define TRC_MAGIC        0x31435254u   /* "TRC1" */

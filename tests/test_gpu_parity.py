@@ -333,6 +333,6 @@ def test_c_harness_links_and_roundtrips(torch_cuda):
         assert r.stdout.count(":") >= 15, r.stdout            # every requested id printed its row
         assert ("nibble" in r.stdout) == (args[0] == "--nibble")   # values 0..15 route ids 46/47/56-58 to the one-table coders
     for args in (["--int16", "2000000"], ["--int32", "4000000"]):        # integer series: the Turbo-VLC coders
-        r = subprocess.run([exe, "-I", "1", "-e", "50,52,53"] + args, capture_output=True, text=True, timeout=300)
+        r = subprocess.run([exe, "-I", "1", "-e", "50,52,53,60,61,62,63"] + args, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "MISMATCH" not in r.stdout and "failed" not in r.stdout, r.stdout + r.stderr
-        assert r.stdout.count("Turbo vlc") == 3, r.stdout
+        assert r.stdout.count("Turbo vlc") == (7 if args[0] == "--int16" else 5), r.stdout

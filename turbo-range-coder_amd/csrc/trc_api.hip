@@ -63,15 +63,20 @@ extern "C" int trc_set_chunk(uint32_t chunk)
 #define TRC_INKERNEL_SCAN_MAX 8192u
 static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline bool is_static(int codec) { return codec == TRC_ANS4S || codec == TRC_RCS1 || codec == TRC_RCS2 || codec == TRC_RCSM; }
-static inline bool codec_ok(int codec) { return codec >= TRC_ANS4S && codec <= TRC_VLCVZ32; }
+static inline bool codec_ok(int codec) { return codec >= TRC_ANS4S && codec <= TRC_VLAVZ32; }
 static inline bool is_vlc(int codec) { return codec >= TRC_VLCU16 && codec <= TRC_VLCVZ32; }
 static inline int vlc_variant(int codec) { return (codec - TRC_VLCU16) >> 1; }      // 0 u, 1 v, 2 vz
 static inline int vlc_elem(int codec) { return ((codec - TRC_VLCU16) & 1) ? 4 : 2; }
+static inline bool is_vla(int codec) { return codec >= TRC_VLAU16 && codec <= TRC_VLAVZ32; }            // ... over rANS
+static inline int vla_variant(int codec) { return codec <= TRC_VLAUZ16 ? 0 : 1; }                          // 0 u, 1 v
+static inline int vla_zz(int codec) { return (codec - TRC_VLAU16) & 1; }
+static inline int vla_elem(int codec) { return codec >= TRC_VLAV32 ? 4 : 2; }
 static inline bool two_streams(int codec) { return codec == TRC_RCS2 || codec == TRC_RCAI || codec == TRC_RCAI4; }
 // second scratch array: RCS2 stream 1 (same stride) or ANSA's record stack (8 B per input byte + one segment)
 static inline size_t scratch2_stride(int codec, uint32_t chunk)
 {
-    if (codec >= TRC_VLCU16 && codec <= TRC_VLCVZ32) return 4;       // u32 per chunk: length of the range-coder piece
+    if (codec >= TRC_VLAU16 && codec <= TRC_VLAVZ32)            // record stack (8 B per element) + room for the mantissa bytes at the slot's end
+        return 8 * (size_t)(chunk / (codec >= TRC_VLAV32 ? 4 : 2)) + chunk + 64;
     return two_streams(codec) ? chunk + 128 : (codec == TRC_ANSA || codec == TRC_ANSO1) ? 8 * (size_t)chunk : codec == TRC_ANSB ? 16 * (size_t)chunk : codec == TRC_ANSA4 ? 4 * (size_t)chunk : 0;
 }
 
@@ -88,7 +93,8 @@ extern "C" size_t trc_work_bytes(int codec, size_t n, uint32_t chunk)
     const size_t nchunks = (n + chunk - 1) / chunk, ngroups = (nchunks + 63) / 64;
     return up256(TRC_TAB_BYTES) + up256(4 * ngroups) + up256(8 * (ngroups + 1)) +
            up256(nchunks * (size_t)scratch_stride(codec, chunk)) + up256(nchunks * scratch2_stride(codec, chunk) + 256) +
-           (codec == TRC_ANSO1 ? up256(nchunks * (size_t)TRC_O1_MODEL_BYTES) : 0) + 4096;
+           (codec == TRC_ANSO1 ? up256(nchunks * (size_t)TRC_O1_MODEL_BYTES) : 0) +
+           (codec >= TRC_VLCU16 ? up256(nchunks * 8) : 0) + 4096;
 }
 
 static int carve(int codec, size_t n, uint32_t chunk, void *d_work, size_t work_bytes, TrcWork &w)
@@ -107,6 +113,7 @@ static int carve(int codec, size_t n, uint32_t chunk, void *d_work, size_t work_
     w.stride2 = (uint32_t)scratch2_stride(codec, chunk);
     w.scratch2 = p + up256(nchunks * (size_t)w.stride);
     w.model = w.scratch2 + up256(nchunks * scratch2_stride(codec, chunk) + 256);
+    w.aux = (uint32_t *)(w.model + (codec == TRC_ANSO1 ? up256(nchunks * (size_t)TRC_O1_MODEL_BYTES) : 0));
     w.nchunks = (uint32_t)nchunks; w.ngroups = (uint32_t)ngroups;
     return TRC_OK;
 }
@@ -228,7 +235,9 @@ extern "C" int trc_encode_dev(int codec, const void *d_in, size_t n, uint32_t ch
     case TRC_ANSA:  trc_launch_ansa_enc(0, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 1; break;
     case TRC_ANSA4: trc_launch_ansa_enc(1, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 1; break;
     case TRC_ANSB:  trc_launch_ansb_enc((const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 1; break;
-    default:        if (is_vlc(codec)) { trc_launch_vlc_enc(vlc_variant(codec), vlc_elem(codec), (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 3; } break;
+    default:        if (is_vlc(codec)) { trc_launch_vlc_enc(vlc_variant(codec), vlc_elem(codec), (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 3; }
+                    else if (is_vla(codec)) { trc_launch_vla_enc(vla_variant(codec), vla_zz(codec), vla_elem(codec), (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 4; }
+                    break;
     case TRC_ANSO1: trc_launch_anso1_model((const uint8_t *)d_in, n, chunk, w, s);
                     trc_launch_ansa_code(0, n, chunk, w, d_clen, s); from_end = 1; break;
     }
@@ -271,7 +280,9 @@ extern "C" int trc_decode_dev(int codec, const uint32_t *d_clen, const void *d_p
     case TRC_ANSA4: trc_launch_ansa_dec(1, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     case TRC_ANSO1: trc_launch_anso1_dec((const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     case TRC_ANSB:  trc_launch_ansb_dec((const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
-    default:        if (is_vlc(codec)) trc_launch_vlc_dec(vlc_variant(codec), vlc_elem(codec), (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
+    default:        if (is_vlc(codec)) trc_launch_vlc_dec(vlc_variant(codec), vlc_elem(codec), (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s);
+                    else if (is_vla(codec)) trc_launch_vla_dec(vla_variant(codec), vla_zz(codec), vla_elem(codec), (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s);
+                    break;
     }
     tm_end(1, tmi);
     HIPCHK(hipGetLastError());
@@ -289,6 +300,7 @@ extern "C" const char *trc_kernel_name(int codec, int decode)
     case TRC_ANSO1: return decode ? "trc_o1_dec_kernel" : "trc_o1_model_kernel";
     case TRC_ANSB: return decode ? "trc_ansb_dec_kernel" : "trc_ansb_model_kernel";
     default: if (is_vlc(codec)) return decode ? "trc_vlc_dec_kernel" : "trc_vlc_enc_kernel";
+             if (is_vla(codec)) return decode ? "trc_vla_dec_kernel" : "trc_vla_model_kernel";
     }
     return "";
 }
@@ -520,6 +532,22 @@ size_t ansbd(unsigned char *in, size_t outlen, unsigned char *out) { return host
 TRC_EXPORT_VLC(rccdfu, TRC_VLCU)
 TRC_EXPORT_VLC(rccdfv, TRC_VLCV)
 TRC_EXPORT_VLC(rccdfvz, TRC_VLCVZ)
+// ... and over the adaptive CDF rANS (reference anscdf.c:139-483, dispatch :820-833; turborc -e60..63)
+#define TRC_EXPORT_VLA(name, bits, codec) \
+    size_t name##enc##bits(unsigned char *in, size_t inlen, unsigned char *out) { return host_encode(codec, in, inlen, out, nullptr, 0); } \
+    size_t name##dec##bits(unsigned char *in, size_t outlen, unsigned char *out) { return host_decode(codec, in, outlen, out, nullptr, 0); } \
+    size_t name##enc##bits##0(unsigned char *in, size_t inlen, unsigned char *out) { return host_encode(codec, in, inlen, out, nullptr, 0); } \
+    size_t name##dec##bits##0(unsigned char *in, size_t outlen, unsigned char *out) { return host_decode(codec, in, outlen, out, nullptr, 0); } \
+    size_t name##enc##bits##s(unsigned char *in, size_t inlen, unsigned char *out) { return host_encode(codec, in, inlen, out, nullptr, 0); } \
+    size_t name##dec##bits##s(unsigned char *in, size_t outlen, unsigned char *out) { return host_decode(codec, in, outlen, out, nullptr, 0); } \
+    size_t name##enc##bits##x(unsigned char *in, size_t inlen, unsigned char *out) { return host_encode(codec, in, inlen, out, nullptr, 0); } \
+    size_t name##dec##bits##x(unsigned char *in, size_t outlen, unsigned char *out) { return host_decode(codec, in, outlen, out, nullptr, 0); }
+TRC_EXPORT_VLA(anscdfu, 16, TRC_VLAU16)
+TRC_EXPORT_VLA(anscdfuz, 16, TRC_VLAUZ16)
+TRC_EXPORT_VLA(anscdfv, 16, TRC_VLAV16)
+TRC_EXPORT_VLA(anscdfvz, 16, TRC_VLAVZ16)
+TRC_EXPORT_VLA(anscdfv, 32, TRC_VLAV32)
+TRC_EXPORT_VLA(anscdfvz, 32, TRC_VLAVZ32)
 
 typedef size_t (*fanscdfenc)(unsigned char *in, size_t inlen, unsigned char *out);
 typedef size_t (*fanscdfdec)(unsigned char *in, size_t inlen, unsigned char *out);

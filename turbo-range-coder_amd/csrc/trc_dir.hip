@@ -103,7 +103,7 @@ void trc_launch_scan_groups(const uint32_t *gsum, uint32_t ngroups, uint64_t *go
 template <int PARTS>
 __global__ __launch_bounds__(256) void trc_gather_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks,
                                                          const u8 *__restrict__ scratch, u32 stride, int from_end,
-                                                         const u8 *__restrict__ scratch2, u32 stride2,
+                                                         const u8 *__restrict__ scratch2, u32 stride2, const u32 *__restrict__ aux,
                                                          const u32 *__restrict__ clen, const u64 *__restrict__ goff,
                                                          const u32 *__restrict__ gsum, u32 ngroups,
                                                          u8 *__restrict__ payload, u64 *__restrict__ total)
@@ -128,12 +128,14 @@ __global__ __launch_bounds__(256) void trc_gather_kernel(const u8 *__restrict__ 
             src_s[lane] = (u64)(uintptr_t)(raw ? in + cstart : from_end ? scratch + (u64)(c + 1) * stride - l : scratch + (u64)c * stride);
         } else {
             // from_end == 0: [4 + len0 bytes at the start of region A][rest at the start of region B], len0 = u32 at region A;
-            // from_end == 3: [la bytes at the start of the region][rest at its END], la = aux[c] (aux = scratch2 as u32[])
+            // from_end == 3: [la bytes at the start of the region][rest at its END], la = aux[2c]
+            // from_end == 4: [la bytes at the END of region A][rest at the END of region B]
             const u8 *a = scratch + (u64)c * stride;
-            const u32 la = (raw || c >= nchunks) ? l : from_end == 3 ? ((const u32 *)scratch2)[c] : 4u + *(const u32 *)a;   // raw: the input chunk is piece 0, piece 1 is empty
+            const u32 la = (raw || c >= nchunks) ? l : from_end >= 3 ? aux[2 * c] : 4u + *(const u32 *)a;   // raw: the input chunk is piece 0, piece 1 is empty
             ex_s[2 * lane] = inc - l; ex_s[2 * lane + 1] = inc - l + la;
-            src_s[2 * lane] = (u64)(uintptr_t)(raw ? in + cstart : a);
-            src_s[2 * lane + 1] = (u64)(uintptr_t)(from_end == 3 ? scratch + (u64)(c + 1) * stride - (l - la) : scratch2 + (u64)c * stride2);
+            src_s[2 * lane] = (u64)(uintptr_t)(raw ? in + cstart : from_end == 4 ? scratch + (u64)(c + 1) * stride - la : a);
+            src_s[2 * lane + 1] = (u64)(uintptr_t)(from_end == 3 ? scratch + (u64)(c + 1) * stride - (l - la) :
+                                                   from_end == 4 ? scratch2 + (u64)(c + 1) * stride2 - (l - la) : scratch2 + (u64)c * stride2);
         }
         if (lane == 63) ex_s[NP] = inc;
     }
@@ -214,11 +216,11 @@ void trc_launch_gather(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcW
 {
     if (from_end >= 2)                                         // two pieces per chunk: mode 2 (two regions) or 3 (both ends of one region)
         hipLaunchKernelGGL(trc_gather_kernel<2>, dim3(w.ngroups), dim3(256), 0, s, d_in, (u64)n, chunk, w.nchunks,
-                           w.scratch, w.stride, from_end == 3 ? 3 : 0, w.scratch2, w.stride2, d_clen, w.goff, w.gsum, w.ngroups,
+                           w.scratch, w.stride, from_end >= 3 ? from_end : 0, w.scratch2, w.stride2, w.aux, d_clen, w.goff, w.gsum, w.ngroups,
                            d_payload, w.goff ? (u64 *)nullptr : d_total);
     else
         hipLaunchKernelGGL(trc_gather_kernel<1>, dim3(w.ngroups), dim3(256), 0, s, d_in, (u64)n, chunk, w.nchunks,
-                           w.scratch, w.stride, from_end, w.scratch2, w.stride2, d_clen, w.goff, w.gsum, w.ngroups,
+                           w.scratch, w.stride, from_end, w.scratch2, w.stride2, w.aux, d_clen, w.goff, w.gsum, w.ngroups,
                            d_payload, w.goff ? (u64 *)nullptr : d_total);
 }
 

@@ -27,6 +27,7 @@ struct TrcWork {
     uint32_t  stride2;
     uint32_t  nchunks, ngroups;
     uint8_t  *model;     // ANSO1 only: one 136 KiB order-1 model per chunk
+    uint32_t *aux;       // Turbo-VLC coders: two u32 per chunk (length of the first payload piece; mantissa bits)
 };
 #define TRC_O1_MODEL_BYTES (256u * 17u * 32u)
 
@@ -94,9 +95,15 @@ void trc_launch_ansb_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_
                          const TrcWork &w, uint8_t *d_out, hipStream_t s);
 
 // Turbo-VLC integer coders (rccdf{u,v,vz}{enc,dec}{16,32}): variant 0 = u, 1 = v, 2 = vz; elem = 2 or 4 bytes;
-// scratch2 is a u32 per chunk (length of the range-coder piece, for gather mode 3)
+// aux[2c] = length of the range-coder piece (gather mode 3)
 void trc_launch_vlc_enc(int variant, int elem, const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s);
 void trc_launch_vlc_dec(int variant, int elem, const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
+                        const TrcWork &w, uint8_t *d_out, hipStream_t s);
+
+// ... over the adaptive CDF rANS (anscdf{u,uz,v,vz}{enc,dec}{16,32}): variant 0 = u, 1 = v; zz = zigzag-delta form;
+// scratch2 holds, per chunk, the record stack (8 B per element) and, at the end of the slot, the mantissa bytes
+void trc_launch_vla_enc(int variant, int zz, int elem, const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s);
+void trc_launch_vla_dec(int variant, int zz, int elem, const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                         const TrcWork &w, uint8_t *d_out, hipStream_t s);
 
 // cdfini on device

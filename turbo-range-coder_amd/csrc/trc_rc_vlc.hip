@@ -21,38 +21,8 @@
 #include "trc_rc.h"
 #include "trc_lane_io.h"
 #include "trc_nibmodel.h"
+#include "trc_vlc.h"
 #include "trc_launch.h"
-
-typedef u64 u64_a1 __attribute__((aligned(1)));
-
-// MSB-first bit string growing DOWN from `end` (byte k of the string at end[-1-k])
-struct LaneBitsDown {
-    u8 *end;             // one past the region's last byte (4-byte aligned)
-    u64 acc;             // pending bits, from bit 63 down
-    u32 nacc;            // pending bits (< 32 between calls)
-    u32 nwords;          // 32-bit groups already stored
-    u32 total;           // bits appended so far
-    __device__ __forceinline__ void start(u8 *e) { end = e; acc = 0; nacc = 0; nwords = 0; total = 0; }
-    __device__ __forceinline__ void put_if(bool take, u32 f, u32 ma)       // f <= 30 bits of ma
-    {
-        const u32 ff = take ? f : 0u;
-        acc |= (u64)(take ? ma : 0u) << ((64u - nacc - ff) & 63u);
-        nacc += ff; total += ff;
-        if (nacc >= 32u) {
-            *(u32 *)(end - 4u * (nwords + 1u)) = (u32)(acc >> 32);
-            acc <<= 32; nacc -= 32u; nwords++;
-        }
-    }
-    __device__ __forceinline__ u32 bytes() const { return 4u * nwords + ((nacc + 7u) >> 3); }
-    __device__ __forceinline__ void finish(bool ok)
-    {
-        const u32 nb = (nacc + 7u) >> 3;
-        for (u32 j = 0; j < nb; j++) if (ok) end[-(int)(4u * nwords + 1u + j)] = (u8)(acc >> (56u - 8u * j));
-    }
-};
-
-__device__ __forceinline__ u32 vlc_zigzag_enc(u32 d, bool wide) { return wide ? (d << 1) ^ (u32)((int)d >> 31) : ((d << 1) ^ (u32)((int)(short)d >> 15)) & 0xffffu; }
-__device__ __forceinline__ u32 vlc_zigzag_dec(u32 x) { return (x >> 1) ^ (0u - (x & 1u)); }
 
 template <int ES, int VN, bool ZZ>
 __global__ __launch_bounds__(64) void trc_vlc_enc_kernel(
@@ -134,7 +104,7 @@ __global__ __launch_bounds__(64) void trc_vlc_enc_kernel(
     }
     so.finish(alive && !ovf);
     bo.finish(alive && !ovf);
-    if (alive && !ovf) { *(u32 *)(scratch + (u64)c * stride) = out_len; aux[c] = la; }   // header: total
+    if (alive && !ovf) { *(u32 *)(scratch + (u64)c * stride) = out_len; aux[2u * c] = la; }   // header: total
     if (alive) clen[c] = out_len;
     const u32 gs = trc_wave_sum(out_len);
     if (lane == 0) gsum[wc.c0 >> 6] = gs;
@@ -240,7 +210,7 @@ template <int ES, int VN, bool ZZ>
 static void launch_vlc_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
 {
     TRC_LAUNCH_TIMED((trc_vlc_enc_kernel<ES, VN, ZZ>), dim3(w.ngroups), dim3(64), TRC_NIB2_BYTES, s,
-                     d_in, (u64)n, chunk, w.nchunks, w.scratch, w.stride, (u32 *)w.scratch2, d_clen, w.gsum);
+                     d_in, (u64)n, chunk, w.nchunks, w.scratch, w.stride, w.aux, d_clen, w.gsum);
 }
 template <int ES, int VN, bool ZZ>
 static void launch_vlc_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
