@@ -336,3 +336,24 @@ def test_c_harness_links_and_roundtrips(torch_cuda):
         r = subprocess.run([exe, "-I", "1", "-e", "50,52,53,60,61,62,63"] + args, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "MISMATCH" not in r.stdout and "failed" not in r.stdout, r.stdout + r.stderr
         assert r.stdout.count("Turbo vlc") == (7 if args[0] == "--int16" else 5), r.stdout
+
+
+def test_file_tool_roundtrips(torch_cuda, tmp_path):
+    """harness/trcfile.c: compress / decompress files through the reference-named functions"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "harness", "trcfile")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "harness")])
+    src = tmp_path / "in.bin"
+    for kind, n in (("text", 3000001), ("uniform", 200000), ("zipf", 1)):
+        gen(kind, n, 21).tofile(src)
+        for cid in (1, 42, 44, 45, 46, 47, 56, 64, 65, 66):
+            packed, back = tmp_path / ("p%d" % cid), tmp_path / ("b%d" % cid)
+            r = subprocess.run([exe, "c", str(cid), str(src), str(packed)], capture_output=True, text=True, timeout=120)
+            assert r.returncode == 0, r.stdout + r.stderr
+            r = subprocess.run([exe, "d", str(packed), str(back)], capture_output=True, text=True, timeout=120)
+            assert r.returncode == 0, r.stdout + r.stderr
+            assert np.array_equal(np.fromfile(back, dtype=np.uint8), np.fromfile(src, dtype=np.uint8)), (kind, cid)
+            if kind == "text":
+                assert os.path.getsize(packed) < 0.9 * n
