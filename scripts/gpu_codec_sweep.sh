@@ -8,7 +8,7 @@ for cdc in $1; do for ch in $2; do
 import json
 try:
     r=json.load(open('gpurun_out/sweep_tmp.json')); rf=r['roofline']
-    print('%-10s chunk %5d  encdec %8.0f MB/s  enc %8.0f dec %8.0f  kernels %.3f/%.3f ms  ratio %.4f' % ('$cdc', $ch, r['value'], r['enc_MBps'], r['dec_MBps'], rf['enc_kernel_ms'], rf['dec_kernel_ms'], r['config']['ratio']))
+    print('%-10s chunk %5d  encdec %8.0f MB/s  enc %8.0f dec %8.0f  kernels %.3f/%.3f ms  ratio %.4f' % ('$cdc', r['config']['chunk'], r['value'], r['enc_MBps'], r['dec_MBps'], rf['enc_kernel_ms'], rf['dec_kernel_ms'], r['config']['ratio']))
 except Exception as e:
     print('$cdc', $ch, 'FAILED', e); print(open('gpurun_out/sweep_err.log').read()[-600:])
 "
