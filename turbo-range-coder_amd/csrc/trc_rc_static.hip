@@ -61,16 +61,19 @@ __global__ __launch_bounds__(64) void trc_rcs_enc_kernel(
     for (u32 s = 0; s < S; s++) {
         tin.commit();
         if (s + 1 < S) tin.issue(wc, (s + 1) * TRC_SEG);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const u32 p0 = s * TRC_SEG + (u32)k * 16u;
+        // The piece and dword loops are kept as loops (registers rotate instead of being indexed): fully unrolled, the
+        // 64 coding steps of a segment with their carry paths were 94-174 KB of code, more than the instruction cache.
+        uint4 pc0 = tin.read(0), pc1 = tin.read(1), pc2 = tin.read(2), pc3 = tin.read(3);
+#pragma nounroll
+        for (u32 k = 0; k < 4; k++) {
+            uint4 v = pc0; pc0 = pc1; pc1 = pc2; pc2 = pc3;
+            const u32 p0 = s * TRC_SEG + k * 16u;
             const bool act = alive && !ovf && p0 < len;
             if (act && p0 + 16u <= len) {
-                const uint4 v = tin.read((u32)k);
-                const u32 w[4] = { v.x, v.y, v.z, v.w };
-#pragma unroll
-                for (int d = 0; d < 4; d++) {
-                    const u32 t0 = tab[w[d] & 255u], t1 = tab[(w[d] >> 8) & 255u], t2 = tab[(w[d] >> 16) & 255u], t3 = tab[w[d] >> 24];
+#pragma nounroll
+                for (u32 d = 0; d < 4; d++) {
+                    const u32 wd = v.x; v.x = v.y; v.y = v.z; v.z = v.w;
+                    const u32 t0 = tab[wd & 255u], t1 = tab[(wd >> 8) & 255u], t2 = tab[(wd >> 16) & 255u], t3 = tab[wd >> 24];
                     if (NS == 1) {
                         e0.sym(so0, t0 & 0xffffu, t0 >> 16); e0.sym(so0, t1 & 0xffffu, t1 >> 16);
                         e0.sym(so0, t2 & 0xffffu, t2 >> 16); e0.sym(so0, t3 & 0xffffu, t3 >> 16);
@@ -173,26 +176,32 @@ __global__ __launch_bounds__(896) void trc_rcs_dec_kernel(
     const u32 pairs = len & ~1u;
     u8 *dst = out + (u64)c * chunk;
     for (u32 s = 0; s < S; s++) {
+        // rolled like the encoder's loops (the refill protocol wants the period parity as a literal: pieces go in pairs)
+        uint4 pc0 = make_uint4(0, 0, 0, 0), pc1 = pc0, pc2 = pc0, pc3 = pc0;
+#pragma nounroll
+        for (u32 kk = 0; kk < 2; kk++) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const u32 p0 = s * TRC_SEG + (u32)k * 16u;
-            s0.period(coded && p0 < len, k & 1);
-            if (NS == 2) s1.period(coded && p0 < len, k & 1);
-            if (coded && p0 + 16u <= len) {
-                u32 w[4];
-#pragma unroll
-                for (int d = 0; d < 4; d++) {
-                    u32 x0, x1, x2, x3;
-                    if (NS == 1) { x0 = get(d0, s0); x1 = get(d0, s0); x2 = get(d0, s0); x3 = get(d0, s0); }
-                    else         { x0 = get(d0, s0); x1 = get(d1, s1); x2 = get(d0, s0); x3 = get(d1, s1); }
-                    w[d] = x0 | (x1 << 8) | (x2 << 16) | (x3 << 24);
+            for (int j = 0; j < 2; j++) {
+                const u32 p0 = s * TRC_SEG + (2u * kk + (u32)j) * 16u;
+                s0.period(coded && p0 < len, j);
+                if (NS == 2) s1.period(coded && p0 < len, j);
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (coded && p0 + 16u <= len) {
+#pragma nounroll
+                    for (u32 d = 0; d < 4; d++) {
+                        u32 x0, x1, x2, x3;
+                        if (NS == 1) { x0 = get(d0, s0); x1 = get(d0, s0); x2 = get(d0, s0); x3 = get(d0, s0); }
+                        else         { x0 = get(d0, s0); x1 = get(d1, s1); x2 = get(d0, s0); x3 = get(d1, s1); }
+                        v.x = v.y; v.y = v.z; v.z = v.w; v.w = x0 | (x1 << 8) | (x2 << 16) | (x3 << 24);
+                    }
+                } else if (coded && p0 < len) {
+                    for (u32 pos = p0; pos < len; pos++)
+                        dst[pos] = (u8)((NS == 2 && pos < pairs && (pos & 1u)) ? get(d1, s1) : get(d0, s0));
                 }
-                tout.put((u32)k, make_uint4(w[0], w[1], w[2], w[3]));
-            } else if (coded && p0 < len) {
-                for (u32 pos = p0; pos < len; pos++)
-                    dst[pos] = (u8)((NS == 2 && pos < pairs && (pos & 1u)) ? get(d1, s1) : get(d0, s0));
+                pc0 = pc1; pc1 = pc2; pc2 = pc3; pc3 = v;
             }
         }
+        tout.put(0, pc0); tout.put(1, pc1); tout.put(2, pc2); tout.put(3, pc3);
         tout.flush(wc, s * TRC_SEG);
     }
     u64 rawmask = __ballot(alive && cl == len && len != 0);
