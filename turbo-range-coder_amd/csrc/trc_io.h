@@ -188,6 +188,11 @@ struct StreamOut {
         *(u16 *)(rings + trc_raddr(trc_lane(), roff16(wpos))) = (u16)v;
         wpos += take ? 2u : 0u;
     }
+    __device__ __forceinline__ void put32_if(bool take, u32 v)          // same, 32-bit unit (a full ring is drained before 4 bytes are missing)
+    {
+        *(u32 *)(rings + trc_raddr(trc_lane(), roff32(wpos))) = v;
+        wpos += take ? 4u : 0u;
+    }
     __device__ __forceinline__ void put16(u32 v) { *(u16 *)(rings + trc_raddr(trc_lane(), roff16(wpos))) = (u16)v; wpos += 2; }
     __device__ __forceinline__ void put32(u32 v) { *(u32 *)(rings + trc_raddr(trc_lane(), roff32(wpos))) = v; wpos += 4; }
 

@@ -43,10 +43,7 @@ struct RcEnc {
     template <class SO>
     __device__ __forceinline__ void sym(SO &so, u32 c0, u32 f)          // _rccdfenc_ + renorm
     {
-        range >>= TRC_PROB_BITS;
-        low += range * c0;
-        range *= f;
-        renorm(so);
+        sym_if(so, true, c0, f);                                        // the common renorm without a branch (rccdfs: 192 -> 181 us)
     }
     // predicated, branch-free in the common case: where !act nothing changes (model-bound coders, trc_rc_adaptive.hip)
     template <class SO>
