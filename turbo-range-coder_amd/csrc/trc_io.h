@@ -71,7 +71,7 @@ struct TileIn {
             row = row < w.rows ? row : w.rows - 1;
             // a short last chunk has no bytes in its upper segments: never read past the input's pad
             const u32 so = segoff < w.len_of(row) ? segoff : 0u;
-            r[j] = *(const uint4 *)(base + (size_t)row * w.chunk + so + part);
+            r[j] = trc_ld16_nt(base + (size_t)row * w.chunk + so + part);     // read once: do not keep it in the caches
         }
     }
     __device__ __forceinline__ void commit()
@@ -129,7 +129,7 @@ struct QuadIn {
             u32 row = (lane & ~3u) + (u32)j;
             row = row < w.rows ? row : w.rows - 1;
             const u32 so = segoff < w.len_of(row) ? segoff : 0u;     // never read past the input's pad
-            r[j] = *(const uint4 *)(base + (size_t)row * w.chunk + so + part);
+            r[j] = trc_ld16_nt(base + (size_t)row * w.chunk + so + part);     // read once: do not keep it in the caches
         }
     }
     __device__ __forceinline__ void commit()
@@ -160,7 +160,7 @@ struct QuadOut {
         for (int j = 0; j < 4; j++) {                          // m[j] = piece (lane&3) of the chunk of lane (lane&~3)+j
             const u32 row = (lane & ~3u) + (u32)j;
             if (row < w.rows && segoff + part + 16u <= w.len_of(row))
-                *(uint4 *)(base + (size_t)row * w.chunk + segoff + part) = make_uint4(m[j][0], m[j][1], m[j][2], m[j][3]);
+                trc_st16_nt(base + (size_t)row * w.chunk + segoff + part, make_uint4(m[j][0], m[j][1], m[j][2], m[j][3]));
         }
     }
 };
