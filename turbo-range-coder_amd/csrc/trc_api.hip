@@ -252,8 +252,8 @@ extern "C" int trc_decode_dev(int codec, const uint32_t *d_clen, const void *d_p
                               const uint16_t *d_cdf, unsigned cdfnum,
                               void *d_out, void *d_work, size_t work_bytes, void *stream)
 {
-    const bool tables_ready = codec & TRC_TABLES_READY;
-    codec &= ~TRC_TABLES_READY;
+    const bool tables_ready = codec & TRC_TABLES_READY, dir_ready = codec & TRC_DIR_READY;
+    codec &= ~(TRC_TABLES_READY | TRC_DIR_READY);
     int rc = check_common(codec, n, chunk, d_cdf, cdfnum);
     if (rc) return rc;
     if (n == 0) return TRC_OK;
@@ -263,8 +263,10 @@ extern "C" int trc_decode_dev(int codec, const uint32_t *d_clen, const void *d_p
     TrcWork w;
     if ((rc = carve(codec, n, chunk, d_work, work_bytes, w))) return rc;
     if (is_static(codec) && !tables_ready) trc_launch_static_prep(d_cdf, cdfnum, w.tables, s);
-    trc_launch_group_sums(d_clen, w.nchunks, n, chunk, w.gsum, s);
-    if (w.goff) trc_launch_scan_groups(w.gsum, w.ngroups, w.goff, nullptr, s);
+    if (!dir_ready) {
+        trc_launch_group_sums(d_clen, w.nchunks, n, chunk, w.gsum, s);
+        if (w.goff) trc_launch_scan_groups(w.gsum, w.ngroups, w.goff, nullptr, s);
+    }
     const int tmi = tm_begin(1);
     switch (codec) {
     case TRC_ANS4S: trc_launch_ans4s_dec((const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;

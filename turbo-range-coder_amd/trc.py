@@ -29,6 +29,7 @@ VLC_ELEM = {VLCU16: 2, VLCU32: 4, VLCV16: 2, VLCV32: 4, VLCVZ16: 2, VLCVZ32: 4,
 NIBBLE_CODECS = (RCA4, RCAI4, ANSA4)                           # `turborc -n` coders: input values 0..15
 STATIC = (ANS4S, RCS1, RCS2, RCSM)
 TABLES_READY = 0x100                                          # include/trc_hip.h
+DIR_READY = 0x200
 AVAILABLE = (ANS4S, RCS1, RCS2, RCB, RCA, ANSA, RCAI, RCA4, RCAI4, ANSA4, RCSM, ANSO1, ANSB) + VLC_CODECS          # codecs with HIP kernels behind them (grows per round)
 PAD = 256
 HDR = 32
@@ -167,12 +168,14 @@ class DeviceCoder:
                                   self.clen.data_ptr(), self.payload.data_ptr(), self.total.data_ptr(),
                                   self.work.data_ptr(), self.work_bytes, self._stream()))
 
-    def decode(self, d_out, n=None, clen=None, payload=None):
+    def decode(self, d_out, n=None, clen=None, payload=None, dir_ready=False):
+        """dir_ready: the workspace still holds the group sums of `clen` (the encode or decode just before this call
+        was for the same directory): TRC_DIR_READY, include/trc_hip.h"""
         n = self.n if n is None else n
         st = self.codec in STATIC
         clen = self.clen if clen is None else clen
         payload = self.payload if payload is None else payload
-        _chk(lib().trc_decode_dev(self.codec | self.tables_ready, clen.data_ptr(), payload.data_ptr(), n, self.chunk,
+        _chk(lib().trc_decode_dev(self.codec | self.tables_ready | (DIR_READY if dir_ready else 0), clen.data_ptr(), payload.data_ptr(), n, self.chunk,
                                   self.cdf.data_ptr() if st else None, self.cdfnum if st else 0,
                                   d_out.data_ptr(), self.work.data_ptr(), self.work_bytes, self._stream()))
 
