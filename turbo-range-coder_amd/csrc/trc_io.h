@@ -271,6 +271,7 @@ struct StreamIn {
     __device__ __forceinline__ u32 peek16() const { return *(const u16 *)(rings + trc_raddr(trc_lane(), rpos & (TRC_SRING - 1))); }
     __device__ __forceinline__ u32 peek32() const { return *(const u32 *)(rings + trc_raddr(trc_lane(), rpos & (TRC_SRING - 1))); }
     __device__ __forceinline__ u32 avail() const { return lbytes - rpos; }
+    __device__ __forceinline__ void skip_if(bool take) { rpos += take ? 4u : 0u; }
 
     // first fill: every live lane fetches its own first 128 bytes (8 independent loads, one round trip)
     __device__ __forceinline__ void prime(bool alive)
