@@ -170,6 +170,18 @@ __global__ __launch_bounds__(64) void trc_rca_dec_kernel(
     { const u32 a = s0.peek32(); s0.skip_if(coded); const u32 b = s0.peek32(); s0.skip_if(coded); d0.start(a, b); }
     { const u32 a = s1.peek32(); s1.skip_if(NS == 2 && coded); const u32 b = s1.peek32(); s1.skip_if(NS == 2 && coded); d1.start(a, b); }
 
+    // Table 0 (the hi-nibble table of the byte model, the only table of the nibble coders) is used at every step: it
+    // lives in registers for the whole chunk and never travels to LDS, which takes two of the four dependent LDS round
+    // trips out of every byte (one wave per SIMD: nothing else hides them).
+    NibTable T0 = m.load(m.table(0));
+    auto get0 = [&](RcDec &dq, LaneIn<4> &sq, bool act) -> u32 {
+        const u32 q = dq.quotient15();
+        u32 c0, c1;
+        const u32 x = trc_nib_find(T0, q, c0, c1);
+        dq.consume_if(sq, act, c0, c1);
+        m.adapt(T0, x);
+        return x;
+    };
     auto get = [&](RcDec &dq, LaneIn<4> &sq, u8 *tb, bool act) -> u32 {
         const u32 q = dq.quotient15();
         NibTable T = m.load(tb);
@@ -198,25 +210,23 @@ __global__ __launch_bounds__(64) void trc_rca_dec_kernel(
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
                             const bool act = coded && q0 + (u32)i < len;
-                            const u32 h = get(d0, s0, m.table(0), act);
+                            const u32 h = get0(d0, s0, act);
                             const u32 l = NS == 1 ? get(d0, s0, m.table(1u + h), act) : get(d1, s1, m.table(1u + h), act);
                             w |= (h << 4 | l) << (8 * i);
                         }
                     } else if (NS == 1) {
 #pragma unroll
-                        for (int i = 0; i < 4; i++) w |= get(d0, s0, m.table(0), coded && q0 + (u32)i < len) << (8 * i);
+                        for (int i = 0; i < 4; i++) w |= get0(d0, s0, coded && q0 + (u32)i < len) << (8 * i);
                     } else {
 #pragma unroll
                         for (int pr = 0; pr < 2; pr++) {       // both symbols searched in the table before the pair
                             const bool act0 = coded && q0 + 2u * (u32)pr < len, act1 = coded && q0 + 2u * (u32)pr + 1u < len;
-                            u8 *tb = m.table(0);
                             const u32 t0 = d0.quotient15(), t1 = d1.quotient15();
-                            NibTable T = m.load(tb);
                             u32 a0, a1, b0, b1;
-                            const u32 x0 = trc_nib_find(T, t0, a0, a1), x1 = trc_nib_find(T, t1, b0, b1);
+                            const u32 x0 = trc_nib_find(T0, t0, a0, a1), x1 = trc_nib_find(T0, t1, b0, b1);
                             d0.consume_if(s0, act0, a0, a1);
                             d1.consume_if(s1, act1, b0, b1);
-                            m.adapt(T, x0); m.adapt(T, x1); m.store(tb, T);
+                            m.adapt(T0, x0); m.adapt(T0, x1);
                             w |= (x0 | x1 << 8) << (16 * pr);
                         }
                     }
