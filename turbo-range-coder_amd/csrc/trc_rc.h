@@ -91,7 +91,6 @@ struct RcDec {
         const u32 a = si.peek32(); si.rpos += 4; const u32 b = si.peek32(); si.rpos += 4;
         start(a, b);
     }
-    __device__ __forceinline__ u32 slot() { range >>= TRC_PROB_BITS; return quotient(); }   // _rccdf: scale, then code/range
     // t = code / r for r = range >> 15 (the caller has NOT shifted range), branch-free: the f32 estimate is within
     // +-1 of the exact quotient (relative errors: operand truncation 2^-23, cvt 2^-24, v_rcp_f32 1 ulp, product 2^-24,
     // times t < 2^15 => < 0.02 absolute), so one correction step each way is exact for every valid stream.
@@ -122,37 +121,6 @@ struct RcDec {
         range = act ? (rn ? range2 << 32 : range2) : range;
         code = act ? (rn ? (code2 << 32) | w : code2) : code;
         si.skip_if(rn);
-    }
-    __device__ __forceinline__ void renorm(StreamIn &si)
-    {
-        const bool rn = range < TRC_TOP32;
-        const u32 w = si.peek32();
-        if (rn) { range <<= 32; code = (code << 32) | w; }
-        si.rpos += rn ? 4u : 0u;
-    }
-    // t = code / range exactly, for code < range * 2^15, 2^17 <= range < 2^49: f32 estimate of the
-    // quotient from the top 24 bits, then exact 64-bit correction.  Selects the same symbol as the
-    // reference's linear/binary/division searches (they all find x with cdf[x]*r <= code < cdf[x+1]*r).
-    __device__ __forceinline__ u32 quotient() const
-    {
-        const int bl = 64 - __clzll((long long)range);                   // bit length of range (18..49)
-        const int sh = bl > 24 ? bl - 24 : 0;                            // range >> sh is exact in f32
-        const float rf = (float)(u32)(range >> sh);
-        const u64 cs = code >> sh;                                       // < 2^39
-        const float cf = (float)(u32)(cs >> 16) * 65536.0f + (float)(u32)(cs & 0xffffu);
-        u32 t = (u32)(cf * __builtin_amdgcn_rcpf(rf));
-        if (t > TRC_PROB_ONE - 1) t = TRC_PROB_ONE - 1;
-        u64 p = range * t;
-        while (p > code) { t--; p -= range; }
-        while (code - p >= range && t < TRC_PROB_ONE - 1) { t++; p += range; }   // (bounded: corrupt input must not hang)
-        return t;
-    }
-    __device__ __forceinline__ void consume(StreamIn &si, u32 c0, u32 c1)   // _rccdfupdate + renorm
-    {
-        const u64 rp = range * c0;
-        range = range * c1 - rp;
-        code -= rp;
-        renorm(si);
     }
 };
 
