@@ -258,6 +258,40 @@ def test_many_groups_uses_scan_kernel(torch_cuda, codec):
         assert clen[c] == exp.size and np.array_equal(payload[off[c]:off[c + 1]], exp), "chunk %d" % c
 
 
+def test_config5_shard_one_gigabyte(torch_cuda):
+    """BASELINE config 5 gives every GPU a 1 GB shard of Zipf(1.1) bytes: static rANS at the bench chunk, 1 953 125 chunks,
+    30 518 groups (scan-kernel directory), eight residency rounds.  Round trip on device, directory consistency, sampled
+    chunks equal to the oracle.  (The shard is 20 rotated copies of a 50 MB Zipf sample: same statistics, one CDF.)"""
+    torch = torch_cuda
+    base_n, reps, chunk, codec = 50 * 1000 * 1000, 20, 512, trc.ANS4S
+    n = base_n * reps
+    base = gen("zipf", base_n, 11)
+    _, cdf, cdfnum = T.orc_cdfini(base)
+    b = torch.from_numpy(base).to("cuda:0")
+    d_in = torch.empty(n + 512, dtype=torch.uint8, device="cuda:0")
+    d_in[n:] = 0
+    for r in range(reps):
+        d_in[r * base_n:(r + 1) * base_n] = torch.roll(b, 4099 * r)
+    dc = trc.DeviceCoder(codec, n, chunk, "cuda:0")
+    dc.set_cdf(cdf, cdfnum)
+    dc.encode(d_in, n)
+    d_out = torch.zeros(n + 512, dtype=torch.uint8, device="cuda:0")
+    dc.decode(d_out, n)
+    torch.cuda.synchronize()
+    assert torch.equal(d_out[:n], d_in[:n]), "1 GB round trip failed"
+    nch = trc.nchunks(n, chunk)
+    clen = dc.clen[:nch].to(torch.int64)
+    total = int(dc.total[0].item())
+    assert int(clen.sum().item()) == total and total < n
+    off = torch.cumsum(clen, 0) - clen
+    for c in [0, 1, 63, 64, nch // 2, nch - 65, nch - 1] + list(np.random.default_rng(9).integers(0, nch, 40)):
+        c = int(c)
+        sl = d_in[c * chunk:(c + 1) * chunk].cpu().numpy()
+        exp = T.orc_enc(codec, sl, cdf, cdfnum)
+        o, l = int(off[c].item()), int(clen[c].item())
+        assert l == exp.size and np.array_equal(dc.payload[o:o + l].cpu().numpy(), exp), "chunk %d" % c
+
+
 @pytest.mark.parametrize("codec", trc.AVAILABLE, ids=lambda c: trc.CODEC_NAMES[c])
 def test_max_rate_bursts(torch_cuda, codec):
     """chunks that stay compressible overall but contain long bursts of the rarest symbols (frequency 1 in the
