@@ -58,13 +58,6 @@ struct RcEnc {
         range = act ? (rn ? range2 << 32 : range2) : range;
         mark = rn ? low : mark;
     }
-    template <class SO>
-    __device__ __forceinline__ void bit(SO &so, u32 p, u32 b)           // rcbe_: p = P(bit==1) * 2^15
-    {
-        const u64 cut = (range >> TRC_PROB_BITS) * p;
-        if (b) range = cut; else { low += cut; range -= cut; }
-        (void)so;
-    }
     // rceflush, then release everything still held back
     template <class SO>
     __device__ __forceinline__ void finish(SO &so)
