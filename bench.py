@@ -6,9 +6,10 @@
 
 A "step" = one encode pass + one decode pass of the hot path over this rank's 100 MB shard, inputs
 already resident in HBM (weak scaling: every rank codes its own 100 MB of independent chunks; for
-N > 1 the per-rank compressed payloads are gathered to rank 0 with RCCL inside the timed region --
-the path's only exchange step -- on a side stream, double-buffered, so the transfer of step k overlaps
-the decode of step k and the coding of step k+1; all K transfers complete inside the timed region).
+N > 1 the per-rank compressed payloads of every step are gathered onto one GPU with RCCL inside the
+timed region -- the path's only exchange step -- with the root rotating over the ranks and N steps per
+grouped exchange, on a side stream, double-buffered, so that the transfers of one group overlap the
+coding of the next; all K steps are gathered inside the timed region).
 value = bytes all ranks processed / max-over-ranks wall time, with
 MB = 10^6 (reference include_/time_.h:113,233), i.e. N / (t_enc + t_dec) per SURVEY 8d.
 
@@ -203,53 +204,83 @@ def main():
         assert int(dc.status[0].item()) > 0, "cdfini failed"
     d_out = torch.zeros(n + 512, dtype=torch.uint8, device=dev)
 
-    # multi-GPU exchange buffers: rank 0 receives every rank's directory slice + payload (variable size)
+    # ---- multi-GPU exchange (the path's only exchange step: the compressed results are gathered over xGMI) ----------
+    # Steps are exchanged in GROUPS of `world`: step j of a group is gathered onto rank j (shard.exchange_group: one
+    # all_gather of the sizes, then every transfer of the group in ONE grouped send/receive call).  With a fixed root
+    # only the root's links would carry payload and no step could be shorter than C / link (~0.65 ms against 0.2 ms of
+    # coding); with the root rotating every directed link carries one payload per `world` steps, all at the same time.
+    # The exchange of a group runs on a side stream while the next group is coded into the other bank of result
+    # buffers; a bank is reused only after its own exchange has finished (event).  The last, possibly partial, group
+    # of the timed region is flushed inside it: all K steps are gathered before the clock stops.
+    # TRC_BENCH_EXCHANGE=root0 selects the plain per-step gather to rank 0 (groups of one step, root 0).
     nch = trc.nchunks(n, chunk)
-    recv_clen = recv_payload = None
-    if world > 1 and rank == 0:
-        recv_clen = [torch.empty(nch, dtype=torch.int32, device=dev) for _ in range(world - 1)]
-        recv_payload = [torch.empty(n + 1024, dtype=torch.uint8, device=dev) for _ in range(world - 1)]
-
-    def exchange():
-        """RCCL gather of the compressed results to rank 0 (shard.py): all_gather of the sizes, then one
-        point-to-point transfer per peer -- over xGMI each rides its own direct link."""
-        shard.gather_to_root(dist, rank, world, dc.total[:1], dc.clen[:nch], dc.payload, recv_clen, recv_payload)
-
+    rotate = use_dist and os.environ.get("TRC_BENCH_EXCHANGE", "rotate") != "root0"
+    G = world if rotate else 1                                 # steps per exchange group
     side = torch.cuda.Stream(device=dev) if use_dist else None
-    # Two result buffers alternate, so that the gather of step k (side stream; one xGMI link per peer, ~C / 100 GB/s --
-    # several times the coding time of a step) runs while step k+1 is coded into the other buffer.  A buffer is
-    # reused only after its own gather has finished (event), gathers follow each other in order on the side stream.
-    bufs = [(dc.clen, dc.payload, dc.total)]
+
+    def new_result():
+        return (torch.zeros_like(dc.clen), torch.zeros_like(dc.payload), torch.zeros_like(dc.total))
+    banks = [[(dc.clen, dc.payload, dc.total)]]
+    recv = [None, None]
     if use_dist:
-        bufs.append((torch.zeros_like(dc.clen), torch.zeros_like(dc.payload), torch.zeros_like(dc.total)))
-    gathered = [None, None]
-    stepno = [0]
+        banks = [[new_result() for _ in range(G)] for _ in range(2)]
+        banks[0][0] = (dc.clen, dc.payload, dc.total)
+        if world > 1 and (rotate or rank == 0):                # this rank is the root of one step per group
+            recv = [([torch.empty(nch, dtype=torch.int32, device=dev) for _ in range(world - 1)],
+                     [torch.empty(n + 1024, dtype=torch.uint8, device=dev) for _ in range(world - 1)]) for _ in range(2)]
+    done = [None, None]
+
+    def exchange(bank, ns):
+        """gather the `ns` steps coded into `bank`: step j onto rank j (rotate) / onto rank 0 (root0: ns == 1)"""
+        res = banks[bank][:ns]
+        mine = rank if rotate else 0                           # the step of the group this rank is the root of
+        rc = rp = None
+        if recv[bank] is not None and mine < ns:
+            rc, rp = {mine: recv[bank][0]}, {mine: recv[bank][1]}
+        shard.exchange_group(dist, rank, world, [r[2][:1] for r in res], [r[0][:nch] for r in res], [r[1] for r in res], rc, rp)
 
     DIRR = os.environ.get('TRC_NO_DIRR') is None           # ablation knob: TRC_NO_DIRR=1 re-derives the group sums in every decode (-1.8 %)
 
-    def step():
-        b = stepno[0] % len(bufs)
-        stepno[0] += 1
+    pending = []                                               # the exchange of the group that has just been coded
+
+    def run_pending():
+        while pending:
+            bank, ns, coded = pending.pop(0)
+            side.wait_event(coded)                             # the exchange may start once the group's last encode is done
+            with torch.cuda.stream(side):
+                exchange(bank, ns)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                done[bank] = ev
+
+    def step(k, last):
         if not use_dist:
             dc.encode(d_in, n)
             dc.decode(d_out, n, dir_ready=DIRR)                # the encode just left this directory's group sums in the workspace
             return
+        j, bank = k % G, (k // G) % 2
         main = torch.cuda.current_stream(dev)
-        if gathered[b] is not None:
-            main.wait_event(gathered[b])                       # this buffer's previous gather is done
-        dc.clen, dc.payload, dc.total = bufs[b]
+        if j == 0 and done[bank] is not None:
+            main.wait_event(done[bank])                        # the previous exchange out of this bank is done
+        dc.clen, dc.payload, dc.total = banks[bank][j]
         dc.encode(d_in, n)
-        side.wait_stream(main)                                 # side stream: starts once this encode is done
-        dc.decode(d_out, n, dir_ready=DIRR)                    # main stream: local decode, enqueued first ...
-        with torch.cuda.stream(side):
-            exchange()                                         # ... so the host-side size sync in here overlaps it
-            ev = torch.cuda.Event()
-            ev.record(side)
-            gathered[b] = ev
+        coded = None
+        if j == G - 1 or last:
+            coded = torch.cuda.Event()
+            coded.record(main)
+        dc.decode(d_out, n, dir_ready=DIRR)
+        # The exchange reads the sizes on the host (one sync on the group's last encode).  It is issued one step late,
+        # after this step's kernels are in the queue, so that the GPU has work while the host waits.
+        run_pending()
+        if coded is not None:
+            pending.append((bank, j + 1, coded))
+        if last:
+            run_pending()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k, k == args.warmup - 1)
     torch.cuda.synchronize(dev)
+    done = [None, None]
     if not args.no_verify:
         assert torch.equal(d_out[:n], d_in[:n]), "round trip failed"
 
@@ -258,8 +289,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for k in range(args.steps):
+        step(k, k == args.steps - 1)
     torch.cuda.synchronize(dev)
     if use_dist:
         dist.barrier()
@@ -302,7 +333,7 @@ def main():
             "config": {"workload": "%s: %d B/GPU, %s, chunk %d B, 1 lane = 1 chunk, 64 chunks/wave"
                                    % (wname, n, CODEC_INFO[args.codec][0], chunk),
                        "codec": args.codec, "chunk": chunk, "bytes_per_gpu": n, "compressed_bytes_per_gpu": total_c,
-                       "ratio": round(total_c / n, 5), "exchange": "rccl gather of payloads to rank 0" if world > 1 else "none"},
+                       "ratio": round(total_c / n, 5), "exchange": ("none" if world == 1 else "rccl gather of every step's payloads, root rotating over the ranks, %d steps per grouped exchange" % G if rotate else "rccl gather of payloads to rank 0")},
             "enc_MBps": round(n / (enc_avg * 1e-3) / 1e6, 1) if enc_avg else None,
             "dec_MBps": round(n / (dec_avg * 1e-3) / 1e6, 1) if dec_avg else None,
             "roofline": {"bound": "hbm", "kernel": trc.lib().trc_kernel_name(codec, dom == "dec").decode(),

@@ -66,6 +66,52 @@ def test_two_rank_shard_gather_matches_single(codec, n, chunk):
     assert q.get(timeout=5) is True
 
 
+def _group_worker(rank, world, port, codec, n, chunk, nbatch, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        datas, totals, clens, payloads, cdfs = [], [], [], [], []
+        for j in range(nbatch):                                # batch j: its own data, its own CDF
+            data = T.zipf_bytes(n + 17 * j, 1.1, 256, 500 + j)
+            start, ln = shard.shard_bounds(data.size, world, chunk)[rank]
+            mine = data[start:start + ln]
+            _, cdf, cdfnum = T.orc_cdfini(data)
+            payload, clen, _ = T.orc_chunked_enc(codec, mine, chunk, cdf, cdfnum) if ln else (np.zeros(0, np.uint8), np.zeros(0, np.uint32), None)
+            datas.append(data); cdfs.append((cdf, cdfnum))
+            totals.append(torch.tensor([payload.size], dtype=torch.int64))
+            clens.append(torch.from_numpy(clen.view(np.int32).copy()))
+            payloads.append(torch.from_numpy(np.concatenate([payload, np.zeros(8, np.uint8)])))
+        sizes, got = shard.exchange_group(dist, rank, world, totals, clens, payloads)
+        assert sorted(got) == [j for j in range(nbatch) if j % world == rank]
+        for j, (cl, pl) in got.items():
+            data, (cdf, cdfnum) = datas[j], cdfs[j]
+            cont = shard.assemble_container(codec, data.size, chunk, cdfnum, [c.numpy().view(np.uint32) for c in cl], [p.numpy() for p in pl])
+            full_payload, full_clen, _ = T.orc_chunked_enc(codec, data, chunk, cdf, cdfnum)
+            ref = shard.assemble_container(codec, data.size, chunk, cdfnum, [full_clen], [full_payload])
+            assert [tuple(x) for x in sizes[j]] == [(int(p.numel()), int(c.numel())) for c, p in zip(cl, pl)]
+            q.put((j, bool(np.array_equal(cont, ref))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nbatch", [(2, 2), (3, 3), (3, 2), (3, 5), (2, 1)])
+def test_group_exchange_with_rotating_roots(world, nbatch):
+    """`exchange_group`: batch j of a group is gathered onto rank j % world, all transfers in one grouped call; every
+    assembled container must equal the single-process container of that batch (full groups, a partial group -- the
+    flush at the end of a run -- and a group longer than the world)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_group_worker, args=(r, world, port, T.ANS4S, 60001, 4096, nbatch, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(nbatch))
+    assert res == [(j, True) for j in range(nbatch)]
+
+
 def test_shard_bounds_cover_everything():
     for n, world, chunk in [(100, 2, 64), (10**6, 8, 4096), (4096, 8, 4096), (1, 4, 256)]:
         b = shard.shard_bounds(n, world, chunk)

@@ -7,6 +7,10 @@ inside the coders.  The only exchanges are
   * the gather of the per-rank results to rank 0: all_gather of the payload sizes, then one
     point-to-point transfer per peer (over xGMI each rides its own direct link; a ring would
     serialise on single links) for the directory slice and the payload.
+  * the same gather for a GROUP of batches at once (`exchange_group`): batch j of the group goes to root j mod world,
+    all transfers of the group in ONE grouped send/receive call.  With a fixed root only the root's links carry
+    payload and a step can never be shorter than C / link; with the roots rotating every directed link carries one
+    payload per `world` batches and all of them move at the same time.
 Everything here works on CPU tensors with the gloo backend too (tests/test_shard_gloo.py).
 """
 import struct
@@ -76,6 +80,59 @@ def gather_to_root(dist, rank, world, total, clen, payload, recv_clen=None, recv
         for w in dist.batch_isend_irecv(ops):
             w.wait()
     return sizes, cl, pl
+
+
+def exchange_group(dist, rank, world, totals, clens, payloads, recv_clen=None, recv_payload=None):
+    """Gather the results of len(totals) consecutive batches, batch j onto rank j % world, in one grouped P2P call.
+
+    totals[j]   : int64[1] tensor   this rank's payload bytes of batch j
+    clens[j]    : int32 tensor      this rank's chunk lengths of batch j (trimmed to its chunk count)
+    payloads[j] : uint8 tensor      at least totals[j] bytes
+    recv_*      : {j: list (len world-1, peers in rank order without the root) of receive tensors} for the batches
+                  this rank is the root of, or None to allocate
+    Returns (sizes, got): sizes[j][r] = (payload bytes, chunks) of rank r in batch j; got[j] = (clen list, payload
+    list) in rank order for the batches rooted here (this rank's own pieces included, not copied).
+    Pairs of ranks see their transfers in the same order on both sides (batch order, directory before payload), which
+    is all a grouped send/receive needs; a group of one batch rooted at rank 0 is `gather_to_root`.
+    """
+    import torch
+    ns = len(totals)
+    dev = totals[0].device
+    meta = torch.stack([t.reshape(()).to(torch.int64) for t in totals] +
+                       [torch.tensor(c.numel(), dtype=torch.int64, device=dev) for c in clens])
+    allmeta = torch.empty(2 * ns * world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(allmeta, meta)
+    m = allmeta.tolist()
+    sizes = [[(m[2 * ns * r + j], m[2 * ns * r + ns + j]) for r in range(world)] for j in range(ns)]
+    ops, got = [], {}
+    for j in range(ns):
+        root = j % world
+        if rank == root:
+            cl, pl, k = [], [], 0
+            for r in range(world):
+                tb, nc = sizes[j][r]
+                if r == rank:
+                    cl.append(clens[j]); pl.append(payloads[j][:tb])
+                    continue
+                c_r = recv_clen[j][k][:nc] if recv_clen else torch.empty(nc, dtype=clens[j].dtype, device=dev)
+                p_r = recv_payload[j][k][:tb] if recv_payload else torch.empty(tb, dtype=torch.uint8, device=dev)
+                k += 1
+                cl.append(c_r); pl.append(p_r)
+                if nc:
+                    ops.append(dist.P2POp(dist.irecv, c_r, r))
+                if tb:
+                    ops.append(dist.P2POp(dist.irecv, p_r, r))
+            got[j] = (cl, pl)
+        else:
+            tb, nc = sizes[j][rank]
+            if nc:
+                ops.append(dist.P2POp(dist.isend, clens[j], root))
+            if tb:
+                ops.append(dist.P2POp(dist.isend, payloads[j][:tb], root))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return sizes, got
 
 
 def assemble_container(codec, n, chunk, cdfnum, clens, payloads):
