@@ -277,6 +277,11 @@ def main():
         if last:
             run_pending()
 
+    if use_dist and G > 1:                                     # untimed set-up: one full group, so that every pair of ranks has
+        for k in range(G):                                     # its point-to-point connection before the warmup steps run
+            step(k, k == G - 1)
+        torch.cuda.synchronize(dev)
+        done = [None, None]
     for k in range(args.warmup):
         step(k, k == args.warmup - 1)
     torch.cuda.synchronize(dev)
