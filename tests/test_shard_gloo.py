@@ -81,7 +81,13 @@ def _group_worker(rank, world, port, codec, n, chunk, nbatch, q):
             totals.append(torch.tensor([payload.size], dtype=torch.int64))
             clens.append(torch.from_numpy(clen.view(np.int32).copy()))
             payloads.append(torch.from_numpy(np.concatenate([payload, np.zeros(8, np.uint8)])))
-        sizes, got = shard.exchange_group(dist, rank, world, totals, clens, payloads)
+        # pre-allocated receive buffers (what bench.py passes) for the batches rooted here, on odd worlds; allocation inside otherwise
+        rc = rp = None
+        if world % 2:
+            mine = [j for j in range(nbatch) if j % world == rank]
+            rc = {j: [torch.empty(4096, dtype=torch.int32) for _ in range(world - 1)] for j in mine}
+            rp = {j: [torch.empty(n + 4096, dtype=torch.uint8) for _ in range(world - 1)] for j in mine}
+        sizes, got = shard.exchange_group(dist, rank, world, totals, clens, payloads, rc, rp)
         assert sorted(got) == [j for j in range(nbatch) if j % world == rank]
         for j, (cl, pl) in got.items():
             data, (cdf, cdfnum) = datas[j], cdfs[j]
