@@ -258,14 +258,14 @@ def main():
             dc.encode(d_in, n)
             dc.decode(d_out, n, dir_ready=DIRR)                # the encode just left this directory's group sums in the workspace
             return
-        j, bank = k % G, (k // G) % 2
+        j, bank, ns = shard.group_plan(k, G, last)
         main = torch.cuda.current_stream(dev)
         if j == 0 and done[bank] is not None:
             main.wait_event(done[bank])                        # the previous exchange out of this bank is done
         dc.clen, dc.payload, dc.total = banks[bank][j]
         dc.encode(d_in, n)
         coded = None
-        if j == G - 1 or last:
+        if ns:
             coded = torch.cuda.Event()
             coded.record(main)
         dc.decode(d_out, n, dir_ready=DIRR)
@@ -273,7 +273,7 @@ def main():
         # after this step's kernels are in the queue, so that the GPU has work while the host waits.
         run_pending()
         if coded is not None:
-            pending.append((bank, j + 1, coded))
+            pending.append((bank, ns, coded))
         if last:
             run_pending()
 

@@ -118,6 +118,24 @@ def test_group_exchange_with_rotating_roots(world, nbatch):
     assert res == [(j, True) for j in range(nbatch)]
 
 
+def test_group_plan_exchanges_every_step_once():
+    """the schedule bench.py follows at N > 1: every step lands in exactly one exchange, groups fill slots 0..ns-1 of one
+    bank, consecutive groups alternate banks, and only the last group of a run may be partial"""
+    for group in range(1, 9):
+        for steps in range(1, 41):
+            seen, open_slots, groups = [], [], []
+            for k in range(steps):
+                j, bank, ns = shard.group_plan(k, group, k == steps - 1)
+                assert j == len(open_slots) and (not open_slots or open_slots[-1][1] == bank)
+                open_slots.append((k, bank))
+                if ns:
+                    assert ns == len(open_slots)
+                    groups.append((bank, ns)); seen += [x[0] for x in open_slots]; open_slots = []
+            assert not open_slots and seen == list(range(steps))
+            assert all(a[0] != b[0] for a, b in zip(groups, groups[1:]))
+            assert all(ns == group for _, ns in groups[:-1])
+
+
 def test_shard_bounds_cover_everything():
     for n, world, chunk in [(100, 2, 64), (10**6, 8, 4096), (4096, 8, 4096), (1, 4, 256)]:
         b = shard.shard_bounds(n, world, chunk)

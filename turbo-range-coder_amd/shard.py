@@ -82,6 +82,14 @@ def gather_to_root(dist, rank, world, total, clen, payload, recv_clen=None, recv
     return sizes, cl, pl
 
 
+def group_plan(k, group, last):
+    """Where step k of a run goes when results are exchanged `group` steps at a time out of two alternating banks of
+    result buffers: -> (slot in the group, bank, ns) with ns = number of steps to exchange once this step is coded
+    (0: the group is still filling; the group's size when it is complete, or its fill when `last` flushes it)."""
+    j, bank = k % group, (k // group) % 2
+    return j, bank, (j + 1 if (j == group - 1 or last) else 0)
+
+
 def exchange_group(dist, rank, world, totals, clens, payloads, recv_clen=None, recv_payload=None):
     """Gather the results of len(totals) consecutive batches, batch j onto rank j % world, in one grouped P2P call.
 
