@@ -36,54 +36,54 @@ int cdfini(unsigned char *in, size_t inlen, cdf_t *cdf, unsigned cdfnum);
 /* static-CDF range coder, one stream (reference rccdf.c:71-122).  The four reference decoders differ
  * only in how they search the CDF (linear / binary / division+linear / division+binary) and decode
  * the same stream; all four names are served by the same kernel. */
-size_t rccdfsenc(unsigned char *in, size_t inlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum);
-size_t rccdfsldec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum);
-size_t rccdfsbdec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum);
-size_t rccdfsvldec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum);
-size_t rccdfsvbdec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum);
+size_t rccdfsenc(unsigned char *src, size_t srclen, unsigned char *dst, cdf_t *cdf, unsigned cdfnum);
+size_t rccdfsldec(unsigned char *src, size_t dstlen, unsigned char *dst, cdf_t *cdf, unsigned cdfnum);
+size_t rccdfsbdec(unsigned char *src, size_t dstlen, unsigned char *dst, cdf_t *cdf, unsigned cdfnum);
+size_t rccdfsvldec(unsigned char *src, size_t dstlen, unsigned char *dst, cdf_t *cdf, unsigned cdfnum);
+size_t rccdfsvbdec(unsigned char *src, size_t dstlen, unsigned char *dst, cdf_t *cdf, unsigned cdfnum);
 
 /* the one-stream static coder with a 32-bit range and 16-bit I/O (reference rccdf.c:648-694, include/turborc.h:521-526;
  * `turborc -e44`).  A different bitstream from rccdfsenc.  The reference decoders divide through a reciprocal table;
  * both names decode the same stream here (exact division). */
-size_t rccdfsmenc(unsigned char *in, size_t inlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum);
-size_t rccdfsmldec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum);
-size_t rccdfsmbdec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum);
+size_t rccdfsmenc(unsigned char *src, size_t srclen, unsigned char *dst, cdf_t *cdf, unsigned cdfnum);
+size_t rccdfsmldec(unsigned char *src, size_t dstlen, unsigned char *dst, cdf_t *cdf, unsigned cdfnum);
+size_t rccdfsmbdec(unsigned char *src, size_t dstlen, unsigned char *dst, cdf_t *cdf, unsigned cdfnum);
 
 /* static-CDF range coder, two interleaved streams (reference rccdf.c:125-184; `turborc -e45`) */
-size_t rccdfs2enc(unsigned char *in, size_t inlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum);
-size_t rccdfsl2dec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum);
-size_t rccdfsb2dec(unsigned char *in, size_t outlen, unsigned char *out, cdf_t *cdf, unsigned cdfnum);
+size_t rccdfs2enc(unsigned char *src, size_t srclen, unsigned char *dst, cdf_t *cdf, unsigned cdfnum);
+size_t rccdfsl2dec(unsigned char *src, size_t dstlen, unsigned char *dst, cdf_t *cdf, unsigned cdfnum);
+size_t rccdfsb2dec(unsigned char *src, size_t dstlen, unsigned char *dst, cdf_t *cdf, unsigned cdfnum);
 
 /* adaptive-CDF byte range coder (reference rccdf.c:187-211; `turborc -e46`) */
-size_t rccdfenc(unsigned char *in, size_t inlen, unsigned char *out);
-size_t rccdfdec(unsigned char *in, size_t outlen, unsigned char *out);
+size_t rccdfenc(unsigned char *src, size_t srclen, unsigned char *dst);
+size_t rccdfdec(unsigned char *src, size_t dstlen, unsigned char *dst);
 
 /* adaptive-CDF byte range coder, hi nibbles on stream 0 / lo nibbles on stream 1 (reference rccdf.c:213-249,
  * include/turborc.h:515-516; `turborc -e47`) */
-size_t rccdfienc(unsigned char *in, size_t inlen, unsigned char *out);
-size_t rccdfidec(unsigned char *in, size_t outlen, unsigned char *out);
+size_t rccdfienc(unsigned char *src, size_t srclen, unsigned char *dst);
+size_t rccdfidec(unsigned char *src, size_t dstlen, unsigned char *dst);
 
 /* the `turborc -n` coders: adaptive-CDF range coder on values 0..15, one CDF16 table (reference rccdf.c:250-275 and,
  * two interleaved streams, rccdf.c:277-323; include/turborc.h:517-519,528-529; harness ids 46/47 when the data is
  * nibble-valued, turborc.c:499-501).  Values above 15 are outside the reference's contract; their low nibble is coded. */
-size_t rccdf4enc(unsigned char *in, size_t inlen, unsigned char *out);
-size_t rccdf4dec(unsigned char *in, size_t outlen, unsigned char *out);
-size_t rccdf4ienc(unsigned char *in, size_t inlen, unsigned char *out);
-size_t rccdf4idec(unsigned char *in, size_t outlen, unsigned char *out);
+size_t rccdf4enc(unsigned char *src, size_t srclen, unsigned char *dst);
+size_t rccdf4dec(unsigned char *src, size_t dstlen, unsigned char *dst);
+size_t rccdf4ienc(unsigned char *src, size_t srclen, unsigned char *dst);
+size_t rccdf4idec(unsigned char *src, size_t dstlen, unsigned char *dst);
 
 /* Turbo-VLC integer coders over the adaptive CDF range coder (reference rccdf.c:391-632, include/turborc.h:536-549;
  * `turborc -e50/52/53` on 16- or 32-bit input): u = 6-bit exponent, v = 7-bit exponent, vz = v on the zigzag of the
  * delta to the previous element.  inlen/outlen are BYTES (multiples of the element size). */
-size_t rccdfuenc16(unsigned char *in, size_t inlen, unsigned char *out);   size_t rccdfudec16(unsigned char *in, size_t outlen, unsigned char *out);
-size_t rccdfuenc32(unsigned char *in, size_t inlen, unsigned char *out);   size_t rccdfudec32(unsigned char *in, size_t outlen, unsigned char *out);
-size_t rccdfvenc16(unsigned char *in, size_t inlen, unsigned char *out);   size_t rccdfvdec16(unsigned char *in, size_t outlen, unsigned char *out);
-size_t rccdfvenc32(unsigned char *in, size_t inlen, unsigned char *out);   size_t rccdfvdec32(unsigned char *in, size_t outlen, unsigned char *out);
-size_t rccdfvzenc16(unsigned char *in, size_t inlen, unsigned char *out);  size_t rccdfvzdec16(unsigned char *in, size_t outlen, unsigned char *out);
-size_t rccdfvzenc32(unsigned char *in, size_t inlen, unsigned char *out);  size_t rccdfvzdec32(unsigned char *in, size_t outlen, unsigned char *out);
+size_t rccdfuenc16(unsigned char *src, size_t srclen, unsigned char *dst);   size_t rccdfudec16(unsigned char *src, size_t dstlen, unsigned char *dst);
+size_t rccdfuenc32(unsigned char *src, size_t srclen, unsigned char *dst);   size_t rccdfudec32(unsigned char *src, size_t dstlen, unsigned char *dst);
+size_t rccdfvenc16(unsigned char *src, size_t srclen, unsigned char *dst);   size_t rccdfvdec16(unsigned char *src, size_t dstlen, unsigned char *dst);
+size_t rccdfvenc32(unsigned char *src, size_t srclen, unsigned char *dst);   size_t rccdfvdec32(unsigned char *src, size_t dstlen, unsigned char *dst);
+size_t rccdfvzenc16(unsigned char *src, size_t srclen, unsigned char *dst);  size_t rccdfvzdec16(unsigned char *src, size_t dstlen, unsigned char *dst);
+size_t rccdfvzenc32(unsigned char *src, size_t srclen, unsigned char *dst);  size_t rccdfvzdec32(unsigned char *src, size_t dstlen, unsigned char *dst);
 
 /* bitwise order-0 range coder, "s" predictor (reference rc_.c:37-58; `turborc -e1`, file codec 1) */
-size_t rcsenc(unsigned char *in, size_t inlen, unsigned char *out);
-size_t rcsdec(unsigned char *in, size_t outlen, unsigned char *out);
+size_t rcsenc(unsigned char *src, size_t srclen, unsigned char *dst);
+size_t rcsdec(unsigned char *src, size_t dstlen, unsigned char *dst);
 
 #ifdef __cplusplus
 }
