@@ -18,9 +18,20 @@ the enwik8 stand-in of SURVEY 8d (no corpus, no network); set ENWIK8=/path/to/en
 file.  Coder: static-CDF rANS, payload(chunk) bit-identical to anscdf4senc(chunk); CDF from cdfini
 on device (untimed, as in the reference harness turborc.c:429-433).
 
+Other workloads (each prints its own JSON line, same contract):
+  --workload zipf1g   BASELINE config 5's per-GPU shard: 10^9 Zipf(1.1) bytes generated ON THE DEVICE (seed 1000+rank),
+                      static rANS, sampled chunks checked against the oracle after the timed region
+  --workload mix100m  heterogeneous stretches (text / incompressible / runs / constant, 1-64 KiB each): lanes of a wave
+                      differ in rate, raw chunks sit among coded ones
+
 Extra objects on the JSON line:
   roofline      dominant coder kernel: algorithmic bytes (N + C) per launch / mean launch duration
                 measured with HIP events recorded around that kernel on its own stream, vs 8 TB/s HBM
+  flags         what the timed region leans on: TABLES_READY (coder tables derived once per CDF, untimed, as the
+                reference harness builds its CDF untimed) and DIR_READY (the decode of a step reuses the directory sums
+                its encode left in the workspace); value_cold = the same steps with both off
+  payload_sha256  SHA-256 of the payload area the last timed step produced on rank 0 (the committed reference hash for
+                the default configurations is in tests/golden/bench_configs.json)
   cpu_baseline  the reference (oracle/_ref) or, where absent, the oracle port, 1 thread, on a bounded
                 sample of the same workload (rank 0, N = 1 only)
 """
@@ -153,17 +164,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--size", type=int, default=100 * 1000 * 1000, help="bytes per GPU")
+    ap.add_argument("--size", type=int, default=0, help="bytes per GPU (default 100 MB; zipf1g: 1 GB)")
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("TRC_BENCH_CHUNK", "0")),
                     help="chunk bytes (parallel unit); default: the coder's throughput optimum at 100 MB per GPU -- 512 = 12 resident "
                          "waves per CU for the static rANS; payload ratio cost vs 4096: +1.6 %% (DESIGN.md)")
     ap.add_argument("--codec", default="anscdf4s")
+    ap.add_argument("--workload", default="default", choices=["default", "zipf1g", "mix100m"])
     ap.add_argument("--cpu-sample", type=int, default=32 * 1000 * 1000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-cold", action="store_true", help="skip the value_cold pass (flags off)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the exchange code even with 1 rank (self-test)")
     args = ap.parse_args()
 
+    import hashlib
     import torch
     import shard
     import trc
@@ -187,9 +201,20 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     codec = {v: k for k, v in trc.CODEC_NAMES.items()}[args.codec]
-    n, chunk = args.size, args.chunk or BEST_CHUNK.get(args.codec, 512)
-    d, wname = make_input(n, rank, CODEC_INFO[args.codec][1])
-    d_in = torch.from_numpy(np.concatenate([d, np.zeros(512, np.uint8)])).to(dev)
+    n = args.size or (1000 * 1000 * 1000 if args.workload == "zipf1g" else 100 * 1000 * 1000)
+    chunk = args.chunk or BEST_CHUNK.get(args.codec, 512)
+    d = None                                                   # host copy of the workload (None: it exists on the device only)
+    if args.workload == "zipf1g":                              # BASELINE config 5: 1 GB of Zipf(1.1) per GPU, generated on the device
+        seed = 1000 + rank
+        d_in = torch.zeros(n + 512, dtype=torch.uint8, device=dev)
+        T.table_bytes_device(torch, dev, n, T.zipf_weights(1.1, 256), seed, out=d_in)
+        wname = "zipf%dm (Zipf(1.1) bytes generated on the device, seed %d)" % (n // 1000000, seed)
+    else:
+        if args.workload == "mix100m":
+            d, wname = T.mix_bytes(n, 13 + rank), "mix%dm" % (n // 1000000)
+        else:
+            d, wname = make_input(n, rank, CODEC_INFO[args.codec][1])
+        d_in = torch.from_numpy(np.concatenate([d, np.zeros(512, np.uint8)])).to(dev)
     dc = trc.DeviceCoder(codec, n, chunk, dev)
     cdfnum = 256
     if codec in trc.STATIC:                                # untimed, like the reference harness (turborc.c:429-433)
@@ -205,87 +230,51 @@ def main():
     d_out = torch.zeros(n + 512, dtype=torch.uint8, device=dev)
 
     # ---- multi-GPU exchange (the path's only exchange step: the compressed results are gathered over xGMI) ----------
-    # Steps are exchanged in GROUPS of `world`: step j of a group is gathered onto rank j (shard.exchange_group: one
-    # all_gather of the sizes, then every transfer of the group in ONE grouped send/receive call).  With a fixed root
-    # only the root's links would carry payload and no step could be shorter than C / link (~0.65 ms against 0.2 ms of
-    # coding); with the root rotating every directed link carries one payload per `world` steps, all at the same time.
-    # The exchange of a group runs on a side stream while the next group is coded into the other bank of result
-    # buffers; a bank is reused only after its own exchange has finished (event).  The last, possibly partial, group
-    # of the timed region is flushed inside it: all K steps are gathered before the clock stops.
-    # TRC_BENCH_EXCHANGE=root0 selects the plain per-step gather to rank 0 (groups of one step, root 0).
+    # shard.StepPipeline holds the schedule (groups of `world` steps, step j of a group gathered onto rank j, one grouped
+    # send/receive call per group on a side stream, two banks of result buffers); tests/test_shard_gloo.py drives the
+    # same class with CPU tensors.  TRC_BENCH_EXCHANGE=root0 selects the plain per-step gather to rank 0.
     nch = trc.nchunks(n, chunk)
     rotate = use_dist and os.environ.get("TRC_BENCH_EXCHANGE", "rotate") != "root0"
     G = world if rotate else 1                                 # steps per exchange group
-    side = torch.cuda.Stream(device=dev) if use_dist else None
+    DIRR = os.environ.get('TRC_NO_DIRR') is None               # ablation knob: TRC_NO_DIRR=1 re-derives the group sums in every decode
 
-    def new_result():
-        return (torch.zeros_like(dc.clen), torch.zeros_like(dc.payload), torch.zeros_like(dc.total))
-    banks = [[(dc.clen, dc.payload, dc.total)]]
-    recv = [None, None]
+    def encode(result):
+        dc.clen, dc.payload, dc.total = result
+        dc.encode(d_in, n)
+
+    def decode(result, dir_ready=None):
+        dc.decode(d_out, n, dir_ready=DIRR if dir_ready is None else dir_ready)   # the encode just left this directory's group sums in the workspace
+
+    own = (dc.clen, dc.payload, dc.total)
+    pipe = None
     if use_dist:
+        def new_result():
+            return (torch.zeros_like(dc.clen), torch.zeros_like(dc.payload), torch.zeros_like(dc.total))
         banks = [[new_result() for _ in range(G)] for _ in range(2)]
-        banks[0][0] = (dc.clen, dc.payload, dc.total)
+        banks[0][0] = own
+        recv = [None, None]
         if world > 1 and (rotate or rank == 0):                # this rank is the root of one step per group
             recv = [([torch.empty(nch, dtype=torch.int32, device=dev) for _ in range(world - 1)],
                      [torch.empty(n + 1024, dtype=torch.uint8, device=dev) for _ in range(world - 1)]) for _ in range(2)]
-    done = [None, None]
-
-    def exchange(bank, ns):
-        """gather the `ns` steps coded into `bank`: step j onto rank j (rotate) / onto rank 0 (root0: ns == 1)"""
-        res = banks[bank][:ns]
-        mine = rank if rotate else 0                           # the step of the group this rank is the root of
-        rc = rp = None
-        if recv[bank] is not None and mine < ns:
-            rc, rp = {mine: recv[bank][0]}, {mine: recv[bank][1]}
-        shard.exchange_group(dist, rank, world, [r[2][:1] for r in res], [r[0][:nch] for r in res], [r[1] for r in res], rc, rp)
-
-    DIRR = os.environ.get('TRC_NO_DIRR') is None           # ablation knob: TRC_NO_DIRR=1 re-derives the group sums in every decode (-1.8 %)
-
-    pending = []                                               # the exchange of the group that has just been coded
-
-    def run_pending():
-        while pending:
-            bank, ns, coded = pending.pop(0)
-            side.wait_event(coded)                             # the exchange may start once the group's last encode is done
-            with torch.cuda.stream(side):
-                exchange(bank, ns)
-                ev = torch.cuda.Event()
-                ev.record(side)
-                done[bank] = ev
+        pipe = shard.StepPipeline(dist, rank, world, G, banks, recv, nch, shard.CudaRuntime(torch, dev), rotate=rotate)
 
     def step(k, last):
-        if not use_dist:
-            dc.encode(d_in, n)
-            dc.decode(d_out, n, dir_ready=DIRR)                # the encode just left this directory's group sums in the workspace
-            return
-        j, bank, ns = shard.group_plan(k, G, last)
-        main = torch.cuda.current_stream(dev)
-        if j == 0 and done[bank] is not None:
-            main.wait_event(done[bank])                        # the previous exchange out of this bank is done
-        dc.clen, dc.payload, dc.total = banks[bank][j]
-        dc.encode(d_in, n)
-        coded = None
-        if ns:
-            coded = torch.cuda.Event()
-            coded.record(main)
-        dc.decode(d_out, n, dir_ready=DIRR)
-        # The exchange reads the sizes on the host (one sync on the group's last encode).  It is issued one step late,
-        # after this step's kernels are in the queue, so that the GPU has work while the host waits.
-        run_pending()
-        if coded is not None:
-            pending.append((bank, ns, coded))
-        if last:
-            run_pending()
+        if pipe is None:
+            encode(own)
+            decode(own)
+        else:
+            pipe.step(k, last, encode, decode)
 
-    if use_dist and G > 1:                                     # untimed set-up: one full group, so that every pair of ranks has
+    if pipe is not None and G > 1:                             # untimed set-up: one full group, so that every pair of ranks has
         for k in range(G):                                     # its point-to-point connection before the warmup steps run
             step(k, k == G - 1)
         torch.cuda.synchronize(dev)
-        done = [None, None]
+        pipe.reset()
     for k in range(args.warmup):
         step(k, k == args.warmup - 1)
     torch.cuda.synchronize(dev)
-    done = [None, None]
+    if pipe is not None:
+        pipe.reset()
     if not args.no_verify:
         assert torch.equal(d_out[:n], d_in[:n]), "round trip failed"
 
@@ -310,13 +299,51 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    total_c = int(dc.total[0].item())
+    # ---- after the clock: the same steps with nothing carried over between calls (N = 1) ---------------------------
+    cold = None
+    if world == 1 and pipe is None and not args.no_cold:
+        ready, dc.tables_ready = dc.tables_ready, 0            # tables derived from the CDF inside every call
+        ksteps = max(1, min(args.steps, 10))
+        for _ in range(2):
+            encode(own); decode(own, dir_ready=False)
+        torch.cuda.synchronize(dev)
+        c0 = time.perf_counter()
+        for _ in range(ksteps):
+            encode(own); decode(own, dir_ready=False)           # ... and the directory sums re-derived by the decode
+        torch.cuda.synchronize(dev)
+        cdt = time.perf_counter() - c0
+        dc.tables_ready = ready
+        cold = (n * ksteps / cdt / 1e6, cdt / ksteps * 1e3, ksteps)
+
+    last_result = own if pipe is None else pipe.banks[shard.group_plan(args.steps - 1, G, True)[1]][shard.group_plan(args.steps - 1, G, True)[0]]
+    total_c = int(last_result[2][0].item())
+    sha = clen_sha = None
+    checked = None
+    if rank == 0:
+        sha = hashlib.sha256(last_result[1][:total_c].cpu().numpy().tobytes()).hexdigest()
+        clen_sha = hashlib.sha256(last_result[0][:nch].cpu().numpy().view(np.uint32).astype("<u4").tobytes()).hexdigest()
+        if args.workload == "zipf1g" and not args.no_verify:
+            # sampled chunks against the oracle: the slice is regenerated on the host from the same stream (which also
+            # pins the device generator), coded by the oracle, compared with the bytes the last timed step produced
+            clen64 = last_result[0][:nch].to(torch.int64) & 0xffffffff
+            off = torch.cumsum(clen64, 0) - clen64
+            cdf_h = np.zeros(257, dtype=np.uint16); cdf_h[:cdfnum + 1] = dc.cdf[:cdfnum + 1].cpu().numpy().view(np.uint16)
+            picks = sorted(set([0, 1, 63, 64, nch // 2, nch - 65, nch - 1] + [int(x) for x in np.random.default_rng(9).integers(0, nch, 57)]))
+            for c in picks:
+                ln = min(chunk, n - c * chunk)
+                sl = T.table_bytes_range(c * chunk, ln, T.zipf_weights(1.1, 256), 1000 + rank)
+                assert np.array_equal(sl, d_in[c * chunk:c * chunk + ln].cpu().numpy()), "device generator differs from the host stream at chunk %d" % c
+                exp = T.orc_enc(codec, sl, cdf_h, cdfnum)
+                o, l = int(off[c].item()), int(clen64[c].item())
+                assert l == exp.size and np.array_equal(last_result[1][o:o + l].cpu().numpy(), exp), "chunk %d differs from the oracle" % c
+            checked = len(picks)
+
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = (n * world * args.steps) / dt / 1e6
         enc_avg = enc_ms / max(enc_cnt, 1)
         dec_avg = dec_ms / max(dec_cnt, 1)
-        # dominant kernel = the slower of the two coder kernels; algorithmic bytes = N + C per launch
+        # dominant kernel = the slower of the two directions' coder kernels; algorithmic bytes = N + C per launch
         dom = "enc" if enc_avg >= dec_avg else "dec"
         dom_ms = max(enc_avg, dec_avg)
         alg_bytes = n + total_c
@@ -325,13 +352,14 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                if n == 100 * 1000 * 1000:                          # the PMC passes were taken on the default workload
+                if n == 100 * 1000 * 1000 and args.workload == "default":   # the PMC passes were taken on the default workload
                     traffic = json.load(open(tpath)).get("%s_%s_chunk%d" % (args.codec, dom, chunk))
             except Exception:
                 traffic = None
+        default_metric = args.codec == "anscdf4s" and args.workload == "default" and n == 100 * 1000 * 1000
         res = {
-            "metric": ("encode+decode MB/s, order-0 static-CDF rANS, 100 MB bytes" if args.codec == "anscdf4s"
-                       else "encode+decode MB/s, %s, %d bytes" % (args.codec, n)),
+            "metric": ("encode+decode MB/s, order-0 static-CDF rANS, 100 MB bytes" if default_metric
+                       else "encode+decode MB/s, %s, %s, %d bytes per GPU" % (args.codec, wname.split(" ")[0], n)),
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
@@ -339,18 +367,32 @@ def main():
                                    % (wname, n, CODEC_INFO[args.codec][0], chunk),
                        "codec": args.codec, "chunk": chunk, "bytes_per_gpu": n, "compressed_bytes_per_gpu": total_c,
                        "ratio": round(total_c / n, 5), "exchange": ("none" if world == 1 else "rccl gather of every step's payloads, root rotating over the ranks, %d steps per grouped exchange" % G if rotate else "rccl gather of payloads to rank 0")},
+            "flags": ["TABLES_READY", "DIR_READY"] if (codec in trc.STATIC and DIRR) else (["DIR_READY"] if DIRR else (["TABLES_READY"] if codec in trc.STATIC else [])),
+            "value_cold": round(cold[0], 1) if cold else None,
+            "ms_per_step_cold": round(cold[1], 4) if cold else None,
+            "payload_sha256": sha, "clen_sha256": clen_sha,
             "enc_MBps": round(n / (enc_avg * 1e-3) / 1e6, 1) if enc_avg else None,
             "dec_MBps": round(n / (dec_avg * 1e-3) / 1e6, 1) if dec_avg else None,
             "roofline": {"bound": "hbm", "kernel": trc.lib().trc_kernel_name(codec, dom == "dec").decode(),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "alg_bytes_per_launch": alg_bytes,
-                         "enc_kernel_ms": round(enc_avg, 4), "dec_kernel_ms": round(dec_avg, 4), "launches_timed": enc_cnt},
+                         "enc_kernel_ms": round(enc_avg, 4), "dec_kernel_ms": round(dec_avg, 4), "launches_timed": enc_cnt,
+                         "timed": "HIP event pairs on every coder-kernel launch of a call (two-pass encoders: both passes summed); directory and gather kernels are in ms_per_step only"},
         }
+        if checked is not None:
+            res["oracle_checked_chunks"] = checked
+        gold = os.path.join(ROOT, "tests", "golden", "bench_configs.json")
+        if args.workload == "default" and os.path.exists(gold) and "ENWIK8" not in os.environ:
+            for e in json.load(open(gold)):
+                if e["codec"] == args.codec and e["chunk"] == chunk and e["n"] == n:
+                    res["payload_matches_reference_sha256"] = bool(e["payload_sha256"] == sha and e["clen_sha256"] == clen_sha)
         if world == 1 and not args.no_cpu:
+            if d is None:                                      # device-only workload: time the CPU on the first bytes of the same stream
+                d = T.table_bytes_range(0, min(n, 100 * 1000 * 1000), T.zipf_weights(1.1, 256), 1000 + rank)
             cdf = dc.cdf[:cdfnum + 1].cpu().numpy().view(np.uint16).copy()
             cdf_full = np.zeros(257, dtype=np.uint16); cdf_full[:cdfnum + 1] = cdf
-            res["cpu_baseline"] = cpu_baseline(codec, d, cdf_full, cdfnum, min(args.cpu_sample, n))
+            res["cpu_baseline"] = cpu_baseline(codec, d, cdf_full, cdfnum, min(args.cpu_sample, d.size))
         print(json.dumps(res))
     if use_dist:
         dist.destroy_process_group()

@@ -60,6 +60,7 @@ int main(int argc, char **argv)
         unsigned char *in = slurp(argv[3], &n);
         if (!in) return 2;
         unsigned char *out = malloc(n + n / 3 + 1024);
+        if (!out) { perror("malloc"); return 2; }
         cdf_t cdf[257];
         unsigned m = 0;
         size_t l = n;
@@ -94,9 +95,15 @@ int main(int argc, char **argv)
         if (pick(id, &e3, &d3, &e5, &d5)) { fprintf(stderr, "unknown id %d\n", id); return 2; }
         size_t pos = 24;
         cdf_t cdf[257];
-        if (d5) { memcpy(cdf, fb + pos, (m + 2) * sizeof(cdf_t)); pos += (m + 2) * sizeof(cdf_t); }
-        if (pos + stored > fl) { fprintf(stderr, "truncated file\n"); return 2; }
+        if (d5) {
+            if (pos + (m + 2) * sizeof(cdf_t) > fl) { fprintf(stderr, "truncated file\n"); return 2; }
+            memcpy(cdf, fb + pos, (m + 2) * sizeof(cdf_t)); pos += (m + 2) * sizeof(cdf_t);
+        }
+        if (stored > fl - pos || stored != fl - pos || stored > raw) { fprintf(stderr, "truncated or padded file\n"); return 2; }
+        /* untrusted input: the decoders take no input length, so the container is validated against what was read */
+        if (stored != raw && trc_container_check(fb + pos, (size_t)stored, 0, (size_t)raw)) { fprintf(stderr, "corrupt file: %s\n", trc_last_error()); return 2; }
         unsigned char *out = malloc(raw + 1024);
+        if (!out) { perror("malloc"); return 2; }
         if (stored == raw) memcpy(out, fb + pos, raw);                    /* stored: the caller copies (CCPY) */
         else if ((d3 ? d3(fb + pos, raw, out) : d5(fb + pos, raw, out, cdf, m + 1)) != raw) { fprintf(stderr, "decode failed: %s\n", trc_last_error()); return 1; }
         FILE *f = fopen(argv[3], "wb");

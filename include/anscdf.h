@@ -134,6 +134,9 @@ LIBAPI size_t anscdf4decx(unsigned char *src, size_t dstlen, unsigned char *dst)
 /* dispatch globals of the reference (include/anscdf.h:27-35); they point at the functions above */
 typedef LIBAPI size_t (*fanscdfenc)(unsigned char *src, size_t srclen, unsigned char *dst);
 typedef LIBAPI size_t (*fanscdfdec)(unsigned char *src, size_t srclen, unsigned char *dst);
+/* static-CDF forms (reference include/anscdf.h:29-30) */
+typedef LIBAPI size_t (*fanscdf4senc)(unsigned char *src, size_t srclen, unsigned char *dst, cdf_t *cdf);
+typedef LIBAPI size_t (*fanscdf4sdec)(unsigned char *src, size_t srclen, unsigned char *dst, cdf_t *cdf);
 #ifdef __cplusplus
 extern "C" {
 #endif

@@ -142,10 +142,19 @@ int trc_decode_dev(int codec, const uint32_t *d_clen, const void *d_payload, siz
                    const uint16_t *d_cdf, unsigned cdfnum,
                    void *d_out, void *d_work, size_t work_bytes, void *stream);
 
-/* Optional per-launch timing of the dominant (coder) kernel: its launch carries a HIP event pair
- * (hipExtLaunchKernel start/stop events on the caller's stream), so the duration is the kernel's own.
- * enable(1) resets the counters; read() waits for the recorded events and returns the summed
- * duration and the number of launches measured (at most 1024 per direction between two enable() calls). */
+/* Validate a TRC1 container held in buf[0..buflen) BEFORE handing it to a reference-named decoder: those prototypes
+ * carry no input length, so a caller reading untrusted files must check that everything the decoder will touch lies
+ * inside its buffer.  Checks header fields, codec (0 = any), the original length (outlen, (size_t)-1 = any), that the
+ * directory fits, and that the directory's lengths add up to exactly the stated payload, which must end inside
+ * buflen.  Host-only (no GPU needed).  Returns TRC_OK or TRC_E_ARG (text in trc_last_error()). */
+int trc_container_check(const void *buf, size_t buflen, int codec, size_t outlen);
+
+/* Optional timing of the coder kernels: every coder launch of a call carries a HIP event pair (hipExtLaunchKernel
+ * start/stop events on the caller's stream), so the durations are the kernels' own -- BOTH passes of the two-pass
+ * rANS encoders and the order-1 model fill included (the directory/gather kernels are not coder kernels).
+ * enable(1) resets the counters; read() waits for the recorded events and returns the summed duration and the
+ * number of encode (decode) CALLS measured: total_ms / launches = coder-kernel time of one call (at most 4096
+ * kernel launches per direction between two enable() calls).  Thread-safe. */
 int trc_timing_enable(int on);
 int trc_timing_read(int decode, double *total_ms, int *launches);
 

@@ -76,3 +76,20 @@ def test_no_cpu_coding_path(lib):
         assert f(d.ctypes.data, d.size, out.ctypes.data) == 0, name
         assert b"no HIP device" in lib.trc_last_error(), name
         assert not out.any(), name                           # nothing was written
+
+
+def test_headers_compile_as_plain_c(tmp_path):
+    """include/turborc.h + include/anscdf.h are plain C a TurboRC-style caller can include: prototypes, cdf_t, the
+    dispatch typedefs of the reference (include/anscdf.h:27-30) and its globals (:32-35)"""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('''
+#include "turborc.h"
+#include "anscdf.h"
+#include "trc_hip.h"
+fanscdfenc e = anscdfenc; fanscdfdec d = anscdfdec;
+fanscdf4senc se = anscdf4senc; fanscdf4sdec sd = anscdf4sdec;
+size_t f(unsigned char *a, size_t n, unsigned char *b, cdf_t *c) { return _anscdfenc(a, n, b) + se(a, n, b, c) + rccdfs2enc(a, n, b, c, 256); }
+''')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)])
+    subprocess.check_call(["g++", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-x", "c++", str(src)])

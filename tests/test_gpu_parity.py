@@ -407,3 +407,132 @@ def test_file_tool_roundtrips(torch_cuda, tmp_path):
             assert np.array_equal(np.fromfile(back, dtype=np.uint8), np.fromfile(src, dtype=np.uint8)), (kind, cid)
             if kind == "text":
                 assert os.path.getsize(packed) < 0.9 * n
+
+
+def test_reference_harness_runs_on_the_gpu_library(torch_cuda, tmp_path):
+    """oracle/_ref/turborc_hip is the REFERENCE's own harness (turborc.c bench(), turborc.c:420-579) and its non-hot
+    objects linked, unchanged, against libturborc_hip.so by scripts/link_reference_harness.sh (build container only; the
+    binary travels like the reference oracle build).  Its hot ids call cdfini / rccdfs2enc / anscdfenc / ... by the
+    reference's names; its own memcheck (turborc.c:287-295) verifies every round trip, and the compressed size it prints
+    must be the TRC1 container of per-chunk reference payloads."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", "turborc_hip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/turborc_hip not built (scripts/link_reference_harness.sh --install, build container only)")
+    n, chunk = 3000001, 1024
+    env = dict(os.environ, TRC_CHUNK=str(chunk))
+    ansi = re.compile(r"[\b]+")
+
+    def rows(out):
+        got = {}
+        for line in ansi.sub(" ", out).splitlines():
+            m = re.match(r"\s*(\d+)\s+([\d.]+)%.*?\s(\d+):\S", line)
+            if m:
+                got[int(m.group(3))] = int(m.group(1))
+        return got
+
+    d = gen("text", n, 33)
+    src = tmp_path / "text.bin"
+    d.tofile(src)
+    _, cdf, cdfnum = T.orc_cdfini(d)
+    m1 = int(d.max()) + 1
+    r = subprocess.run([exe, "-I1", "-J1", "-e1,42,43,44,45,46,47,56,57,58,64,66", str(src)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "ERROR" not in r.stdout and "ERROR" not in r.stderr, r.stdout[-3000:] + r.stderr[-2000:]
+    got = rows(r.stdout)
+    ids = {1: trc.RCB, 42: trc.RCS1, 43: trc.RCS1, 44: trc.RCSM, 45: trc.RCS2, 46: trc.RCA, 47: trc.RCAI, 56: trc.ANSA, 57: trc.ANSA,
+           58: trc.ANSA, 64: trc.ANSO1, 66: trc.ANSB}
+    nch = trc.nchunks(n, chunk)
+    for i, codec in ids.items():
+        assert i in got, (i, r.stdout[-3000:])
+        _, exp_clen, _ = T.orc_chunked_enc(codec, d, chunk, cdf, m1)       # the harness passes cdfnum = max symbol + 1
+        assert got[i] == 32 + 4 * nch + int(exp_clen.sum()), (i, got[i])
+    # `turborc -n`: values 0..15 -> the one-table coders and the static rANS id 65 (harness gate m<16)
+    r = subprocess.run([exe, "-n", "-I1", "-J1", "-e42,45,46,47,56,65", str(src)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "ERROR" not in r.stdout and "ERROR" not in r.stderr, r.stdout[-3000:] + r.stderr[-2000:]
+    got = rows(r.stdout)
+    dn = (d & 15).astype(np.uint8)
+    _, cdfn, _ = T.orc_cdfini(dn)
+    mn = int(dn.max()) + 1
+    for i, codec in {42: trc.RCS1, 45: trc.RCS2, 46: trc.RCA4, 47: trc.RCAI4, 56: trc.ANSA4, 65: trc.ANS4S}.items():
+        assert i in got, (i, r.stdout[-3000:])
+        _, exp_clen, _ = T.orc_chunked_enc(codec, dn, chunk, cdfn, mn)
+        assert got[i] == 32 + 4 * nch + int(exp_clen.sum()), (i, got[i])
+
+
+with open(os.path.join(GOLD, "bench_configs.json")) as _f:
+    BENCH_GOLD = {e["name"]: e for e in json.load(_f)}
+
+
+@pytest.mark.parametrize("cfg", T.BENCH_CONFIGS, ids=lambda c: c["name"])
+def test_bench_config_total_parity(torch_cuda, cfg):
+    """TOTAL (not sampled) parity at the exact configurations bench.py reports on: the whole length directory and the
+    whole payload of the 100 MB workload equal (a) the committed SHA-256 of the REFERENCE's per-chunk outputs
+    (tests/golden/bench_configs.json, generated through oracle/_ref) and (b) the oracle port, byte for byte."""
+    import hashlib
+    torch = torch_cuda
+    g = BENCH_GOLD[cfg["name"]]
+    n, chunk, codec = cfg["n"], cfg["chunk"], cfg["codec"]
+    d = T.bench_input(cfg["kind"], n, cfg["seed"])
+    assert hashlib.sha256(d.tobytes()).hexdigest() == g["in_sha256"], "workload generator drifted"
+    d_in = to_dev(torch, d)
+    dc = trc.DeviceCoder(codec, n, chunk, "cuda:0")
+    cdf, cdfnum = None, 0
+    if codec in trc.STATIC:
+        dc.cdfini(d_in, n, 256)                                 # as bench.py does: cdfini on device
+        torch.cuda.synchronize()
+        cdf = np.zeros(257, dtype=np.uint16)
+        cdf[:257] = dc.cdf[:257].cpu().numpy().view(np.uint16)
+        cdfnum = 256
+        assert hashlib.sha256(cdf[:257].tobytes()).hexdigest() == g["cdf_sha256"], "device cdfini differs from the reference's"
+    dc.encode(d_in, n)
+    clen, payload = dc.result(n)
+    assert payload.size == g["payload_bytes"] and clen.size == g["nchunks"]
+    assert hashlib.sha256(clen.astype("<u4").tobytes()).hexdigest() == g["clen_sha256"], "length directory differs from the reference"
+    assert hashlib.sha256(payload.tobytes()).hexdigest() == g["payload_sha256"], "payload differs from the reference"
+    exp_payload, exp_clen = T.orc_chunked_enc_mt(codec, d, chunk, cdf, cdfnum)
+    assert np.array_equal(clen, exp_clen) and np.array_equal(payload, exp_payload), "differs from the oracle port"
+    d_out = torch.zeros(n + 512, dtype=torch.uint8, device="cuda:0")
+    dc.decode(d_out, n)
+    torch.cuda.synchronize()
+    assert torch.equal(d_out[:n], d_in[:n]), "round trip failed"
+
+
+ALIASES = {
+    trc.RCS1: [("rccdfsenc", d) for d in ("rccdfsldec", "rccdfsbdec", "rccdfsvldec", "rccdfsvbdec")],
+    trc.RCS2: [("rccdfs2enc", "rccdfsl2dec"), ("rccdfs2enc", "rccdfsb2dec")],
+    trc.RCSM: [("rccdfsmenc", "rccdfsmldec"), ("rccdfsmenc", "rccdfsmbdec")],
+    trc.ANS4S: [("anscdf4senc" + v, "anscdf4sdec" + v) for v in ("", "0", "s", "x")],
+    trc.ANSA: [("anscdfenc" + v, "anscdfdec" + v) for v in ("", "0", "s", "x")],
+    trc.ANSA4: [("anscdf4enc" + v, "anscdf4dec" + v) for v in ("", "0", "s", "x")],
+    trc.ANSO1: [("anscdf1enc" + v, "anscdf1dec" + v) for v in ("", "0", "s", "x")],
+    trc.VLAU16: [("anscdfuenc16" + v, "anscdfudec16" + v) for v in ("", "0", "s", "x")],
+    trc.VLAUZ16: [("anscdfuzenc16" + v, "anscdfuzdec16" + v) for v in ("", "0", "s", "x")],
+    trc.VLAV16: [("anscdfvenc16" + v, "anscdfvdec16" + v) for v in ("", "0", "s", "x")],
+    trc.VLAVZ16: [("anscdfvzenc16" + v, "anscdfvzdec16" + v) for v in ("", "0", "s", "x")],
+    trc.VLAV32: [("anscdfvenc32" + v, "anscdfvdec32" + v) for v in ("", "0", "s", "x")],
+    trc.VLAVZ32: [("anscdfvzenc32" + v, "anscdfvzdec32" + v) for v in ("", "0", "s", "x")],
+}
+
+
+@pytest.mark.parametrize("codec", sorted(ALIASES), ids=lambda c: trc.CODEC_NAMES[c])
+def test_every_alias_entry_point_is_called(torch_cuda, codec):
+    """the reference exports several names per coder -- the linear/binary/division decoders of the static range coders
+    (the harness picks the `l` forms when m<16, turborc.c:495-498), the per-ISA `0/s/x` builds of the rANS coders
+    (ids 57/58) -- all of them must RUN here, not just exist: every (encoder, decoder) name pair is called through the
+    host-pointer layer, its container compared with the oracle and decoded back."""
+    chunk = 1024
+    assert trc.lib().trc_set_chunk(chunk) == 0
+    try:
+        for kind, n in (("zipf", 50001), ("nibble", 20000)):
+            d = fit(codec, gen(kind, n, 57))
+            _, cdf, cdfnum = T.orc_cdfini(d)
+            exp_payload, exp_clen, _ = T.orc_chunked_enc(codec, d, chunk, cdf, cdfnum)
+            for en, dn in ALIASES[codec]:
+                comp = trc.host_encode(codec, d, cdf, cdfnum, name=en)
+                _, clen, payload = trc.parse_container(comp)
+                assert np.array_equal(clen, exp_clen) and np.array_equal(payload, exp_payload), en
+                assert np.array_equal(trc.host_decode(codec, comp, n, cdf, cdfnum, name=dn), d), dn
+    finally:
+        trc.lib().trc_set_chunk(4096)

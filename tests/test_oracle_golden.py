@@ -121,3 +121,20 @@ def test_vlc_encode_matches_golden_and_roundtrips(codec):
         assert np.array_equal(T.orc_dec(codec, o, ent["n"]), d)
         seen += 1
     assert seen == 52
+
+
+def test_headline_bench_config_hash():
+    """the oracle port on the WHOLE headline workload (text100m, chunk 512, static rANS) reproduces the committed hash of
+    the reference's per-chunk outputs (tests/golden/bench_configs.json, generated through oracle/_ref)"""
+    import hashlib
+    with open(os.path.join(GOLD, "bench_configs.json")) as f:
+        g = {e["name"]: e for e in json.load(f)}["anscdf4s-text100m-512"]
+    cfg = [c for c in T.BENCH_CONFIGS if c["name"] == g["name"]][0]
+    d = T.bench_input(cfg["kind"], cfg["n"], cfg["seed"])
+    assert hashlib.sha256(d.tobytes()).hexdigest() == g["in_sha256"]
+    r, cdf, cdfnum = T.orc_cdfini(d, 256)
+    assert r == d.size and hashlib.sha256(cdf[:257].tobytes()).hexdigest() == g["cdf_sha256"]
+    payload, clen = T.orc_chunked_enc_mt(cfg["codec"], d, cfg["chunk"], cdf, cdfnum)
+    assert payload.size == g["payload_bytes"]
+    assert hashlib.sha256(clen.astype("<u4").tobytes()).hexdigest() == g["clen_sha256"]
+    assert hashlib.sha256(payload.tobytes()).hexdigest() == g["payload_sha256"]

@@ -118,6 +118,82 @@ def test_group_exchange_with_rotating_roots(world, nbatch):
     assert res == [(j, True) for j in range(nbatch)]
 
 
+def _pipeline_worker(rank, world, port, group, steps, prealloc, q):
+    """bench.py's N>1 schedule (shard.StepPipeline) with CPU tensors: the oracle stands in for the HIP coder"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        codec, n, chunk = T.ANS4S, 40001, 1024
+        start, ln = shard.shard_bounds(n, world, chunk)[rank]
+        nch = (ln + chunk - 1) // chunk
+        cap = ln + 64
+
+        def step_data(k):
+            return T.zipf_bytes(n, 1.1, 256, 700 + k)
+
+        def new_result():
+            return (torch.zeros(nch + 8, dtype=torch.int32), torch.zeros(cap, dtype=torch.uint8), torch.zeros(2, dtype=torch.int64))
+        rotate = group > 1
+        banks = [[new_result() for _ in range(group)] for _ in range(2)]
+        recv = [None, None]
+        if prealloc and (rotate or rank == 0):
+            recv = [([torch.empty(64, dtype=torch.int32) for _ in range(world - 1)], [torch.empty(n + 64, dtype=torch.uint8) for _ in range(world - 1)])
+                    for _ in range(2)]
+        seen = []
+
+        def on_gathered(first, sizes, got):
+            for j, (cl, pl) in got.items():
+                data = step_data(first + j)
+                _, cdf, cdfnum = T.orc_cdfini(data)
+                cont = shard.assemble_container(codec, n, chunk, cdfnum, [c.numpy().view(np.uint32) for c in cl], [p.numpy() for p in pl])
+                fp, fc, _ = T.orc_chunked_enc(codec, data, chunk, cdf, cdfnum)
+                ref = shard.assemble_container(codec, n, chunk, cdfnum, [fc], [fp])
+                seen.append((first + j, bool(np.array_equal(cont, ref))))
+
+        pipe = shard.StepPipeline(dist, rank, world, group, banks, recv, nch, shard.HostRuntime(), rotate=rotate, on_gathered=on_gathered)
+        cur = {}
+
+        def encode(result):
+            data = step_data(cur["k"])
+            _, cdf, cdfnum = T.orc_cdfini(data)                 # (bench.py: histogram all-reduce; here every rank sees the whole input)
+            payload, clen, _ = T.orc_chunked_enc(codec, data[start:start + ln], chunk, cdf, cdfnum)
+            result[0][:nch] = torch.from_numpy(clen.view(np.int32).copy())
+            result[1][:payload.size] = torch.from_numpy(payload)
+            result[2][0] = payload.size
+
+        def decode(result):
+            pass
+
+        for run in range(2):                                    # two runs back to back, as warmup + timed region
+            for k in range(steps):
+                cur["k"] = k
+                pipe.step(k, k == steps - 1, encode, decode)
+            pipe.reset()
+        q.put((rank, seen))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,group,steps,prealloc", [(2, 2, 5, True), (4, 4, 9, True), (4, 4, 4, False), (2, 1, 3, True), (3, 3, 7, False)])
+def test_step_pipeline_schedule(world, group, steps, prealloc):
+    """shard.StepPipeline -- the class bench.py --gpus N runs its steps through -- with CPU tensors over gloo: every step
+    of two consecutive runs must arrive whole on its root (step j of a group on rank j; group 1: rank 0) and equal the
+    single-process container of that step's data, incl. the partial last group and bank reuse."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, group, steps, prealloc, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    got = dict(q.get(timeout=5) for _ in range(world))
+    for r in range(world):
+        mine = [k for k in range(steps) if (k % group if group > 1 else 0) == r] if group > 1 or r == 0 else []
+        assert sorted(got[r]) == sorted([(k, True) for k in mine] * 2), (r, got[r])
+
+
 def test_group_plan_exchanges_every_step_once():
     """the schedule bench.py follows at N > 1: every step lands in exactly one exchange, groups fill slots 0..ns-1 of one
     bank, consecutive groups alternate banks, and only the last group of a run may be partial"""

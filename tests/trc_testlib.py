@@ -70,6 +70,69 @@ def table_bytes(n, weights, seed=1):
     return np.searchsorted(cum, u, side="right").astype(np.uint8)
 
 
+def splitmix64_range(start, count, seed):
+    """words start .. start+count-1 (0-based) of the same stream: any slice of a big input can be regenerated alone"""
+    with np.errstate(over="ignore"):
+        z = (np.arange(start + 1, start + count + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) + np.uint64(seed)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def _cum(weights):
+    w = np.asarray(weights, dtype=np.float64)
+    cum = np.cumsum(w / w.sum())
+    cum[-1] = 1.0
+    return cum
+
+
+def table_bytes_range(start, count, weights, seed=1):
+    """bytes start .. start+count-1 of table_bytes(n, weights, seed), for any n >= start+count"""
+    u = (splitmix64_range(start, count, seed) >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+    return np.searchsorted(_cum(weights), u, side="right").astype(np.uint8)
+
+
+def table_bytes_device(torch, dev, n, weights, seed=1, out=None, slab=1 << 26):
+    """table_bytes generated ON THE DEVICE (1 GB per GPU never crosses PCIe): the same splitmix64
+    stream in wrapping int64 arithmetic, the same double-precision inverse-CDF lookup -> byte-identical to the numpy
+    generator (tests compare slices).  Returns a uint8 tensor of n (+ pad if `out` is given) bytes."""
+    def s64(x):                                                 # unsigned 64-bit constant as the signed value torch takes
+        return x - (1 << 64) if x >= (1 << 63) else x
+    cum = torch.from_numpy(_cum(weights)).to(dev)
+    res = out if out is not None else torch.empty(n, dtype=torch.uint8, device=dev)
+    G, M1, M2 = s64(0x9E3779B97F4A7C15), s64(0xBF58476D1CE4E5B9), s64(0x94D049BB133111EB)
+    for o in range(0, n, slab):
+        c = min(slab, n - o)
+        z = torch.arange(o + 1, o + c + 1, dtype=torch.int64, device=dev) * G + s64(seed & ((1 << 64) - 1))
+        z = (z ^ ((z >> 30) & ((1 << 34) - 1))) * M1            # logical shifts: mask off the sign extension
+        z = (z ^ ((z >> 27) & ((1 << 37) - 1))) * M2
+        z = z ^ ((z >> 31) & ((1 << 33) - 1))
+        u = ((z >> 11) & ((1 << 53) - 1)).to(torch.float64) * (1.0 / (1 << 53))
+        res[o:o + c] = torch.searchsorted(cum, u, right=True).to(torch.uint8)
+    return res
+
+
+def zipf_weights(alpha=1.1, nsym=256):
+    return 1.0 / np.arange(1, nsym + 1) ** alpha
+
+
+def mix_bytes(n, seed=13):
+    """heterogeneous workload ("mix100m"): stretches of 1..64 KiB, each one of text / uniform (incompressible) / runs /
+    constant, so that chunks of one wave differ in compressibility (lane imbalance) and raw chunks sit among coded
+    ones.  Deterministic."""
+    out = np.empty(n, dtype=np.uint8)
+    text, uni, runs = text_bytes(n, seed), uniform_bytes(n, seed + 1), runs_bytes(n, seed + 2)
+    ctl = splitmix64(n // 1024 + 8, seed + 3)
+    pos = i = 0
+    while pos < n:
+        ln = min(n - pos, (int(ctl[i] >> np.uint64(8)) % 64 + 1) * 1024)
+        kind = int(ctl[i] & np.uint64(7))
+        src = text if kind < 3 else uni if kind < 5 else runs if kind < 7 else None
+        out[pos:pos + ln] = src[pos:pos + ln] if src is not None else int(ctl[i] >> np.uint64(40)) & 255
+        pos += ln; i += 1
+    return out
+
+
 def zipf_bytes(n, alpha=1.1, nsym=256, seed=1):
     return table_bytes(n, 1.0 / np.arange(1, nsym + 1) ** alpha, seed)
 
@@ -250,6 +313,37 @@ def orc_chunked_enc(codec, data, chunk, cdf=None, cdfnum=256):
     tot = oracle().orc_chunked_enc(codec, _p8(data), n, chunk, cdfp, cdfnum, _p8(payload),
                                    clen.ctypes.data_as(C.POINTER(C.c_uint32)), poff.ctypes.data_as(C.POINTER(C.c_uint64)))
     return payload[:tot].copy(), clen[:nch].copy(), poff
+
+
+def orc_chunked_enc_mt(codec, data, chunk, cdf=None, cdfnum=256, threads=None):
+    """orc_chunked_enc over the host's cores: the chunk range is cut into one run per thread (ctypes releases the GIL),
+    results concatenated -> (payload, clen).  For the BASELINE-size total-parity tests."""
+    import concurrent.futures as cf
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    n = data.size
+    nch = (n + chunk - 1) // chunk
+    threads = threads or min(64, os.cpu_count() or 1)
+    per = max(1, (nch + threads - 1) // threads) * chunk
+    parts = [data[o:o + per] for o in range(0, n, per)]
+    with cf.ThreadPoolExecutor(threads) as ex:
+        res = list(ex.map(lambda x: orc_chunked_enc(codec, x, chunk, cdf, cdfnum)[:2], parts))
+    return np.concatenate([r[0] for r in res]), np.concatenate([r[1] for r in res])
+
+
+# the exact (workload, coder, chunk) configurations bench.py reports on (BASELINE.json configs 2-4); the expected
+# payload hashes are committed in tests/golden/bench_configs.json, generated THROUGH THE REFERENCE (oracle/_ref)
+BENCH_CONFIGS = [
+    dict(name="anscdf4s-text100m-512", codec=ANS4S, kind="text", seed=7, n=100 * 1000 * 1000, chunk=512),      # the headline
+    dict(name="rccdfs2-text100m-896", codec=RCS2, kind="text", seed=7, n=100 * 1000 * 1000, chunk=896),        # `-e45` literal
+    dict(name="rccdf-bwt100m-512", codec=RCA, kind="bwt", seed=3, n=100 * 1000 * 1000, chunk=512),             # config 3, `-e46`
+    dict(name="anscdf-bwt100m-512", codec=ANSA, kind="bwt", seed=3, n=100 * 1000 * 1000, chunk=512),           # config 3, `-e56`
+    dict(name="rcs-text100m-512", codec=RCB, kind="text", seed=7, n=100 * 1000 * 1000, chunk=512),             # config 4, `-e1`
+    dict(name="anscdf4s-text100m-4096", codec=ANS4S, kind="text", seed=7, n=100 * 1000 * 1000, chunk=4096),    # library default chunk
+]
+
+
+def bench_input(kind, n, seed):
+    return runs_bytes(n, seed) if kind == "bwt" else text_bytes(n, seed)
 
 
 def orc_chunked_dec(codec, payload, clen, n, chunk, cdf=None, cdfnum=256):

@@ -290,7 +290,7 @@ template <bool NIB>
 static void launch_ansa_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
 {
     TRC_LAUNCH_TIMED((trc_ansa_model_kernel<NIB>), dim3(w.ngroups), dim3(64), ANSA_MODEL_LDS(NIB), s, d_in, (u64)n, chunk, w.nchunks, w.scratch2);
-    hipLaunchKernelGGL((trc_ansa_code_kernel<NIB>), dim3(w.ngroups), dim3(64), ANSA_CODE_LDS, s,
+    TRC_LAUNCH_TIMED((trc_ansa_code_kernel<NIB>), dim3(w.ngroups), dim3(64), ANSA_CODE_LDS, s,
                        (const u8 *)w.scratch2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
 }
 template <bool NIB>
@@ -304,10 +304,10 @@ static void launch_ansa_dec(const uint8_t *d_payload, const uint32_t *d_clen, si
 void trc_launch_ansa_code(int nibble, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
 {
     if (nibble)
-        hipLaunchKernelGGL((trc_ansa_code_kernel<true>), dim3(w.ngroups), dim3(64), ANSA_CODE_LDS, s,
+        TRC_LAUNCH_TIMED((trc_ansa_code_kernel<true>), dim3(w.ngroups), dim3(64), ANSA_CODE_LDS, s,
                            (const u8 *)w.scratch2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
     else
-        hipLaunchKernelGGL((trc_ansa_code_kernel<false>), dim3(w.ngroups), dim3(64), ANSA_CODE_LDS, s,
+        TRC_LAUNCH_TIMED((trc_ansa_code_kernel<false>), dim3(w.ngroups), dim3(64), ANSA_CODE_LDS, s,
                            (const u8 *)w.scratch2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
 }
 void trc_launch_ansa_enc(int nibble, const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)

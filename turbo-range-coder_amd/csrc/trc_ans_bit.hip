@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64) void trc_ansb_dec_kernel(
 void trc_launch_ansb_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
 {
     TRC_LAUNCH_TIMED(trc_ansb_model_kernel, dim3(w.ngroups), dim3(64), ANSB_MODEL_BYTES, s, d_in, (u64)n, chunk, w.nchunks, w.scratch2);
-    hipLaunchKernelGGL(trc_ansb_code_kernel, dim3(w.ngroups), dim3(64), ANSB_CODE_LDS, s,
+    TRC_LAUNCH_TIMED(trc_ansb_code_kernel, dim3(w.ngroups), dim3(64), ANSB_CODE_LDS, s,
                        (const u8 *)w.scratch2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
 }
 void trc_launch_ansb_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(64) void trc_o1_dec_kernel(
 static void o1_fill(const TrcWork &w, hipStream_t s)
 {
     const u64 nvec = (u64)w.nchunks * (O1_MODEL_BYTES / 16u);
-    hipLaunchKernelGGL(trc_o1_fill_kernel, dim3((u32)((nvec + 255) / 256)), dim3(256), 0, s, (uint4 *)w.model, nvec);
+    TRC_LAUNCH_TIMED(trc_o1_fill_kernel, dim3((u32)((nvec + 255) / 256)), dim3(256), 0, s, (uint4 *)w.model, nvec);
 }
 void trc_launch_anso1_model(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, hipStream_t s)
 {

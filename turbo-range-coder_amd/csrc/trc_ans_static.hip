@@ -227,12 +227,7 @@ void trc_launch_ans4s_dec(const uint8_t *d_payload, const uint32_t *d_clen, size
     const u8 *lut = w.tables + TRC_TAB_LUT;
     const u32 *dtab = (const u32 *)(w.tables + TRC_TAB_DEC);
     const u32 nwaves = w.ngroups;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)trc_ans4s_dec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  32768 + 2048 + 14 * DEC_WAVE_LDS);
-        attr_set = true;
-    }
+    TRC_RAISE_LDS_ONCE(trc_ans4s_dec_kernel, 32768 + 2048 + 14 * DEC_WAVE_LDS);
     // the 34 KiB of tables are per workgroup, so waves share a workgroup -- but no more than it takes to
     // give every one of the 256 CUs a workgroup (1526 waves: 6 per workgroup -> 255 workgroups); up to 14 fit
     u32 wpb = (nwaves + 255u) / 256u;

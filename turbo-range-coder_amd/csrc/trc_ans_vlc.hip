@@ -301,7 +301,7 @@ static void launch_vla_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const 
 {
     TRC_LAUNCH_TIMED((trc_vla_model_kernel<ES, VN, ZZ>), dim3(w.ngroups), dim3(64), TRC_NIB2_BYTES, s,
                      d_in, (u64)n, chunk, w.nchunks, w.scratch2, w.stride2, w.aux);
-    hipLaunchKernelGGL((trc_vla_code_kernel<ES>), dim3(w.ngroups), dim3(64), VLA_CODE_LDS, s,
+    TRC_LAUNCH_TIMED((trc_vla_code_kernel<ES>), dim3(w.ngroups), dim3(64), VLA_CODE_LDS, s,
                        (const u8 *)w.scratch2, w.stride2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, w.aux, d_clen, w.gsum);
 }
 template <int ES, int VN, bool ZZ>

@@ -129,43 +129,79 @@ static int check_common(int codec, size_t n, uint32_t chunk, const uint16_t *d_c
 }
 
 // ------------------------------------------------------------------ coder-kernel timing (opt-in) ---
-#define TRC_TM_MAX 1024
-static struct { bool on; int cnt[2]; hipEvent_t ev[2][TRC_TM_MAX][2]; bool made[2][TRC_TM_MAX]; } g_tm;
+// Event pairs ride on every coder launch of a call made while timing is on (TRC_LAUNCH_TIMED, trc_launch.h): two-pass
+// encoders contribute both passes.  The pool is process-wide and guarded by a mutex; which direction a launch belongs
+// to is a per-thread flag set around the launches of one trc_encode_dev / trc_decode_dev call.
+#define TRC_TM_MAX 4096
+static struct TmState {
+    std::mutex mu;
+    bool on = false;
+    int calls[2] = { 0, 0 }, pairs[2] = { 0, 0 };
+    hipEvent_t ev[2][TRC_TM_MAX][2];
+    bool made[2][TRC_TM_MAX] = {};
+} g_tm;
+static thread_local int tm_dir = -1;                            // direction of the call in progress on this thread, -1 = not timing
 extern "C" int trc_timing_enable(int on)
 {
-    g_tm.on = on != 0; g_tm.cnt[0] = g_tm.cnt[1] = 0;
+    std::lock_guard<std::mutex> lk(g_tm.mu);
+    g_tm.on = on != 0;
+    g_tm.calls[0] = g_tm.calls[1] = g_tm.pairs[0] = g_tm.pairs[1] = 0;
     return TRC_OK;
 }
-thread_local hipEvent_t trc_tm_start = nullptr, trc_tm_stop = nullptr;      // armed pair, consumed by TRC_LAUNCH_TIMED (trc_launch.h)
-static inline int tm_begin(int dec)
+bool trc_tm_next(hipEvent_t *start, hipEvent_t *stop)
 {
-    if (!g_tm.on || g_tm.cnt[dec] >= TRC_TM_MAX) return -1;
-    const int i = g_tm.cnt[dec];
-    if (!g_tm.made[dec][i]) {
-        if (hipEventCreate(&g_tm.ev[dec][i][0]) != hipSuccess || hipEventCreate(&g_tm.ev[dec][i][1]) != hipSuccess) return -1;
-        g_tm.made[dec][i] = true;
+    if (tm_dir < 0) return false;
+    std::lock_guard<std::mutex> lk(g_tm.mu);
+    const int d = tm_dir, i = g_tm.pairs[d];
+    if (!g_tm.on || i >= TRC_TM_MAX) return false;
+    if (!g_tm.made[d][i]) {
+        if (hipEventCreate(&g_tm.ev[d][i][0]) != hipSuccess || hipEventCreate(&g_tm.ev[d][i][1]) != hipSuccess) return false;
+        g_tm.made[d][i] = true;
     }
-    trc_tm_start = g_tm.ev[dec][i][0]; trc_tm_stop = g_tm.ev[dec][i][1];
-    return i;
+    *start = g_tm.ev[d][i][0]; *stop = g_tm.ev[d][i][1];
+    g_tm.pairs[d] = i + 1;
+    return true;
 }
-static inline void tm_end(int dec, int i)
+static inline void tm_begin(int dec)
 {
-    trc_tm_start = trc_tm_stop = nullptr;
-    if (i >= 0) g_tm.cnt[dec] = i + 1;
+    std::lock_guard<std::mutex> lk(g_tm.mu);
+    tm_dir = g_tm.on ? dec : -1;
 }
+static inline void tm_end(int dec)
+{
+    if (tm_dir < 0) return;
+    tm_dir = -1;
+    std::lock_guard<std::mutex> lk(g_tm.mu);
+    g_tm.calls[dec]++;
+}
+// total_ms = summed duration of every coder kernel launched by the calls of that direction since enable(1);
+// launches = number of CALLS (so total_ms / launches is the coder-kernel time of one encode or decode, all passes)
 extern "C" int trc_timing_read(int decode, double *total_ms, int *launches)
 {
     const int d = decode ? 1 : 0;
+    int np, nc;
+    { std::lock_guard<std::mutex> lk(g_tm.mu); np = g_tm.pairs[d]; nc = g_tm.calls[d]; }
     double sum = 0;
-    for (int i = 0; i < g_tm.cnt[d]; i++) {
+    for (int i = 0; i < np; i++) {
         float ms = 0;
         HIPCHK(hipEventSynchronize(g_tm.ev[d][i][1]));
         HIPCHK(hipEventElapsedTime(&ms, g_tm.ev[d][i][0], g_tm.ev[d][i][1]));
         sum += ms;
     }
     if (total_ms) *total_ms = sum;
-    if (launches) *launches = g_tm.cnt[d];
+    if (launches) *launches = nc;
     return TRC_OK;
+}
+bool trc_first_use_on_device(unsigned long long *mask)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    const unsigned long long bit = 1ull << dev;
+    if (*mask & bit) return false;
+    *mask |= bit;
+    return true;
 }
 
 // ------------------------------------------------------------------------------ layer 2: *_dev ---
@@ -221,7 +257,7 @@ extern "C" int trc_encode_dev(int codec, const void *d_in, size_t n, uint32_t ch
     if ((rc = carve(codec, n, chunk, d_work, work_bytes, w))) return rc;
     if (is_static(codec) && !tables_ready) trc_launch_static_prep(d_cdf, cdfnum, w.tables, s);
     int from_end = 0;
-    const int tmi = tm_begin(0);
+    tm_begin(0);
     switch (codec) {
     case TRC_ANS4S: trc_launch_ans4s_enc((const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 1; break;
     case TRC_RCS1:  trc_launch_rcs_enc(1, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 0; break;
@@ -241,7 +277,7 @@ extern "C" int trc_encode_dev(int codec, const void *d_in, size_t n, uint32_t ch
     case TRC_ANSO1: trc_launch_anso1_model((const uint8_t *)d_in, n, chunk, w, s);
                     trc_launch_ansa_code(0, n, chunk, w, d_clen, s); from_end = 1; break;
     }
-    tm_end(0, tmi);
+    tm_end(0);
     if (w.goff) trc_launch_scan_groups(w.gsum, w.ngroups, w.goff, d_total, s);
     trc_launch_gather((const uint8_t *)d_in, n, chunk, w, from_end, d_clen, (uint8_t *)d_payload, d_total, s);
     HIPCHK(hipGetLastError());
@@ -267,7 +303,7 @@ extern "C" int trc_decode_dev(int codec, const uint32_t *d_clen, const void *d_p
         trc_launch_group_sums(d_clen, w.nchunks, n, chunk, w.gsum, s);
         if (w.goff) trc_launch_scan_groups(w.gsum, w.ngroups, w.goff, nullptr, s);
     }
-    const int tmi = tm_begin(1);
+    tm_begin(1);
     switch (codec) {
     case TRC_ANS4S: trc_launch_ans4s_dec((const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     case TRC_RCS1:  trc_launch_rcs_dec(1, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
@@ -286,7 +322,7 @@ extern "C" int trc_decode_dev(int codec, const uint32_t *d_clen, const void *d_p
                     else if (is_vla(codec)) trc_launch_vla_dec(vla_variant(codec), vla_zz(codec), vla_elem(codec), (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s);
                     break;
     }
-    tm_end(1, tmi);
+    tm_end(1);
     HIPCHK(hipGetLastError());
     return TRC_OK;
 }
@@ -410,6 +446,9 @@ static size_t host_decode(int codec, const unsigned char *in, size_t outlen, uns
         return 0;
     }
     const size_t hdrsz = sizeof h, dir = 4 * (size_t)h.nchunks;
+    // the prototype carries no input length: what is read from `in` is bounded by the caller's own outlen (header
+    // fields were checked against it above) and the directory must add up to the payload the header states
+    if (trc_container_check(in, hdrsz + dir + (size_t)h.payload, codec, outlen)) return 0;
     if (is_static(codec)) {
         if (cdfnum <= 0) cdfnum = host_cdfnum(cdf);
         if (cdfnum <= 0 || cdfnum > 256) { fail(TRC_E_CDF, "bad CDF"); return 0; }
@@ -424,6 +463,33 @@ static size_t host_decode(int codec, const unsigned char *in, size_t outlen, uns
     HCHK(hipMemcpyAsync(out, c.d_in, outlen, hipMemcpyDeviceToHost, c.stream));
     HCHK(hipStreamSynchronize(c.stream));
     return outlen;
+}
+
+// ---- container validation for untrusted input (the reference prototypes carry no input length) ------
+// Everything a decoder will read from buf is checked against buflen: header fields, the directory, and that the
+// directory's (clamped) lengths add up to exactly the stated payload, which must end inside the buffer.
+extern "C" int trc_container_check(const void *buf, size_t buflen, int codec, size_t outlen)
+{
+    trc_container_hdr h;
+    if (!buf || buflen < sizeof h) return fail(TRC_E_ARG, "container: %zu bytes is shorter than the header", buflen);
+    memcpy(&h, buf, sizeof h);
+    if (h.magic != TRC_MAGIC || h.version != 1) return fail(TRC_E_ARG, "container: bad magic/version");
+    if (!codec_ok(h.codec) || (codec && h.codec != codec)) return fail(TRC_E_ARG, "container: codec %u (expected %d)", h.codec, codec);
+    if (!chunk_ok(h.chunk)) return fail(TRC_E_ARG, "container: chunk %u", h.chunk);
+    if (outlen != (size_t)-1 && h.n != outlen) return fail(TRC_E_ARG, "container: holds %llu bytes, caller expects %zu", (unsigned long long)h.n, outlen);
+    if (h.n == 0 || (h.n + h.chunk - 1) / h.chunk != h.nchunks) return fail(TRC_E_ARG, "container: nchunks %u does not match n/chunk", h.nchunks);
+    const size_t dir = 4 * (size_t)h.nchunks;
+    if (dir > buflen - sizeof h) return fail(TRC_E_ARG, "container: directory (%zu B) runs past the buffer", dir);
+    if (h.payload > h.n || h.payload > buflen - sizeof h - dir) return fail(TRC_E_ARG, "container: payload (%llu B) runs past the buffer", (unsigned long long)h.payload);
+    const uint8_t *d = (const uint8_t *)buf + sizeof h;
+    uint64_t sum = 0;
+    for (uint32_t c = 0; c < h.nchunks; c++) {
+        uint32_t l; memcpy(&l, d + 4 * (size_t)c, 4);
+        const uint64_t len = (c + 1 == h.nchunks) ? h.n - (uint64_t)c * h.chunk : h.chunk;
+        sum += l < len ? l : len;                               // the decoders read an entry above the chunk length as "raw"
+    }
+    if (sum != h.payload) return fail(TRC_E_ARG, "container: directory sums to %llu, header says %llu", (unsigned long long)sum, (unsigned long long)h.payload);
+    return TRC_OK;
 }
 
 // ---- exports with the reference's names (include/turborc.h:500, include/anscdf.h:40-96) ----------

@@ -5,15 +5,27 @@
 #include <stddef.h>
 #include <stdint.h>
 
-// Optional timing of the dominant (coder) kernel of a call: when the API layer has armed an event pair, the launch
-// of that kernel carries the pair itself (hipExtLaunchKernelGGL: timestamps of the dispatch, no extra barrier packets
-// in the queue -- separate hipEventRecord calls around the launch cost ~6 us of queue time each), else it is a plain
-// launch.  `kern` goes in parentheses when it is a template instance.
-extern thread_local hipEvent_t trc_tm_start, trc_tm_stop;
+// Optional timing of the coder kernels of a call: while the API layer has timing armed for the calling thread, every
+// coder launch of the call (both passes of the two-pass rANS encoders, the order-1 model fill) carries its own event
+// pair (hipExtLaunchKernelGGL: timestamps of the dispatch itself, no extra barrier packets in the queue -- separate
+// hipEventRecord calls around a launch cost ~6 us of queue time each); otherwise it is a plain launch.  `kern` goes in
+// parentheses when it is a template instance.
+bool trc_tm_next(hipEvent_t *start, hipEvent_t *stop);      // trc_api.hip: hands out the next pair, false = not timing
 #define TRC_LAUNCH_TIMED(kern, grid, block, lds, stream, ...)                                                      \
     do {                                                                                                         \
-        if (trc_tm_start) hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)(lds), stream, trc_tm_start, trc_tm_stop, 0, __VA_ARGS__); \
+        hipEvent_t tm_a_, tm_b_;                                                                                 \
+        if (trc_tm_next(&tm_a_, &tm_b_)) hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)(lds), stream, tm_a_, tm_b_, 0, __VA_ARGS__); \
         else hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                                    \
+    } while (0)
+
+// Kernels that need more than 64 KiB of dynamic LDS raise their limit once per DEVICE (the attribute is per device:
+// a process that moves to another GPU must set it there too).
+bool trc_first_use_on_device(unsigned long long *mask);
+#define TRC_RAISE_LDS_ONCE(kern, bytes)                                                                            \
+    do {                                                                                                         \
+        static unsigned long long seen_ = 0;                                                                     \
+        if (trc_first_use_on_device(&seen_))                                                                     \
+            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
     } while (0)
 
 // Workspace carve-up shared by encode and decode (all offsets 256-byte aligned).

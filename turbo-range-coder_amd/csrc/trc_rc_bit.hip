@@ -213,16 +213,14 @@ __global__ __launch_bounds__(64) void trc_rcb_dec_kernel(
 
 void trc_launch_rcb_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
 {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)trc_rcb_enc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RCB_WAVE_LDS); attr = true; }
+    TRC_RAISE_LDS_ONCE(trc_rcb_enc_kernel, RCB_WAVE_LDS);
     TRC_LAUNCH_TIMED(trc_rcb_enc_kernel, dim3(w.ngroups), dim3(64), RCB_WAVE_LDS, s,
                        d_in, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
 }
 void trc_launch_rcb_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                         const TrcWork &w, uint8_t *d_out, hipStream_t s)
 {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)trc_rcb_dec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RCB_WAVE_LDS); attr = true; }
+    TRC_RAISE_LDS_ONCE(trc_rcb_dec_kernel, RCB_WAVE_LDS);
     TRC_LAUNCH_TIMED(trc_rcb_dec_kernel, dim3(w.ngroups), dim3(64), RCB_WAVE_LDS, s,
                        d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, d_out);
 }

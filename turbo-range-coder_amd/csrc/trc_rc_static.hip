@@ -243,8 +243,7 @@ static void launch_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t 
                        const TrcWork &w, uint8_t *d_out, hipStream_t s)
 {
     const u32 maxw = NS == 1 ? 14u : 7u;                       // 34 KiB tables + waves x (NS rings) must fit 160 KiB
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)trc_rcs_dec_kernel<NS, GEO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(32768 + 1024 + maxw * RCS_WAVE_LDS(NS))); attr = true; }
+    TRC_RAISE_LDS_ONCE((trc_rcs_dec_kernel<NS, GEO>), 32768 + 1024 + maxw * RCS_WAVE_LDS(NS));
     u32 wpb = (w.ngroups + 255u) / 256u;                       // just enough waves per workgroup to give every CU one
     wpb = wpb < 1u ? 1u : wpb > maxw ? maxw : wpb;
     const size_t sm = 32768 + 1024 + wpb * RCS_WAVE_LDS(NS);

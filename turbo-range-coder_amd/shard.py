@@ -143,6 +143,119 @@ def exchange_group(dist, rank, world, totals, clens, payloads, recv_clen=None, r
     return sizes, got
 
 
+class HostRuntime:
+    """Stream/event plumbing of StepPipeline for CPU tensors (gloo): everything is synchronous, events are no-ops."""
+    def record_main(self):
+        return None
+
+    def main_wait(self, ev):
+        pass
+
+    def side_wait(self, ev):
+        pass
+
+    def on_side(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def record_side(self):
+        return None
+
+
+class CudaRuntime:
+    """... for one GPU: `main` = torch's current stream (where the coder kernels are enqueued), one side stream for the
+    exchanges."""
+    def __init__(self, torch, dev):
+        self.torch, self.dev = torch, dev
+        self.side = torch.cuda.Stream(device=dev)
+
+    def record_main(self):
+        ev = self.torch.cuda.Event()
+        ev.record(self.torch.cuda.current_stream(self.dev))
+        return ev
+
+    def main_wait(self, ev):
+        if ev is not None:
+            self.torch.cuda.current_stream(self.dev).wait_event(ev)
+
+    def side_wait(self, ev):
+        if ev is not None:
+            self.side.wait_event(ev)
+
+    def on_side(self):
+        return self.torch.cuda.stream(self.side)
+
+    def record_side(self):
+        ev = self.torch.cuda.Event()
+        ev.record(self.side)
+        return ev
+
+
+class StepPipeline:
+    """The schedule `bench.py --gpus N` runs: code a step, exchange finished GROUPS of steps behind the coder's back.
+
+    Steps are exchanged in groups of `group` (= world with rotating roots: step j of a group is gathered onto rank j;
+    = 1 for the plain per-step gather to rank 0).  A group's exchange (exchange_group: one all_gather of sizes + ONE
+    grouped send/receive call) runs on the side stream while the next group is coded into the OTHER bank of result
+    buffers; a bank is coded into again only after its own exchange has finished (event).  The exchange reads the sizes
+    on the host, so it is issued one step late -- after the next step's kernels are in the queue -- and the last,
+    possibly partial, group of a run is flushed by the step flagged `last`.
+
+    banks      [2][group] result buffers: tuples (clen int32 tensor, payload uint8 tensor, total int64[>=1] tensor)
+    recv       [2] of (list of world-1 clen receive tensors, list of world-1 payload receive tensors) or None
+               (ranks that are never a root, or tests that let exchange_group allocate)
+    nch        chunks per step on this rank (clen tensors are trimmed to it)
+    on_gathered(first_step_of_group, sizes, got)  optional hook, called on every rank after its part of a group's
+               exchange has been issued (tests assert every step's container there)
+    """
+    def __init__(self, dist, rank, world, group, banks, recv, nch, rt, rotate=True, on_gathered=None):
+        self.dist, self.rank, self.world, self.group = dist, rank, world, group
+        self.banks, self.recv, self.nch, self.rt, self.rotate = banks, recv, nch, rt, rotate
+        self.on_gathered = on_gathered
+        self.done = [None, None]
+        self.pending = []
+
+    def reset(self):
+        """between independent runs (set-up / warmup / timed): forget finished exchanges"""
+        assert not self.pending
+        self.done = [None, None]
+
+    def _exchange(self, bank, ns, first):
+        res = self.banks[bank][:ns]
+        mine = self.rank if self.rotate else 0                 # the step of the group this rank is the root of
+        rc = rp = None
+        if self.recv[bank] is not None and mine < ns and (self.rotate or self.rank == 0):
+            rc, rp = {mine: self.recv[bank][0]}, {mine: self.recv[bank][1]}
+        sizes, got = exchange_group(self.dist, self.rank, self.world, [r[2][:1] for r in res], [r[0][:self.nch] for r in res],
+                                    [r[1] for r in res], rc, rp)
+        if self.on_gathered:
+            self.on_gathered(first, sizes, got)
+
+    def _run_pending(self):
+        while self.pending:
+            bank, ns, coded, first = self.pending.pop(0)
+            self.rt.side_wait(coded)                           # the exchange may start once the group's last encode is done
+            with self.rt.on_side():
+                self._exchange(bank, ns, first)
+                self.done[bank] = self.rt.record_side()
+
+    def step(self, k, last, encode, decode):
+        """step k of a run: encode(result) codes this rank's shard into the result buffers `result`, decode(result)
+        decodes them again (both only enqueue work on the main stream)"""
+        j, bank, ns = group_plan(k, self.group, last)
+        if j == 0:
+            self.rt.main_wait(self.done[bank])                 # the previous exchange out of this bank is done
+        result = self.banks[bank][j]
+        encode(result)
+        coded = self.rt.record_main() if ns else None
+        decode(result)
+        self._run_pending()                                    # one step late: the GPU has this step's kernels queued meanwhile
+        if ns:
+            self.pending.append((bank, ns, coded, k - j))
+        if last:
+            self._run_pending()
+
+
 def assemble_container(codec, n, chunk, cdfnum, clens, payloads):
     """rank 0: TRC1 container bytes (include/trc_hip.h) from the gathered per-rank pieces (numpy arrays)."""
     clen = np.concatenate([np.asarray(c, dtype=np.uint32) for c in clens]) if clens else np.zeros(0, np.uint32)
