@@ -436,7 +436,7 @@ def test_reference_harness_runs_on_the_gpu_library(torch_cuda, tmp_path):
     d = gen("text", n, 33)
     src = tmp_path / "text.bin"
     d.tofile(src)
-    _, cdf, cdfnum = T.orc_cdfini(d)
+    _, cdf, _ = T.orc_cdfini(d, 256)                           # the harness: cdfini(in, n, cdf, 0x100), then cdfnum = m + 1 (turborc.c:429-433)
     m1 = int(d.max()) + 1
     r = subprocess.run([exe, "-I1", "-J1", "-e1,42,43,44,45,46,47,56,57,58,64,66", str(src)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "ERROR" not in r.stdout and "ERROR" not in r.stderr, r.stdout[-3000:] + r.stderr[-2000:]
@@ -453,7 +453,7 @@ def test_reference_harness_runs_on_the_gpu_library(torch_cuda, tmp_path):
     assert r.returncode == 0 and "ERROR" not in r.stdout and "ERROR" not in r.stderr, r.stdout[-3000:] + r.stderr[-2000:]
     got = rows(r.stdout)
     dn = (d & 15).astype(np.uint8)
-    _, cdfn, _ = T.orc_cdfini(dn)
+    _, cdfn, _ = T.orc_cdfini(dn, 256)
     mn = int(dn.max()) + 1
     for i, codec in {42: trc.RCS1, 45: trc.RCS2, 46: trc.RCA4, 47: trc.RCAI4, 56: trc.ANSA4, 65: trc.ANS4S}.items():
         assert i in got, (i, r.stdout[-3000:])

@@ -19,31 +19,62 @@
 
 #define ENC_WAVE_LDS (TRC_SRING_BYTES + TRC_SEL_BYTES)       // input arrives through an in-register quad transpose
 #define DEC_WAVE_LDS (TRC_SRING_BYTES + TRC_SEL_BYTES)       // 8.3 KiB: 12 waves + 34 KiB of tables fit one CU
+#ifndef TRC_ENC_REP_DEFAULT
+#define TRC_ENC_REP_DEFAULT 16
+#endif
 
 // ------------------------------------------------------------------------------------- encode ---
+// LDS traffic of the symbol loop is written out by hand (inline asm, waits counted by hand: cdna_hip_programming.md 5.7):
+//   * the symbol table is REPLICATED REP times inside LDS, entry x of replica r at byte x*16*REP + r*16, and lane l reads
+//     replica l & (REP-1).  A ds_read_b128 is served in four groups of 16 lanes and a group finishes in one LDS cycle only
+//     if its lanes touch 16 different 16-byte bank groups (MI355X_MICROARCH.md, LDS): with one copy of the table, 16 random
+//     symbols take ~3 cycles (PMC round 1: 61 % of the LDS cycles were bank conflicts); with REP = 16 every lane of a
+//     group owns its own bank group (the lane sets {0-3,12-15,20-27} / {4-11,16-19,28-31} have distinct l & 15) and the
+//     read is conflict free whatever the symbols are; REP = 8 leaves two lanes per bank group.
+//   * the compiler split part of these 16-byte reads into pairs of ds_read2_b32 (two LDS instructions, 32-bank rules);
+//     the asm form is always one ds_read_b128, and the reads of the NEXT four symbols are in flight while the current
+//     four are coded.
+//   * renorm words go to the ring speculatively every symbol (the slot of the next unit is always free); the cursor
+//     is kept as a halfword counter that a compare's carry decrements (v_subb), ring address = and + shift-add.
 // one rANS step (ece, anscdf_.h:90-94): renorm-emit, then st = (st/f)<<15 + st%f + c0.
 //   e = { m, (2^15-f) | sh<<24, f<<16, c0' }:  q = umulhi(st, m) >> sh == st / f  for st < 2^31
 //   (f == 1 uses m = 2^32-1, sh = 0, c0' = c0 + 2^15-1: umulhi gives st-1, see trc_dir.hip)
-__device__ __forceinline__ void ans_put(u32 &st, const uint4 e, StreamOut<true> &so)
+__device__ __forceinline__ void ans_put(u32 &st, const trc_v4u e, u32 rbase, u32 &wn)
 {
     const bool emit = st >= e.z;                              // st >= f<<16
-    so.put16_if(emit, st);
+    u32 slot = wn & 63u;
+    asm("" : "+v"(slot));                                   // keep and / shift-add apart (v_and + v_lshl_add: 2 ops, not 3)
+    trc_lds_write16(rbase + (slot << 1), st);                 // speculative: only the cursor decides whether it counts
+    wn -= emit ? 1u : 0u;
     st = emit ? st >> 16 : st;
     const u32 q = __umulhi(st, e.x) >> (e.y >> 24);
     st = st + e.w + __umul24(q, e.y);                         // mul24 ignores the shift byte
 }
+// the four table entries of one input dword, requested together
+struct EncQuad { trc_v4u e0, e1, e2, e3; };
+__device__ __forceinline__ void ans_fetch4(EncQuad &q, u32 w, u32 tbase, int shift)
+{
+    q.e3 = trc_lds_read128(((w >> 24) << shift) + tbase);
+    q.e2 = trc_lds_read128((((w >> 16) & 255u) << shift) + tbase);
+    q.e1 = trc_lds_read128((((w >> 8) & 255u) << shift) + tbase);
+    q.e0 = trc_lds_read128(((w & 255u) << shift) + tbase);
+}
+// all of q's registers become valid here: at most `pending` LDS operations were issued after its four reads
+#define ANS_WAIT4(q, pending)                                                                                        \
+    asm volatile("s_waitcnt lgkmcnt(" #pending ")" : "+v"(q.e0), "+v"(q.e1), "+v"(q.e2), "+v"(q.e3) :: "memory")
 
-template <int BLOCK>
+template <int BLOCK, int REP>
 __global__ __launch_bounds__(BLOCK) void trc_ans4s_enc_kernel(
     const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks,
     const uint4 *__restrict__ etab_g, u8 *__restrict__ scratch, u32 stride,
     u32 *__restrict__ clen, u32 *__restrict__ gsum)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    uint4 *etab = (uint4 *)smem;                                                     // 4096 B
+    constexpr u32 TAB = 4096u * REP;
+    constexpr int SH = REP == 16 ? 8 : REP == 8 ? 7 : REP == 4 ? 6 : 4;
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    u8 *wbase = smem + 4096 + wv * ENC_WAVE_LDS;
-    for (u32 i = tid; i < 256; i += BLOCK) etab[i] = etab_g[i];
+    u8 *wbase = smem + TAB + wv * ENC_WAVE_LDS;
+    for (u32 i = tid; i < 256u * REP; i += BLOCK) ((uint4 *)smem)[i] = etab_g[i / REP];
     __syncthreads();
 
     WaveChunks wc;
@@ -59,6 +90,9 @@ __global__ __launch_bounds__(BLOCK) void trc_ans4s_enc_kernel(
     StreamOut<true> so;
     so.rings = wbase; so.sel = wbase + TRC_SRING_BYTES;
     so.scratch = scratch; so.stride = stride; so.c0 = wc.c0; so.wpos = 0; so.nfl = 0;
+    const u32 tbase = (lane & (u32)(REP - 1)) << 4;                              // this lane's replica (table at LDS offset 0)
+    const u32 rbase = (u32)(uintptr_t)(so.rings - smem) + trc_raddr(lane, 0);    // this lane's ring, as an LDS byte address
+    const uint4 *etab1 = (const uint4 *)smem;                                    // generic view for the ragged tail: replica 0
 
     const u32 S = chunk / TRC_SEG;
     const u32 top = alive ? (len - 1u) / TRC_SEG : 0u;          // segment holding the chunk's last byte
@@ -77,8 +111,11 @@ __global__ __launch_bounds__(BLOCK) void trc_ans4s_enc_kernel(
             const u8 *mine = in + (u64)c * chunk;               // (one lane in the whole grid: plain byte loads)
             for (u32 pos = len; pos > TRC_SEG * top;) {
                 pos--;
-                const uint4 e = etab[mine[pos]];
-                if (pos >= body || !(pos & 1u)) ans_put(st0, e, so); else ans_put(st1, e, so);
+                const uint4 e = etab1[(u32)mine[pos] * REP];
+                const trc_v4u ev = { e.x, e.y, e.z, e.w };
+                u32 wn = ~(so.wpos >> 1);
+                if (pos >= body || !(pos & 1u)) ans_put(st0, ev, rbase, wn); else ans_put(st1, ev, rbase, wn);
+                so.wpos = (~wn) << 1;                           // (the top segment is a lane's first: <= 126 bytes into an empty ring)
             }
             act = false;
         }
@@ -86,15 +123,25 @@ __global__ __launch_bounds__(BLOCK) void trc_ans4s_enc_kernel(
         for (int k = 3; k >= 0; k--) {
             if (act) {
                 const uint4 v = tin.read((u32)k);
-                const u32 w[4] = { v.x, v.y, v.z, v.w };
-#pragma unroll
-                for (int d = 3; d >= 0; d--) {
-                    // table entries depend only on the input bytes: fetch all four before the chains
-                    const uint4 e3 = etab[w[d] >> 24], e2 = etab[(w[d] >> 16) & 255u], e1 = etab[(w[d] >> 8) & 255u], e0 = etab[w[d] & 255u];
-                    ans_put(st1, e3, so); ans_put(st0, e2, so);
-                    ans_put(st1, e1, so); ans_put(st0, e0, so);
-                }
+                u32 wn = ~(so.wpos >> 1);                       // halfword cursor: next unit -> ring halfword wn & 63
+                EncQuad a, b;
+                // four dwords, top first; the reads of dword d-1 fly while dword d is coded.  LDS operations issued
+                // after a's reads when a is waited for: 4 (b's reads) [+ 4 ring writes of the dword before]
+                ans_fetch4(a, v.w, tbase, SH);
+                ans_fetch4(b, v.z, tbase, SH);
+                ANS_WAIT4(a, 4);
+                ans_put(st1, a.e3, rbase, wn); ans_put(st0, a.e2, rbase, wn); ans_put(st1, a.e1, rbase, wn); ans_put(st0, a.e0, rbase, wn);
+                ans_fetch4(a, v.y, tbase, SH);
+                ANS_WAIT4(b, 8);
+                ans_put(st1, b.e3, rbase, wn); ans_put(st0, b.e2, rbase, wn); ans_put(st1, b.e1, rbase, wn); ans_put(st0, b.e0, rbase, wn);
+                ans_fetch4(b, v.x, tbase, SH);
+                ANS_WAIT4(a, 8);
+                ans_put(st1, a.e3, rbase, wn); ans_put(st0, a.e2, rbase, wn); ans_put(st1, a.e1, rbase, wn); ans_put(st0, a.e0, rbase, wn);
+                ANS_WAIT4(b, 4);
+                ans_put(st1, b.e3, rbase, wn); ans_put(st0, b.e2, rbase, wn); ans_put(st1, b.e1, rbase, wn); ans_put(st0, b.e0, rbase, wn);
+                so.wpos = (~wn) << 1;
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the ring writes above are not in the compiler's books
             so.drain(false, alive);                             // <= 32 new bytes per lane since the last drain
             ovf = ovf || (alive && so.wpos + 8u >= len);        // already incompressible: stop coding this chunk
             act = act && !ovf;
@@ -205,19 +252,41 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
 }
 
 // ------------------------------------------------------------------------------------- launch ---
-void trc_launch_ans4s_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w,
-                          uint32_t *d_clen, hipStream_t s)
+// Encoder launch shape.  LDS per workgroup = REP x 4 KiB of symbol table + 8.3 KiB per wave; a CU holds 160 KiB.
+//   REP 16 (conflict-free table reads, 64 KiB): up to 11 waves per workgroup, one workgroup per CU
+//   REP  8 (32 KiB): up to 15 waves;   REP 1 (4 KiB, round-1 layout): 4 waves per workgroup, 4 workgroups per CU
+// Few waves (small inputs): one wave per workgroup with the plain table, so that they spread over all CUs.
+template <int REP>
+static void ans4s_enc_launch(u32 wpb, const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
 {
     const uint4 *etab = (const uint4 *)(w.tables + TRC_TAB_ENC);
     const u32 nwaves = w.ngroups;
-    if (nwaves >= 2048) {        // 4 waves share one 4 KiB symbol table: 37 KiB per workgroup -> 16 waves per CU
-        const size_t sm = 4096 + 4 * ENC_WAVE_LDS;
-        TRC_LAUNCH_TIMED(trc_ans4s_enc_kernel<256>, dim3((nwaves + 3) / 4), dim3(256), sm, s,
-                           d_in, (u64)n, chunk, w.nchunks, etab, w.scratch, w.stride, d_clen, w.gsum);
-    } else {                     // few waves: one per workgroup so they spread over all CUs (12.4 KiB -> 12 per CU)
-        const size_t sm = 4096 + ENC_WAVE_LDS;
-        TRC_LAUNCH_TIMED(trc_ans4s_enc_kernel<64>, dim3(nwaves), dim3(64), sm, s,
-                           d_in, (u64)n, chunk, w.nchunks, etab, w.scratch, w.stride, d_clen, w.gsum);
+    const size_t sm = 4096u * REP + wpb * ENC_WAVE_LDS;
+#define TRC_ENC_CASE(W)                                                                                              \
+    case W: TRC_RAISE_LDS_ONCE((trc_ans4s_enc_kernel<64 * W, REP>), 4096u * REP + W * ENC_WAVE_LDS);                 \
+            TRC_LAUNCH_TIMED((trc_ans4s_enc_kernel<64 * W, REP>), dim3((nwaves + W - 1) / W), dim3(64 * W), sm, s,   \
+                             d_in, (u64)n, chunk, w.nchunks, etab, w.scratch, w.stride, d_clen, w.gsum); break;
+    switch (wpb) {
+    TRC_ENC_CASE(1) TRC_ENC_CASE(4) TRC_ENC_CASE(8) TRC_ENC_CASE(10) TRC_ENC_CASE(11) TRC_ENC_CASE(12) TRC_ENC_CASE(14) TRC_ENC_CASE(15)
+    default: break;
+    }
+#undef TRC_ENC_CASE
+}
+void trc_launch_ans4s_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w,
+                          uint32_t *d_clen, hipStream_t s)
+{
+    const u32 nwaves = w.ngroups;
+    static const int env_rep = getenv("TRC_ENC_REP") ? atoi(getenv("TRC_ENC_REP")) : 0;     // tuning aids
+    static const int env_wpb = getenv("TRC_ENC_WPB") ? atoi(getenv("TRC_ENC_WPB")) : 0;
+    int rep = env_rep ? env_rep : TRC_ENC_REP_DEFAULT;
+    if (nwaves < 1024) rep = 1;                              // small inputs: spread single waves over the CUs
+    u32 wpb = rep == 16 ? 11u : rep == 8 ? 12u : 4u;
+    if (env_wpb) wpb = (u32)env_wpb;
+    if (nwaves < 1024) wpb = 1;
+    switch (rep) {
+    case 16: ans4s_enc_launch<16>(wpb > 11u ? 11u : wpb, d_in, n, chunk, w, d_clen, s); break;
+    case 8:  ans4s_enc_launch<8>(wpb, d_in, n, chunk, w, d_clen, s); break;
+    default: ans4s_enc_launch<1>(wpb, d_in, n, chunk, w, d_clen, s); break;
     }
 }
 

@@ -47,6 +47,20 @@ __device__ __forceinline__ void trc_st16_nt(u8 *p, uint4 q)
     __builtin_nontemporal_store(v, (trc_v4u *)p);
 }
 
+// ---- LDS accesses written out by hand (the symbol loops of the static coders) ----------------------------------------
+// Not in the compiler's s_waitcnt bookkeeping: a read's destination is valid only after a counted s_waitcnt statement
+// that names it "+v" (cdna_hip_programming.md 5.7 form ii); `addr` is an LDS byte address.
+__device__ __forceinline__ trc_v4u trc_lds_read128(u32 addr)
+{
+    trc_v4u v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void trc_lds_write16(u32 addr, u32 v)
+{
+    asm volatile("ds_write_b16 %0, %1" :: "v"(addr), "v"(v) : "memory");
+}
+
 __device__ __forceinline__ u32 trc_min(u32 a, u32 b) { return a < b ? a : b; }
 __device__ __forceinline__ u32 trc_sub_sat(u32 a, u32 b) { return a > b ? a - b : 0u; }
 
