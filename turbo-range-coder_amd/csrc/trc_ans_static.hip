@@ -20,7 +20,7 @@
 #define ENC_WAVE_LDS (TRC_SRING_BYTES + TRC_SEL_BYTES)       // input arrives through an in-register quad transpose
 #define DEC_WAVE_LDS (TRC_SRING_BYTES + TRC_SEL_BYTES)       // 8.3 KiB: 12 waves + 34 KiB of tables fit one CU
 #ifndef TRC_ENC_REP_DEFAULT
-#define TRC_ENC_REP_DEFAULT 16
+#define TRC_ENC_REP_DEFAULT 1
 #endif
 
 // ------------------------------------------------------------------------------------- encode ---
@@ -39,25 +39,71 @@
 // one rANS step (ece, anscdf_.h:90-94): renorm-emit, then st = (st/f)<<15 + st%f + c0.
 //   e = { m, (2^15-f) | sh<<24, f<<16, c0' }:  q = umulhi(st, m) >> sh == st / f  for st < 2^31
 //   (f == 1 uses m = 2^32-1, sh = 0, c0' = c0 + 2^15-1: umulhi gives st-1, see trc_dir.hip)
+//
+// The renorm half of a step is one hand-written block (6 instructions, 5 VALU): compare -> VCC; ring address of the next
+// unit from the halfword cursor (and, shift-add: also the two wait states a VALU write of VCC needs before a VALU reads
+// it as a mask on gfx950); speculative 16-bit store; st = VCC ? st >> 16 : st as ONE v_cndmask with an SDWA source
+// select (WORD_1 of st); cursor -= VCC (v_subbrev).  The division half (mul_hi, SDWA shift, mul24, add3) is left to the
+// compiler, which schedules it across the two chains.
+#ifndef TRC_ENC_PRED_WRITE
+#define TRC_ENC_PRED_WRITE 0          // 1: store only in lanes that emit (EXEC = VCC around the ds_write): ablation
+#endif
 __device__ __forceinline__ void ans_put(u32 &st, const trc_v4u e, u32 rbase, u32 &wn)
 {
-    const bool emit = st >= e.z;                              // st >= f<<16
-    u32 slot = wn & 63u;
-    asm("" : "+v"(slot));                                   // keep and / shift-add apart (v_and + v_lshl_add: 2 ops, not 3)
-    trc_lds_write16(rbase + (slot << 1), st);                 // speculative: only the cursor decides whether it counts
-    wn -= emit ? 1u : 0u;
-    st = emit ? st >> 16 : st;
+    u32 t;
+#if TRC_ENC_PRED_WRITE
+    u64 sv;
+    asm volatile("v_cmp_ge_u32_e32 vcc, %0, %4\n\t"
+                 "v_and_b32_e32 %2, 63, %1\n\t"
+                 "v_lshl_add_u32 %2, %2, 1, %5\n\t"
+                 "s_and_saveexec_b64 %3, vcc\n\t"
+                 "ds_write_b16 %2, %0\n\t"
+                 "s_mov_b64 exec, %3\n\t"
+                 "v_cndmask_b32_sdwa %0, %0, %0, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+                 "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc"
+                 : "+v"(st), "+v"(wn), "=&v"(t), "=&s"(sv) : "v"(e.z), "v"(rbase) : "vcc", "memory");
+#elif defined(TRC_ENC_ABL_NOWRITE)                             // timing experiment: no ring store at all (output is garbage)
+    asm volatile("v_cmp_ge_u32_e32 vcc, %0, %3\n\t"
+                 "v_and_b32_e32 %2, 63, %1\n\t"
+                 "v_lshl_add_u32 %2, %2, 1, %4\n\t"
+                 "v_cndmask_b32_sdwa %0, %0, %0, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+                 "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc"
+                 : "+v"(st), "+v"(wn), "=&v"(t) : "v"(e.z), "v"(rbase) : "vcc", "memory");
+#else
+    asm volatile("v_cmp_ge_u32_e32 vcc, %0, %3\n\t"
+                 "v_and_b32_e32 %2, 63, %1\n\t"
+                 "v_lshl_add_u32 %2, %2, 1, %4\n\t"
+                 "ds_write_b16 %2, %0\n\t"
+                 "v_cndmask_b32_sdwa %0, %0, %0, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+                 "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc"
+                 : "+v"(st), "+v"(wn), "=&v"(t) : "v"(e.z), "v"(rbase) : "vcc", "memory");
+#endif
     const u32 q = __umulhi(st, e.x) >> (e.y >> 24);
     st = st + e.w + __umul24(q, e.y);                         // mul24 ignores the shift byte
+}
+// table address of byte k of w: (byte << SH) in one SDWA shift (+ the lane's replica offset when the table is replicated)
+template <int K>
+__device__ __forceinline__ u32 ans_taddr(u32 w, u32 sh, u32 tbase, bool replicated)
+{
+    u32 a;
+#ifdef TRC_ENC_ABL_ONEENTRY                                    // timing experiment: every lane reads entry 32 (broadcast, no conflicts)
+    w = 0x20202020u;
+#endif
+    if (K == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(a) : "v"(sh), "v"(w));
+    if (K == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(a) : "v"(sh), "v"(w));
+    if (K == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(a) : "v"(sh), "v"(w));
+    if (K == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(a) : "v"(sh), "v"(w));
+    return replicated ? a + tbase : a;
 }
 // the four table entries of one input dword, requested together
 struct EncQuad { trc_v4u e0, e1, e2, e3; };
 __device__ __forceinline__ void ans_fetch4(EncQuad &q, u32 w, u32 tbase, int shift)
 {
-    q.e3 = trc_lds_read128(((w >> 24) << shift) + tbase);
-    q.e2 = trc_lds_read128((((w >> 16) & 255u) << shift) + tbase);
-    q.e1 = trc_lds_read128((((w >> 8) & 255u) << shift) + tbase);
-    q.e0 = trc_lds_read128(((w & 255u) << shift) + tbase);
+    const u32 sh = (u32)shift;
+    q.e3 = trc_lds_read128(ans_taddr<3>(w, sh, tbase, shift != 4));
+    q.e2 = trc_lds_read128(ans_taddr<2>(w, sh, tbase, shift != 4));
+    q.e1 = trc_lds_read128(ans_taddr<1>(w, sh, tbase, shift != 4));
+    q.e0 = trc_lds_read128(ans_taddr<0>(w, sh, tbase, shift != 4));
 }
 // all of q's registers become valid here: at most `pending` LDS operations were issued after its four reads
 #define ANS_WAIT4(q, pending)                                                                                        \
@@ -72,6 +118,7 @@ __global__ __launch_bounds__(BLOCK) void trc_ans4s_enc_kernel(
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     constexpr u32 TAB = 4096u * REP;
     constexpr int SH = REP == 16 ? 8 : REP == 8 ? 7 : REP == 4 ? 6 : 4;
+    static_assert(REP == 1 || REP == 8 || REP == 16, "replica count");
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     u8 *wbase = smem + TAB + wv * ENC_WAVE_LDS;
     for (u32 i = tid; i < 256u * REP; i += BLOCK) ((uint4 *)smem)[i] = etab_g[i / REP];
@@ -100,10 +147,14 @@ __global__ __launch_bounds__(BLOCK) void trc_ans4s_enc_kernel(
     u32 st0 = TRC_ANS_LOW, st1 = TRC_ANS_LOW;
     bool ovf = false;
 
-    tin.issue(wc, (S - 1u) * TRC_SEG);
+    // both halves of a 128-byte line are requested together (QuadIn, paired mode)
+    if ((S - 1u) & 1u) { tin.issue_slot<1>(wc, S - 1u); tin.issue_slot<0>(wc, S - 2u); } else tin.issue_slot<0>(wc, S - 1u);
     for (u32 s = S - 1u;; s--) {
-        tin.commit();
-        if (s) tin.issue(wc, (s - 1u) * TRC_SEG);               // next (lower) segment in flight during this one
+        if (s & 1u) tin.commit_slot<1>(); else tin.commit_slot<0>();
+        if (!(s & 1u) && s >= 1u) {                             // the next line down: in flight during this segment (and the next)
+            tin.issue_slot<1>(wc, s - 1u);
+            if (s >= 2u) tin.issue_slot<0>(wc, s - 2u);
+        }
         bool act = alive && s <= top && !ovf;
         const bool ragged = act && s == top && toplen != TRC_SEG;
         if (ragged) {                                           // last chunk only: byte by byte
@@ -178,7 +229,10 @@ __device__ __forceinline__ u32 ans_get(u32 &st, const u8 *lut, const uint2 *dtab
     si.rpos += rn ? 2u : 0u;
     return x;
 }
-
+// (A hand-issued form of this step -- both states' LUT bytes and both candidate ring words requested up front, counted
+// s_waitcnt, SDWA address selects -- was built and measured in round 2: bit-exact, 11 instead of 14 VALU per symbol, and
+// SLOWER, 77-79 us against 74-75 us for 100 MB at chunk 512: the compiler's schedule overlaps consecutive pairs where the
+// fixed waits of the asm form serialise them.  profiles/r02_notes.md.)
 __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
     const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
     u64 n, u32 chunk, u32 nchunks,
@@ -253,9 +307,10 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
 
 // ------------------------------------------------------------------------------------- launch ---
 // Encoder launch shape.  LDS per workgroup = REP x 4 KiB of symbol table + 8.3 KiB per wave; a CU holds 160 KiB.
-//   REP 16 (conflict-free table reads, 64 KiB): up to 11 waves per workgroup, one workgroup per CU
-//   REP  8 (32 KiB): up to 15 waves;   REP 1 (4 KiB, round-1 layout): 4 waves per workgroup, 4 workgroups per CU
-// Few waves (small inputs): one wave per workgroup with the plain table, so that they spread over all CUs.
+//   REP 1 (default): 4 waves share one 4 KiB table, 37 KiB per workgroup -> 16 waves per CU
+//   REP 8 (TRC_ENC_REP=8, 32 KiB, 12 waves per workgroup): kept as a measuring aid -- with the hand-issued b128 reads the
+//   replicated table is NOT faster (100 MB, chunk 512: 64 vs 63 us; REP 16 at 11 waves per CU, chunk 576: 67 vs 68 us;
+//   profiles/r02_notes.md): the bank conflicts round 1's PMC showed were not what the kernel waited for.
 template <int REP>
 static void ans4s_enc_launch(u32 wpb, const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
 {
@@ -267,7 +322,7 @@ static void ans4s_enc_launch(u32 wpb, const uint8_t *d_in, size_t n, uint32_t ch
             TRC_LAUNCH_TIMED((trc_ans4s_enc_kernel<64 * W, REP>), dim3((nwaves + W - 1) / W), dim3(64 * W), sm, s,   \
                              d_in, (u64)n, chunk, w.nchunks, etab, w.scratch, w.stride, d_clen, w.gsum); break;
     switch (wpb) {
-    TRC_ENC_CASE(1) TRC_ENC_CASE(4) TRC_ENC_CASE(8) TRC_ENC_CASE(10) TRC_ENC_CASE(11) TRC_ENC_CASE(12) TRC_ENC_CASE(14) TRC_ENC_CASE(15)
+    TRC_ENC_CASE(1) TRC_ENC_CASE(4) TRC_ENC_CASE(12)
     default: break;
     }
 #undef TRC_ENC_CASE
@@ -279,15 +334,11 @@ void trc_launch_ans4s_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const T
     static const int env_rep = getenv("TRC_ENC_REP") ? atoi(getenv("TRC_ENC_REP")) : 0;     // tuning aids
     static const int env_wpb = getenv("TRC_ENC_WPB") ? atoi(getenv("TRC_ENC_WPB")) : 0;
     int rep = env_rep ? env_rep : TRC_ENC_REP_DEFAULT;
-    if (nwaves < 1024) rep = 1;                              // small inputs: spread single waves over the CUs
-    u32 wpb = rep == 16 ? 11u : rep == 8 ? 12u : 4u;
-    if (env_wpb) wpb = (u32)env_wpb;
-    if (nwaves < 1024) wpb = 1;
-    switch (rep) {
-    case 16: ans4s_enc_launch<16>(wpb > 11u ? 11u : wpb, d_in, n, chunk, w, d_clen, s); break;
-    case 8:  ans4s_enc_launch<8>(wpb, d_in, n, chunk, w, d_clen, s); break;
-    default: ans4s_enc_launch<1>(wpb, d_in, n, chunk, w, d_clen, s); break;
-    }
+    u32 wpb = rep == 8 ? 12u : 4u;
+    if (env_wpb == 1 || env_wpb == 4 || env_wpb == 12) wpb = (u32)env_wpb;
+    if (nwaves < 2048) { rep = 1; wpb = 1; }                 // few waves: one per workgroup so they spread over all CUs (12.4 KiB -> 12 per CU)
+    if (rep == 8) ans4s_enc_launch<8>(wpb, d_in, n, chunk, w, d_clen, s);
+    else ans4s_enc_launch<1>(wpb, d_in, n, chunk, w, d_clen, s);
 }
 
 void trc_launch_ans4s_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,

@@ -120,6 +120,7 @@ __device__ __forceinline__ void trc_quad_transpose(u32 (&m)[4][4])
 struct QuadIn {
     const u8 *base;      // global address of chunk c0
     uint4 r[4];          // segment in flight: r[j] = piece (lane&3) of the chunk of lane (lane&~3)+j
+    uint4 r2[4];         // second segment in flight (paired mode: the other 64-byte half of the same 128-byte line)
     uint4 p[4];          // current segment: p[k] = piece k of this lane's chunk
     __device__ __forceinline__ void issue(const WaveChunks &w, u32 segoff)
     {
@@ -142,6 +143,39 @@ struct QuadIn {
         for (int k = 0; k < 4; k++) p[k] = make_uint4(m[k][0], m[k][1], m[k][2], m[k][3]);
     }
     __device__ __forceinline__ uint4 read(u32 k) const { return p[k]; }           // k is a literal after unrolling
+
+    // Paired mode, for kernels that walk their chunks DOWNWARD: the two 64-byte halves of a 128-byte line are requested in
+    // the same breath (odd segment -> r, the even one below it -> r2) instead of one segment-time apart.  With the
+    // nontemporal hint the first half's line was gone from the L2 by the time the second half was asked for: round 1's PMC
+    // showed 167 MB read for a 100 MB input.  Protocol (s = segment index, wave-uniform):
+    //   start:   issue_slot<(S-1)&1>(S-1), and issue_slot<0>(S-2) too if S-1 is odd
+    //   every s: commit_slot<s&1>(); if s is even and s >= 1: issue_slot<1>(s-1) and, if s >= 2, issue_slot<0>(s-2); code segment s
+    template <int ODD>                                         // ODD = s & 1 (a literal: the register sets must not be indexed at run time)
+    __device__ __forceinline__ void issue_slot(const WaveChunks &w, u32 s)
+    {
+        const u32 lane = trc_lane(), part = (lane & 3u) << 4, segoff = s * TRC_SEG;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            u32 row = (lane & ~3u) + (u32)j;
+            row = row < w.rows ? row : w.rows - 1;
+            const u32 so = segoff < w.len_of(row) ? segoff : 0u;     // never read past the input's pad
+            const uint4 v = trc_ld16_nt(base + (size_t)row * w.chunk + so + part);
+            if (ODD) r[j] = v; else r2[j] = v;
+        }
+    }
+    template <int ODD>
+    __device__ __forceinline__ void commit_slot()
+    {
+        u32 m[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint4 v = ODD ? r[j] : r2[j];
+            m[j][0] = v.x; m[j][1] = v.y; m[j][2] = v.z; m[j][3] = v.w;
+        }
+        trc_quad_transpose(m);
+#pragma unroll
+        for (int k = 0; k < 4; k++) p[k] = make_uint4(m[k][0], m[k][1], m[k][2], m[k][3]);
+    }
 };
 
 struct QuadOut {
