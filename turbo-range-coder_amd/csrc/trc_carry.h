@@ -47,12 +47,16 @@ struct TrcCarryT {
         }
     }
     // Predicated form for branch-free symbol loops: the event happens only where `on`.  SINK additionally needs
-    // put32_if(bool, uint32_t).  The common case costs no branch; everything else takes the general path.
+    // put32_if(bool, uint32_t).  The common cases cost no branch -- a plain append AND a carry into a held word with no
+    // all-ones words behind it (release cache + 1 instead of cache: same as `emit` with npend == 0); only an all-ones
+    // word, held all-ones words or the very first word take the general path.  Carries are not rare (the adaptive
+    // coders see one on 10-30 % of their words), and with 64 lanes per wave a branchy carry path ran at almost every
+    // renormalisation point of the wave: round 2 measured rcs encode 2.59 -> see profiles/r02_notes.md.
     template <class SINK>
     TRC_HD void emit_if(SINK &so, bool on, bool cy, uint32_t W)
     {
-        const bool fast = on && have && !cy && npend == 0 && W != FF;
-        so.put32_if(fast, cache);
+        const bool fast = on && have && npend == 0 && W != FF;
+        so.put32_if(fast, (cache + (cy ? 1u : 0u)) & FF);
         cache = fast ? W : cache;
         nwords += fast ? 1u : 0u;
         if (on && !fast) emit(so, cy, W);

@@ -61,6 +61,15 @@ __device__ __forceinline__ void trc_lds_write16(u32 addr, u32 v)
     asm volatile("ds_write_b16 %0, %1" :: "v"(addr), "v"(v) : "memory");
 }
 
+// LDS accesses by integer byte address (address space 3): the compiler then folds constant parts into the instruction's
+// offset field; through a generic pointer into `extern __shared__` memory it adds the (zero) segment base with a VALU op
+// per access (v_add_u32 v, 0, v in the round-1 listings of the model-bound coders).
+typedef __attribute__((address_space(3))) u8 trc_lds_u8;
+typedef __attribute__((address_space(3))) u16 trc_lds_u16;
+__device__ __forceinline__ u32 trc_lds_addr(const void *p) { return (u32)(uintptr_t)(const trc_lds_u8 *)p; }   // p must point into LDS
+__device__ __forceinline__ u32 trc_ldsr16(u32 a) { return *(const trc_lds_u16 *)(uintptr_t)a; }
+__device__ __forceinline__ void trc_ldsw16(u32 a, u32 v) { *(trc_lds_u16 *)(uintptr_t)a = (u16)v; }
+
 __device__ __forceinline__ u32 trc_min(u32 a, u32 b) { return a < b ? a : b; }
 __device__ __forceinline__ u32 trc_sub_sat(u32 a, u32 b) { return a > b ? a - b : 0u; }
 

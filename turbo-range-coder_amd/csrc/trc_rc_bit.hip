@@ -49,23 +49,44 @@ __global__ __launch_bounds__(64) void trc_rcb_enc_kernel(
     LaneOut32 so; so.start(scratch + (u64)c * stride);
     RcEnc e; e.start();
     bool ovf = alive && lim <= 0;
+    // `live`: this lane is still coding.  A lane that is not (dead lane, incompressible chunk, past the end of a short
+    // last chunk) keeps running the same arithmetic on its own registers and its own model column -- nothing of it is
+    // observable, because only live lanes emit words -- so the eight steps of a byte carry no per-lane predication at
+    // all.  A lane whose chunk ends before the wave's does (the input's last chunk) flushes at that byte boundary.
+    bool live = alive && !ovf;
+    u32 out_len = alive ? len : 0u;                            // raw until proven otherwise
 
-    // one byte: where !act nothing but the (dead) lane's own model changes.  The body is a 4-trip loop over bit
-    // pairs (renorm + two steps) so that the kernel stays small in the instruction cache.
-    auto put_byte = [&](u32 x, bool act) {
-        const u32 path = 0x100u | x;
+    // one byte.  The body is a 4-trip loop over bit pairs (renorm + two steps) so that the kernel stays small in the
+    // instruction cache.  A renormalisation SHIFTS the state at once, but the word it produces is only remembered
+    // (`pend`): a lane emits a word every ~6 bytes, and the emit logic (held-back word, carry, 16-byte register window,
+    // its store) is by far the largest block of the loop, so it runs ONCE per byte -- for the one word almost every
+    // lane has at most -- instead of at each of the four renormalisation points.  A second word inside one byte (>= 32
+    // bits of range spent on <= 6 bits) first flushes the remembered one, in order, behind a wave-uniform branch.
+    const u32 mcol = trc_lds_addr(smem) + lane * 2u;           // this lane's model column as an LDS byte address
+    auto put_byte = [&](u32 x) {
+        const u32 path = (0x100u | x) << 7;                    // node k of the byte's path, times the row stride: (path >> (8-k)) & ~127
         u32 pp0, pp1, pp2, pp3;                                // the eight probabilities, two per register
         {
-            const u32 a0 = mb[(path >> 8) * 64], a1 = mb[(path >> 7) * 64], a2 = mb[(path >> 6) * 64], a3 = mb[(path >> 5) * 64];
-            const u32 a4 = mb[(path >> 4) * 64], a5 = mb[(path >> 3) * 64], a6 = mb[(path >> 2) * 64], a7 = mb[(path >> 1) * 64];
+            const u32 a0 = trc_ldsr16(mcol + 128u), a1 = trc_ldsr16(((path >> 7) & ~127u) + mcol);
+            const u32 a2 = trc_ldsr16(((path >> 6) & ~127u) + mcol), a3 = trc_ldsr16(((path >> 5) & ~127u) + mcol);
+            const u32 a4 = trc_ldsr16(((path >> 4) & ~127u) + mcol), a5 = trc_ldsr16(((path >> 3) & ~127u) + mcol);
+            const u32 a6 = trc_ldsr16(((path >> 2) & ~127u) + mcol), a7 = trc_ldsr16(((path >> 1) & ~127u) + mcol);
             pp0 = a0 | a1 << 16; pp1 = a2 | a3 << 16; pp2 = a4 | a5 << 16; pp3 = a6 | a7 << 16;
         }
         u32 xs = x << 24, node = 1;
+        bool pend = false, pcy = false;
+        u32 pw = 0;
 #pragma nounroll
         for (u32 j = 0; j < 4; j++) {
             {                                                  // renorm before bits 7,5,3,1 only (_RCENORM2)
-                const bool rn = act && e.range < TRC_TOP32;
-                e.cw.emit_if(so, rn, e.mark > e.low, (u32)(e.low >> 32));
+                const bool rn = e.range < TRC_TOP32;
+                if (__ballot(rn && pend)) {                    // second word within this byte (rare): the first one goes out now
+                    e.cw.emit_if(so, rn && pend && live, pcy, pw);
+                    pend = pend && !rn;
+                }
+                pcy = rn ? e.mark > e.low : pcy;
+                pw = rn ? (u32)(e.low >> 32) : pw;
+                pend = pend || rn;
                 e.low = rn ? e.low << 32 : e.low;
                 e.range = rn ? e.range << 32 : e.range;
                 e.mark = rn ? e.low : e.mark;
@@ -75,14 +96,14 @@ __global__ __launch_bounds__(64) void trc_rcb_enc_kernel(
                 const u32 p = h ? pp0 >> 16 : pp0 & 0xffffu;
                 const u32 bit = xs >> 31; xs <<= 1;
                 const u64 cut = (e.range >> TRC_PROB_BITS) * p;                  // rcbe_
-                const u64 nr = bit ? cut : e.range - cut;
-                e.low += (act && !bit) ? cut : 0;
-                e.range = act ? nr : e.range;
-                mb[node * 64] = (u16)rcb_adapt(p, bit);
+                e.low += bit ? 0 : cut;
+                e.range = bit ? cut : e.range - cut;
+                trc_ldsw16((node << 7) + mcol, rcb_adapt(p, bit));
                 node = node * 2 + bit;
             }
             pp0 = pp1; pp1 = pp2; pp2 = pp3;
         }
+        e.cw.emit_if(so, pend && live, pcy, pw);
     };
 
     const u32 S = chunk / TRC_SEG;
@@ -94,24 +115,28 @@ __global__ __launch_bounds__(64) void trc_rcb_enc_kernel(
 #pragma nounroll
         for (u32 k = 0; k < 4; k++) {
             uint4 v = pc0; pc0 = pc1; pc1 = pc2; pc2 = pc3;
-            if (!__ballot(alive && !ovf && s * TRC_SEG + k * 16u < len)) continue;
+            if (!__ballot(live)) continue;
 #pragma nounroll
             for (u32 d = 0; d < 4; d++) {
                 const u32 w = v.x; v.x = v.y; v.y = v.z; v.z = v.w;
                 const u32 q0 = s * TRC_SEG + k * 16u + d * 4u;
-                const bool run = alive && !ovf;
 #pragma nounroll
-                for (u32 i = 0; i < 4; i++) put_byte((w >> (8 * i)) & 255u, run && q0 + i < len);
-                ovf = ovf || (run && q0 < len && (int)(4u * e.cw.nwords) >= lim);   // OVERFLOW per byte, monotone
+                for (u32 i = 0; i < 4; i++) {
+                    if (__ballot(live && q0 + i == len)) {     // a short last chunk ends here: decide and flush it now (once per grid)
+                        if (live && q0 + i == len) {
+                            if ((int)(4u * e.cw.nwords) < lim) { e.finish(so); out_len = so.wpos; so.finish(true); }
+                            live = false;                      // (else: incompressible, out_len stays the raw length)
+                        }
+                    }
+                    put_byte((w >> (8 * i)) & 255u);
+                }
+                ovf = ovf || (live && (int)(4u * e.cw.nwords) >= lim);           // OVERFLOW per byte, monotone
+                live = live && !ovf;
             }
         }
     }
-    u32 out_len = 0;
-    if (alive) {
-        if (!ovf) { e.finish(so); out_len = so.wpos; }
-        else out_len = len;
-    }
-    so.finish(alive && !ovf);
+    if (live) { e.finish(so); out_len = so.wpos; }
+    so.finish(live);
     if (alive) clen[c] = out_len;
     const u32 gs = trc_wave_sum(out_len);
     if (lane == 0) gsum[wc.c0 >> 6] = gs;
@@ -142,9 +167,10 @@ __global__ __launch_bounds__(64) void trc_rcb_dec_kernel(
     RcDec dc;
     { const u32 a = si.peek32(); si.skip_if(coded); const u32 b = si.peek32(); si.skip_if(coded); dc.start(a, b); }
 
+    const u32 mcol = trc_lds_addr(smem) + lane * 2u;           // this lane's model column as an LDS byte address
     auto get_byte = [&](bool act) -> u32 {
         u32 ctx = 1;
-        u32 p = mb[64];
+        u32 p = trc_ldsr16(mcol + 128u);
 #pragma nounroll
         for (u32 j = 0; j < 4; j++) {
             {                                                  // renorm before bits 7,5,3,1 only
@@ -158,14 +184,13 @@ __global__ __launch_bounds__(64) void trc_rcb_dec_kernel(
             for (int h = 0; h < 2; h++) {
                 // both children are requested before this bit is known (below the last level the index wraps into the
                 // model and the values are unused)
-                const u32 lc = (2u * ctx) & 255u;
-                const u32 pl = mb[lc * 64], pr = mb[(lc + 1u) * 64];
+                const u32 lc = ((ctx << 8) & 0x7f00u) + mcol;  // row 2*ctx (mod 256), 128 bytes per row
+                const u32 pl = trc_ldsr16(lc), pr = trc_ldsr16(lc + 128u);
                 const u64 cut = (dc.range >> TRC_PROB_BITS) * p;
                 const bool one = dc.code < cut;                // rcbd_
-                const u64 nr = one ? cut : dc.range - cut, nc = one ? dc.code : dc.code - cut;
-                dc.range = act ? nr : dc.range;
-                dc.code = act ? nc : dc.code;
-                mb[ctx * 64] = (u16)rcb_adapt(p, one ? 1u : 0u);
+                dc.range = one ? cut : dc.range - cut;        // (lanes that are not decoding run along on their own registers
+                dc.code = one ? dc.code : dc.code - cut;       //  and model column: only `act` lanes consume stream words)
+                trc_ldsw16((ctx << 7) + mcol, rcb_adapt(p, one ? 1u : 0u));
                 ctx = ctx * 2 + (one ? 1u : 0u);
                 p = one ? pr : pl;
             }
