@@ -76,6 +76,8 @@ CODEC_INFO = {
     "anscdfvz16": ("Turbo-VLC (7-bit exponent) on zigzag deltas over the adaptive CDF rANS, 16-bit elements (anscdfvzenc16/anscdfvzdec16 per chunk)", "i16"),
     "anscdfv32": ("Turbo-VLC (7-bit exponent) over the adaptive CDF rANS, 32-bit elements (anscdfvenc32/anscdfvdec32 per chunk)", "i32"),
     "anscdfvz32": ("Turbo-VLC (7-bit exponent) on zigzag deltas over the adaptive CDF rANS, 32-bit elements (anscdfvzenc32/anscdfvzdec32 per chunk)", "i32"),
+    "rccdf8":   ("variable-length ('vnibble') adaptive-CDF range coder, 1-3 CDF16 symbols per byte (rccdfenc8/rccdfdec8 per chunk, `-e48`)", "small"),
+    "rccdfi8":  ("variable-length ('vnibble') adaptive-CDF range coder, 2 streams (rccdfienc8/rccdfidec8 per chunk, `-e49`)", "small"),
     "rccdf4":   ("adaptive-CDF nibble range coder (rccdf4enc/rccdf4dec per chunk), one CDF16 table per lane in LDS", "nib"),
     "rccdf4i":  ("adaptive-CDF nibble range coder, 2 streams (rccdf4ienc/rccdf4idec per chunk), one CDF16 table per lane in LDS", "nib"),
     "anscdf4":  ("adaptive-CDF nibble rANS, 2 states (anscdf4enc/anscdf4dec per chunk), one CDF16 table per lane in LDS", "nib"),
@@ -98,6 +100,8 @@ def make_input(n, rank, kind="text"):
         return T.runs_bytes(n, 3 + rank), "bwt%dm" % (n // 1000000)
     if kind in ("i16", "i32"):                               # slow random walk: what the zigzag-delta coders are for
         return T.int_bytes(n, 2 if kind == "i16" else 4, "walk", 9 + rank), "walk%dm-%s" % (n // 1000000, kind)
+    if kind == "small":
+        return T.small_bytes(n, 15 + rank, "geo"), "small%dm" % (n // 1000000)
     if kind == "nib":
         return T.nibble_bytes(n, 5 + rank, "runs"), "nib%dm" % (n // 1000000)
     return T.text_bytes(n, 7 + rank), "text%dm" % (n // 1000000)

@@ -103,6 +103,8 @@ static int bench(unsigned char *in, size_t n, unsigned char *out, unsigned char 
     case 45: name = "cdfsb interleaved (rccdfs2enc/rccdfsb2dec)"; e5 = rccdfs2enc; d5 = rccdfsb2dec; break;
     case 46: name = "cdf byte adaptive (rccdfenc/rccdfdec)"; e3 = rccdfenc; d3 = rccdfdec; break;
     case 47: name = "cdfi byte adaptive interleaved (rccdfienc/rccdfidec)"; e3 = rccdfienc; d3 = rccdfidec; break;
+    case 48: name = "cdf-8 variable-length (rccdfenc8/rccdfdec8)"; e3 = rccdfenc8; d3 = rccdfdec8; break;
+    case 49: name = "cdfi-8 variable-length interleaved (rccdfienc8/rccdfidec8)"; e3 = rccdfienc8; d3 = rccdfidec8; break;
     case 56: name = "ans auto (anscdfenc/anscdfdec)"; e3 = anscdfenc; d3 = anscdfdec; break;
     case 57: name = "ans s (anscdfencs/anscdfdecs)"; e3 = anscdfencs; d3 = anscdfdecs; break;
     case 58: name = "ans x (anscdfencx/anscdfdecx)"; e3 = anscdfencx; d3 = anscdfdecx; break;

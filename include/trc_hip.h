@@ -57,7 +57,10 @@ enum trc_codec {
     /* ... and over the adaptive CDF rANS (anscdf.c:139-483; -e60..63) */
     TRC_VLAU16 = 20,  TRC_VLAUZ16 = 21,  /* anscdfuenc16 / anscdfuzenc16 (+dec)        6-bit exponent, plain / zigzag deltas */
     TRC_VLAV16 = 22,  TRC_VLAVZ16 = 23,  /* anscdfvenc16 / anscdfvzenc16 (+dec)        7-bit exponent */
-    TRC_VLAV32 = 24,  TRC_VLAVZ32 = 25   /* anscdfvenc32 / anscdfvzenc32 (+dec) */
+    TRC_VLAV32 = 24,  TRC_VLAVZ32 = 25,  /* anscdfvenc32 / anscdfvzenc32 (+dec) */
+    /* "vnibble" coders: a byte becomes 1-3 CDF16 symbols on three adaptive tables (rccdf.c:326-390, rccdf_.h:76-98) */
+    TRC_RCV8 = 26,    /* rccdfenc8  / rccdfdec8    one stream    (-e48) */
+    TRC_RCVI8 = 27    /* rccdfienc8 / rccdfidec8   two streams   (-e49) */
 };
 
 #define TRC_MAGIC        0x31435254u   /* "TRC1" */

@@ -81,6 +81,12 @@ size_t rccdfvenc32(unsigned char *src, size_t srclen, unsigned char *dst);   siz
 size_t rccdfvzenc16(unsigned char *src, size_t srclen, unsigned char *dst);  size_t rccdfvzdec16(unsigned char *src, size_t dstlen, unsigned char *dst);
 size_t rccdfvzenc32(unsigned char *src, size_t srclen, unsigned char *dst);  size_t rccdfvzdec32(unsigned char *src, size_t dstlen, unsigned char *dst);
 
+/* "vnibble" coders (reference rccdf.c:326-390, include/turborc.h:531-534; `turborc -e48 / -e49`): a byte becomes one to
+ * three CDF16 symbols on three adaptive tables (0-12 | 13,14 + nibble | 15 + two nibbles) -- for data that is mostly small
+ * values; the `i` form codes the middle symbols on a second interleaved stream */
+size_t rccdfenc8(unsigned char *src, size_t srclen, unsigned char *dst);     size_t rccdfdec8(unsigned char *src, size_t dstlen, unsigned char *dst);
+size_t rccdfienc8(unsigned char *src, size_t srclen, unsigned char *dst);    size_t rccdfidec8(unsigned char *src, size_t dstlen, unsigned char *dst);
+
 /* bitwise order-0 range coder, "s" predictor (reference rc_.c:37-58; `turborc -e1`, file codec 1) */
 size_t rcsenc(unsigned char *src, size_t srclen, unsigned char *dst);
 size_t rcsdec(unsigned char *src, size_t dstlen, unsigned char *dst);

@@ -357,6 +357,88 @@ size_t orc_rccdfidec(const uint8_t *in, size_t outlen, uint8_t *out)
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* "vnibble" coders rccdfenc8 / rccdfdec8 (`turborc -e48`) and rccdfienc8 / rccdfidec8 (`-e49`):    */
+/* rccdf.c:326-390, symbol split cdfe8 / cdfd8 rccdf_.h:76-98.  A byte x becomes 1-3 CDF16 symbols */
+/* on three adaptive tables m0, m1, m2:                                                            */
+/*     x < 13        : m0 <- x                                                                     */
+/*     13 <= x < 45  : m0 <- 13 + ((x-13) >> 4)   (13 or 14),   m1 <- (x-13) & 15                   */
+/*     x >= 45       : m0 <- 15,   m1 <- (x-45) >> 4 (0..13),   m2 <- (x-45) & 15                   */
+/* One-stream form: all symbols on one range coder, OVERFLOW after every byte.  Interleaved form:   */
+/* the m0 and m2 symbols on stream 0 (base out+4), the m1 symbols on stream 1 (base out+4+inlen*37/64),*/
+/* OVERFLOWI after every full group of 4 bytes, header = u32 len0, OVERFLOW on the total; both     */
+/* streams are written into `out` itself as the reference does (out needs inlen + 64 bytes).        */
+typedef struct { uint16_t t[3][17]; } vnibmodel_t;
+static void vnib_reset(vnibmodel_t *m) { for (int k = 0; k < 3; k++) for (int j = 0; j <= 16; j++) m->t[k][j] = (uint16_t)(j << 11); }
+static inline void vnib_put(rce_t *e, uint16_t *t, unsigned y) { rce_sym(e, t[y], t[y + 1]); nib_adapt(t, y); }
+static inline void vnib_enc_byte(vnibmodel_t *m, rce_t *e0, rce_t *e1, unsigned x)
+{
+    if (x < 13) vnib_put(e0, m->t[0], x);
+    else if (x < 13 + 32) { x -= 13; vnib_put(e0, m->t[0], (x >> 4) + 13); vnib_put(e1, m->t[1], x & 15); }
+    else { x -= 13 + 32; vnib_put(e0, m->t[0], 15); vnib_put(e1, m->t[1], x >> 4); vnib_put(e0, m->t[2], x & 15); }
+}
+static inline unsigned vnib_dec_byte(vnibmodel_t *m, rcd_t *d0, rcd_t *d1)
+{
+    unsigned x = rcd_nibble(d0, m->t[0]);
+    if (x >= 13) {
+        unsigned y = rcd_nibble(d1, m->t[1]);
+        if (x != 15) x = (((x - 13) << 4) | y) + 13;
+        else { x = rcd_nibble(d0, m->t[2]); x = ((y << 4) | x) + 13 + 32; }
+    }
+    return x;
+}
+size_t orc_rccdfenc8(const uint8_t *in, size_t inlen, uint8_t *out)
+{
+    vnibmodel_t m; vnib_reset(&m);
+    rce_t e; rce_start(&e, out);
+    for (size_t i = 0; i < inlen; i++) {
+        vnib_enc_byte(&m, &e, &e, in[i]);
+        if (rc_overflow((size_t)(e.op - out), inlen)) { memcpy(out, in, inlen); return inlen; }
+    }
+    rce_finish(&e);
+    return (size_t)(e.op - out);
+}
+size_t orc_rccdfdec8(const uint8_t *in, size_t outlen, uint8_t *out)
+{
+    vnibmodel_t m; vnib_reset(&m);
+    rcd_t d; rcd_start(&d, in);
+    for (size_t i = 0; i < outlen; i++) out[i] = (uint8_t)vnib_dec_byte(&m, &d, &d);
+    return outlen;
+}
+size_t orc_rccdfienc8(const uint8_t *in, size_t inlen, uint8_t *out)
+{
+    vnibmodel_t m; vnib_reset(&m);
+    uint8_t *base0 = out + 4, *base1 = out + 4 + inlen * 37 / 64;
+    rce_t e0, e1; rce_start(&e0, base0); rce_start(&e1, base1);
+    size_t groups = inlen & ~(size_t)3;
+    for (size_t i = 0; i < inlen; i++) {
+        vnib_enc_byte(&m, &e0, &e1, in[i]);
+        if (i < groups && (i & 3) == 3)
+            if (rc_overflow((size_t)(e1.op - out), inlen) || e0.op >= base1) { memcpy(out, in, inlen); return inlen; }
+    }
+    rce_finish(&e0);
+    rce_finish(&e1);
+    size_t len0 = (size_t)(e0.op - base0), len1 = (size_t)(e1.op - base1);
+    /* the reference lets stream 0's last bytes run into stream 1's region when stream 0 ends within ~11 bytes past it (the
+     * tail and the flush are not tested): what it returns then cannot be decoded.  Stored raw here, like every other
+     * chunk the coder cannot represent (and the kernels, which keep the streams apart, do the same). */
+    if (e0.op > base1) { memcpy(out, in, inlen); return inlen; }
+    st32(out, (uint32_t)len0);
+    memmove(e0.op, base1, len1);
+    size_t total = 4 + len0 + len1;
+    if (rc_overflow(total, inlen)) { memcpy(out, in, inlen); return inlen; }
+    return total;
+}
+size_t orc_rccdfidec8(const uint8_t *in, size_t outlen, uint8_t *out)
+{
+    vnibmodel_t m; vnib_reset(&m);
+    rcd_t d0, d1;
+    rcd_start(&d0, in + 4);
+    rcd_start(&d1, in + 4 + ld32(in));
+    for (size_t i = 0; i < outlen; i++) out[i] = (uint8_t)vnib_dec_byte(&m, &d0, &d1);
+    return outlen;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* M6  32-bit rANS core, 16-bit renorm, 15-bit scale (anscdf_.h:33-48,90-94)                   */
 #define ANS_LO (1u << 15)
 static inline void ans_put(uint32_t *st, uint32_t c0, uint32_t f, uint8_t **ep)
@@ -1104,6 +1186,8 @@ static size_t enc_one(int codec, const uint8_t *in, size_t n, uint8_t *out, cons
     case ORC_VLAVZ16: return orc_anscdfvzenc16(in, n, out);
     case ORC_VLAV32:  return orc_anscdfvenc32(in, n, out);
     case ORC_VLAVZ32: return orc_anscdfvzenc32(in, n, out);
+    case ORC_RCV8:    return orc_rccdfenc8(in, n, out);
+    case ORC_RCVI8:   return orc_rccdfienc8(in, n, out);
     }
     return 0;
 }
@@ -1135,6 +1219,8 @@ static void dec_one(int codec, const uint8_t *in, size_t n, uint8_t *out, const 
     case ORC_VLAVZ16: orc_anscdfvzdec16(in, n, out); break;
     case ORC_VLAV32:  orc_anscdfvdec32(in, n, out); break;
     case ORC_VLAVZ32: orc_anscdfvzdec32(in, n, out); break;
+    case ORC_RCV8:    orc_rccdfdec8(in, n, out); break;
+    case ORC_RCVI8:   orc_rccdfidec8(in, n, out); break;
     }
 }
 size_t orc_chunked_enc(int codec, const uint8_t *in, size_t n, size_t chunk,

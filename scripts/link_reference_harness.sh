@@ -56,7 +56,7 @@ gcc $OBJS -L"$LIBDIR" -lturborc_hip -Wl,-rpath,"$LIBDIR" -lrt -lpthread -lm -o t
 # ---- 4. assertions ------------------------------------------------------------------------------------------
 fail=0
 MUST="cdfini rccdfsenc rccdfsbdec rccdfsldec rccdfsvbdec rccdfsvldec rccdfsmenc rccdfsmbdec rccdfsmldec rccdfs2enc rccdfsb2dec rccdfsl2dec
-rccdfenc rccdfdec rccdfienc rccdfidec rccdf4enc rccdf4dec rccdf4ienc rccdf4idec rcsenc rcsdec
+rccdfenc rccdfdec rccdfienc rccdfidec rccdf4enc rccdf4dec rccdf4ienc rccdf4idec rccdfenc8 rccdfdec8 rccdfienc8 rccdfidec8 rcsenc rcsdec
 rccdfuenc16 rccdfudec16 rccdfvenc16 rccdfvdec16 rccdfvzenc16 rccdfvzdec16 rccdfuenc32 rccdfvenc32 rccdfvzenc32
 anscdfenc anscdfdec anscdfencs anscdfdecs anscdfencx anscdfdecx anscdf4enc anscdf4dec anscdf1enc anscdf1dec anscdf4senc anscdf4sdec
 anscdfuenc16 anscdfuzenc16 anscdfvenc16 anscdfvzenc16 anscdfvenc32 anscdfvzenc32 ansbc ansbd"

@@ -111,6 +111,45 @@ def main_vlc():
     print("wrote", len(index), "vlc cases")
 
 
+def small_bytes(n, seed, kind):
+    """bytes that are mostly small values (what the vnibble coders are for)"""
+    u = (T.splitmix64(n, seed) >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+    if kind == "geo":
+        return np.minimum(np.floor(np.log1p(-u) / np.log(0.85)), 255).astype(np.uint8)
+    if kind == "mid":
+        return (13 + np.minimum(np.floor(np.log1p(-u) / np.log(0.9)), 200)).astype(np.uint8)
+    return gen(kind, n, seed)
+
+
+def main_vnib():
+    """"vnibble" coders rccdfenc8 / rccdfienc8 (`turborc -e48/-e49`): own fixture file.  Cases where the reference's
+    two-stream output cannot be decoded by the reference itself (stream 0 ran into stream 1, see oracle/trc_oracle.c) are
+    recorded as raw (`refbad`), which is what the oracle and the kernels produce."""
+    arrays, index = {}, []
+    ci = 0
+    for kind in ("geo", "mid", "zipf", "text", "uniform"):
+        for n in SMALL_SIZES + [16384, 65536]:
+            seed = 7000 + ci
+            d = small_bytes(n, seed, kind)
+            arrays["in_%d" % ci] = d
+            ent = dict(case=ci, kind=kind, n=n, seed=seed, out={}, refbad=[])
+            for codec in (T.RCV8, T.RCVI8):
+                o = T.ref_enc(codec, d)
+                name = T.CODEC_NAMES[codec]
+                if o.size != n and not np.array_equal(T.ref_dec(codec, o, n), d):
+                    assert codec == T.RCVI8 and 4 + int(o[:4].view(np.uint32)[0]) > 4 + n * 37 // 64
+                    ent["refbad"].append(name)
+                    o = d                                      # raw
+                ent["out"][name] = int(o.size)
+                if o.size != n:
+                    arrays["out_%d_%s" % (ci, name)] = o
+            index.append(ent)
+            ci += 1
+    arrays["index"] = np.frombuffer(json.dumps(index).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "vnib_vectors.npz"), **arrays)
+    print("wrote", len(index), "vnibble cases,", sum(len(e["refbad"]) for e in index), "stored raw where the reference output is undecodable")
+
+
 def main():
     assert T.have_ref(), "reference build missing: make -C oracle"
     arrays, index = {}, []
@@ -167,8 +206,12 @@ def main():
 
 
 if __name__ == "__main__":
+    if "--vnib-only" in sys.argv:
+        main_vnib()
+        sys.exit(0)
     if "--nibble-only" not in sys.argv and "--vlc-only" not in sys.argv:
         main()
     if "--vlc-only" not in sys.argv:
         main_nibble()
     main_vlc()
+    main_vnib()

@@ -112,7 +112,9 @@ def test_mixed_raw_and_coded_chunks(torch_cuda, codec):
 def test_golden_vectors_single_chunk(torch_cuda, codec):
     """n <= 65536 with chunk >= n: the one payload must equal the reference's whole-buffer output"""
     nib = codec in SMALL_ALPHABET
-    z = np.load(os.path.join(GOLD, "vlc_vectors.npz" if codec in trc.VLC_CODECS else "nibble_vectors.npz" if nib else "vectors.npz"))
+    vnib = codec in (trc.RCV8, trc.RCVI8)
+    z = np.load(os.path.join(GOLD, "vlc_vectors.npz" if codec in trc.VLC_CODECS else "vnib_vectors.npz" if vnib else
+                             "nibble_vectors.npz" if nib else "vectors.npz"))
     index = json.loads(bytes(z["index"]).decode())
     name = trc.CODEC_NAMES[codec]
     done = 0
@@ -123,7 +125,7 @@ def test_golden_vectors_single_chunk(torch_cuda, codec):
         n = ent["n"]
         chunk = min(65536, max(256, (n + 63) // 64 * 64))
         cdf = np.zeros(257, dtype=np.uint16)
-        if not nib:
+        if not nib and not vnib:
             cdf[:ent["cdfnum"] + 1] = z["cdf_%d" % ent["case"]]
         dc = trc.DeviceCoder(codec, n, chunk, "cuda:0")
         if codec in trc.STATIC:
@@ -377,10 +379,10 @@ def test_c_harness_links_and_roundtrips(torch_cuda):
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-s", "-C", os.path.join(root, "harness")])
     for args in (["--zipf", "3000001"], ["--text", "1000000", "-c", "1024"], ["--uniform", "500000"], ["--nibble", "2000003"]):
-        r = subprocess.run([exe, "-I", "1", "-e", "1,42,43,44,45,46,47,56,57,58,64,65,66,79"] + args, capture_output=True, text=True, timeout=300)
+        r = subprocess.run([exe, "-I", "1", "-e", "1,42,43,44,45,46,47,48,49,56,57,58,64,65,66,79"] + args, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         assert "MISMATCH" not in r.stdout and "failed" not in r.stdout, r.stdout
-        assert r.stdout.count(":") >= 15, r.stdout            # every requested id printed its row
+        assert r.stdout.count(":") >= 17, r.stdout            # every requested id printed its row
         assert ("nibble" in r.stdout) == (args[0] == "--nibble")   # values 0..15 route ids 46/47/56-58 to the one-table coders
     for args in (["--int16", "2000000"], ["--int32", "4000000"]):        # integer series: the Turbo-VLC coders
         r = subprocess.run([exe, "-I", "1", "-e", "50,52,53,60,61,62,63"] + args, capture_output=True, text=True, timeout=300)
@@ -438,10 +440,11 @@ def test_reference_harness_runs_on_the_gpu_library(torch_cuda, tmp_path):
     d.tofile(src)
     _, cdf, _ = T.orc_cdfini(d, 256)                           # the harness: cdfini(in, n, cdf, 0x100), then cdfnum = m + 1 (turborc.c:429-433)
     m1 = int(d.max()) + 1
-    r = subprocess.run([exe, "-I1", "-J1", "-e1,42,43,44,45,46,47,56,57,58,64,66", str(src)], capture_output=True, text=True, timeout=600, env=env)
+    r = subprocess.run([exe, "-I1", "-J1", "-e1,42,43,44,45,46,47,48,49,56,57,58,64,66", str(src)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "ERROR" not in r.stdout and "ERROR" not in r.stderr, r.stdout[-3000:] + r.stderr[-2000:]
     got = rows(r.stdout)
-    ids = {1: trc.RCB, 42: trc.RCS1, 43: trc.RCS1, 44: trc.RCSM, 45: trc.RCS2, 46: trc.RCA, 47: trc.RCAI, 56: trc.ANSA, 57: trc.ANSA,
+    ids = {1: trc.RCB, 42: trc.RCS1, 43: trc.RCS1, 44: trc.RCSM, 45: trc.RCS2, 46: trc.RCA, 47: trc.RCAI, 48: trc.RCV8, 49: trc.RCVI8,
+           56: trc.ANSA, 57: trc.ANSA,
            58: trc.ANSA, 64: trc.ANSO1, 66: trc.ANSB}
     nch = trc.nchunks(n, chunk)
     for i, codec in ids.items():

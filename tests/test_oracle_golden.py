@@ -138,3 +138,17 @@ def test_headline_bench_config_hash():
     assert payload.size == g["payload_bytes"]
     assert hashlib.sha256(clen.astype("<u4").tobytes()).hexdigest() == g["clen_sha256"]
     assert hashlib.sha256(payload.tobytes()).hexdigest() == g["payload_sha256"]
+
+
+@pytest.mark.parametrize("codec", [T.RCV8, T.RCVI8], ids=lambda c: T.CODEC_NAMES[c])
+def test_vnibble_golden_vectors(codec):
+    """rccdfenc8 / rccdfienc8 (`turborc -e48/-e49`): the oracle against the committed reference outputs"""
+    z = np.load(os.path.join(GOLD, "vnib_vectors.npz"))
+    index = json.loads(bytes(z["index"]).decode())
+    name = T.CODEC_NAMES[codec]
+    for ent in index:
+        d, n = z["in_%d" % ent["case"]], ent["n"]
+        o = T.orc_enc(codec, d)
+        assert o.size == ent["out"][name], (ent["kind"], n)
+        assert np.array_equal(o, d if o.size == n else z["out_%d_%s" % (ent["case"], name)]), (ent["kind"], n)
+        assert np.array_equal(T.orc_dec(codec, o, n), d)

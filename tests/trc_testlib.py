@@ -21,10 +21,12 @@ REF_SO = os.path.join(ORACLE_DIR, "_ref", "libtrc_ref.so")
 ANS4S, RCS1, RCS2, RCA, ANSA, RCB, RCAI, RCA4, RCAI4, ANSA4, RCSM, ANSO1, ANSB = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13
 VLCU16, VLCU32, VLCV16, VLCV32, VLCVZ16, VLCVZ32 = 14, 15, 16, 17, 18, 19   # Turbo-VLC integer coders
 VLAU16, VLAUZ16, VLAV16, VLAVZ16, VLAV32, VLAVZ32 = 20, 21, 22, 23, 24, 25   # ... over the CDF rANS
+RCV8, RCVI8 = 26, 27                                                          # "vnibble" coders (rccdfenc8 / rccdfienc8, ids 48/49)
 CODEC_NAMES = {ANS4S: "anscdf4s", RCS1: "rccdfs", RCS2: "rccdfs2", RCA: "rccdf", ANSA: "anscdf", RCB: "rcs", RCAI: "rccdfi",
                RCA4: "rccdf4", RCAI4: "rccdf4i", ANSA4: "anscdf4", RCSM: "rccdfsm", ANSO1: "anscdf1", ANSB: "ansb",
                VLCU16: "rccdfu16", VLCU32: "rccdfu32", VLCV16: "rccdfv16", VLCV32: "rccdfv32", VLCVZ16: "rccdfvz16", VLCVZ32: "rccdfvz32",
-               VLAU16: "anscdfu16", VLAUZ16: "anscdfuz16", VLAV16: "anscdfv16", VLAVZ16: "anscdfvz16", VLAV32: "anscdfv32", VLAVZ32: "anscdfvz32"}
+               VLAU16: "anscdfu16", VLAUZ16: "anscdfuz16", VLAV16: "anscdfv16", VLAVZ16: "anscdfvz16", VLAV32: "anscdfv32", VLAVZ32: "anscdfvz32",
+               RCV8: "rccdf8", RCVI8: "rccdfi8"}
 VLA_CODECS = (VLAU16, VLAUZ16, VLAV16, VLAVZ16, VLAV32, VLAVZ32)
 VLC_CODECS = (VLCU16, VLCU32, VLCV16, VLCV32, VLCVZ16, VLCVZ32) + VLA_CODECS
 VLC_ELEM = {VLCU16: 2, VLCU32: 4, VLCV16: 2, VLCV32: 4, VLCVZ16: 2, VLCVZ32: 4,
@@ -39,7 +41,8 @@ _ADAPTIVE = {RCA: ("rccdfenc", "rccdfdec"), ANSA: ("anscdfenc", "anscdfdec"), RC
              VLCVZ16: ("rccdfvzenc16", "rccdfvzdec16"), VLCVZ32: ("rccdfvzenc32", "rccdfvzdec32"),
              VLAU16: ("anscdfuenc16", "anscdfudec16"), VLAUZ16: ("anscdfuzenc16", "anscdfuzdec16"),
              VLAV16: ("anscdfvenc16", "anscdfvdec16"), VLAVZ16: ("anscdfvzenc16", "anscdfvzdec16"),
-             VLAV32: ("anscdfvenc32", "anscdfvdec32"), VLAVZ32: ("anscdfvzenc32", "anscdfvzdec32")}
+             VLAV32: ("anscdfvenc32", "anscdfvdec32"), VLAVZ32: ("anscdfvzenc32", "anscdfvzdec32"),
+             RCV8: ("rccdfenc8", "rccdfdec8"), RCVI8: ("rccdfienc8", "rccdfidec8")}
 STATIC_CODECS = (ANS4S, RCS1, RCS2, RCSM)
 
 _u8p = C.POINTER(C.c_uint8)
@@ -178,6 +181,15 @@ def nibble_bytes(n, seed=5, kind="geo"):
         while v.size < n:
             v = np.concatenate([v, v])
     return v[:n].copy()
+
+
+def small_bytes(n, seed=15, kind="geo"):
+    """bytes that are mostly small values -- what the vnibble coders (`turborc -e48/-e49`) are for.
+    geo: geometric from 0; mid: geometric from 13 (the two-symbol range)"""
+    u = (splitmix64(n, seed) >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+    if kind == "mid":
+        return (13 + np.minimum(np.floor(np.log1p(-u) / np.log(0.9)), 200)).astype(np.uint8)
+    return np.minimum(np.floor(np.log1p(-u) / np.log(0.85)), 255).astype(np.uint8)
 
 
 def int_bytes(n, es, kind="walk", seed=9):

@@ -63,7 +63,7 @@ extern "C" int trc_set_chunk(uint32_t chunk)
 #define TRC_INKERNEL_SCAN_MAX 8192u
 static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline bool is_static(int codec) { return codec == TRC_ANS4S || codec == TRC_RCS1 || codec == TRC_RCS2 || codec == TRC_RCSM; }
-static inline bool codec_ok(int codec) { return codec >= TRC_ANS4S && codec <= TRC_VLAVZ32; }
+static inline bool codec_ok(int codec) { return codec >= TRC_ANS4S && codec <= TRC_RCVI8; }
 static inline bool is_vlc(int codec) { return codec >= TRC_VLCU16 && codec <= TRC_VLCVZ32; }
 static inline int vlc_variant(int codec) { return (codec - TRC_VLCU16) >> 1; }      // 0 u, 1 v, 2 vz
 static inline int vlc_elem(int codec) { return ((codec - TRC_VLCU16) & 1) ? 4 : 2; }
@@ -71,7 +71,7 @@ static inline bool is_vla(int codec) { return codec >= TRC_VLAU16 && codec <= TR
 static inline int vla_variant(int codec) { return codec <= TRC_VLAUZ16 ? 0 : 1; }                          // 0 u, 1 v
 static inline int vla_zz(int codec) { return (codec - TRC_VLAU16) & 1; }
 static inline int vla_elem(int codec) { return codec >= TRC_VLAV32 ? 4 : 2; }
-static inline bool two_streams(int codec) { return codec == TRC_RCS2 || codec == TRC_RCAI || codec == TRC_RCAI4; }
+static inline bool two_streams(int codec) { return codec == TRC_RCS2 || codec == TRC_RCAI || codec == TRC_RCAI4 || codec == TRC_RCVI8; }
 // second scratch array: RCS2 stream 1 (same stride) or ANSA's record stack (8 B per input byte + one segment)
 static inline size_t scratch2_stride(int codec, uint32_t chunk)
 {
@@ -94,7 +94,7 @@ extern "C" size_t trc_work_bytes(int codec, size_t n, uint32_t chunk)
     return up256(TRC_TAB_BYTES) + up256(4 * ngroups) + up256(8 * (ngroups + 1)) +
            up256(nchunks * (size_t)scratch_stride(codec, chunk)) + up256(nchunks * scratch2_stride(codec, chunk) + 256) +
            (codec == TRC_ANSO1 ? up256(nchunks * (size_t)TRC_O1_MODEL_BYTES) : 0) +
-           (codec >= TRC_VLCU16 ? up256(nchunks * 8) : 0) + 4096;
+           ((codec >= TRC_VLCU16 && codec <= TRC_VLAVZ32) ? up256(nchunks * 8) : 0) + 4096;
 }
 
 static int carve(int codec, size_t n, uint32_t chunk, void *d_work, size_t work_bytes, TrcWork &w)
@@ -271,6 +271,8 @@ extern "C" int trc_encode_dev(int codec, const void *d_in, size_t n, uint32_t ch
     case TRC_ANSA:  trc_launch_ansa_enc(0, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 1; break;
     case TRC_ANSA4: trc_launch_ansa_enc(1, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 1; break;
     case TRC_ANSB:  trc_launch_ansb_enc((const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 1; break;
+    case TRC_RCV8:  trc_launch_rcv_enc(1, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 0; break;
+    case TRC_RCVI8: trc_launch_rcv_enc(2, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 2; break;
     default:        if (is_vlc(codec)) { trc_launch_vlc_enc(vlc_variant(codec), vlc_elem(codec), (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 3; }
                     else if (is_vla(codec)) { trc_launch_vla_enc(vla_variant(codec), vla_zz(codec), vla_elem(codec), (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 4; }
                     break;
@@ -318,6 +320,8 @@ extern "C" int trc_decode_dev(int codec, const uint32_t *d_clen, const void *d_p
     case TRC_ANSA4: trc_launch_ansa_dec(1, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     case TRC_ANSO1: trc_launch_anso1_dec((const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     case TRC_ANSB:  trc_launch_ansb_dec((const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
+    case TRC_RCV8:  trc_launch_rcv_dec(1, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
+    case TRC_RCVI8: trc_launch_rcv_dec(2, (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
     default:        if (is_vlc(codec)) trc_launch_vlc_dec(vlc_variant(codec), vlc_elem(codec), (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s);
                     else if (is_vla(codec)) trc_launch_vla_dec(vla_variant(codec), vla_zz(codec), vla_elem(codec), (const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s);
                     break;
@@ -337,6 +341,7 @@ extern "C" const char *trc_kernel_name(int codec, int decode)
     case TRC_ANSA: case TRC_ANSA4: return decode ? "trc_ansa_dec_kernel" : "trc_ansa_model_kernel";
     case TRC_ANSO1: return decode ? "trc_o1_dec_kernel" : "trc_o1_model_kernel";
     case TRC_ANSB: return decode ? "trc_ansb_dec_kernel" : "trc_ansb_model_kernel";
+    case TRC_RCV8: case TRC_RCVI8: return decode ? "trc_rcv_dec_kernel" : "trc_rcv_enc_kernel";
     default: if (is_vlc(codec)) return decode ? "trc_vlc_dec_kernel" : "trc_vlc_enc_kernel";
              if (is_vla(codec)) return decode ? "trc_vla_dec_kernel" : "trc_vla_model_kernel";
     }
@@ -552,6 +557,12 @@ size_t rccdfdec(unsigned char *in, size_t outlen, unsigned char *out) { return h
 // interleaved adaptive-CDF byte range coder (reference rccdf.c:213-249; turborc -e47) -- SURVEY 8f rank 1
 size_t rccdfienc(unsigned char *in, size_t inlen, unsigned char *out) { return host_encode(TRC_RCAI, in, inlen, out, nullptr, 0); }
 size_t rccdfidec(unsigned char *in, size_t outlen, unsigned char *out) { return host_decode(TRC_RCAI, in, outlen, out, nullptr, 0); }
+
+// "vnibble" adaptive-CDF range coders (reference rccdf.c:326-390; turborc -e48 / -e49)
+size_t rccdfenc8(unsigned char *in, size_t inlen, unsigned char *out) { return host_encode(TRC_RCV8, in, inlen, out, nullptr, 0); }
+size_t rccdfdec8(unsigned char *in, size_t outlen, unsigned char *out) { return host_decode(TRC_RCV8, in, outlen, out, nullptr, 0); }
+size_t rccdfienc8(unsigned char *in, size_t inlen, unsigned char *out) { return host_encode(TRC_RCVI8, in, inlen, out, nullptr, 0); }
+size_t rccdfidec8(unsigned char *in, size_t outlen, unsigned char *out) { return host_decode(TRC_RCVI8, in, outlen, out, nullptr, 0); }
 
 // adaptive-CDF byte rANS (reference anscdf.c:567-605, dispatch :816-817; turborc -e56 / -e57 / -e58)
 #define TRC_EXPORT_ANSA(sfx) \

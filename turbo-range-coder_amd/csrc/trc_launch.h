@@ -86,6 +86,11 @@ void trc_launch_rca_enc(int nstreams, int nibble, const uint8_t *d_in, size_t n,
 void trc_launch_rca_dec(int nstreams, int nibble, const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                         const TrcWork &w, uint8_t *d_out, hipStream_t s);
 
+// RCV8 / RCVI8: "vnibble" adaptive-CDF range coders, 1 or 2 streams (rccdfenc8 / rccdfienc8 and their decoders)
+void trc_launch_rcv_enc(int nstreams, const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s);
+void trc_launch_rcv_dec(int nstreams, const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
+                        const TrcWork &w, uint8_t *d_out, hipStream_t s);
+
 // ANSA: adaptive-CDF byte rANS (anscdfenc / anscdfdec); scratch2 holds the 8 B/byte record stack
 // nibble != 0: anscdf4enc / anscdf4dec on values 0..15 (2 states, 4 B/byte record stack)
 void trc_launch_ansa_enc(int nibble, const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s);

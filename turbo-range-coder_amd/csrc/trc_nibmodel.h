@@ -26,9 +26,11 @@ typedef short trc_s2 __attribute__((ext_vector_type(2)));
 #define TRC_NIB_ROW     560u                      // bytes per lane, byte model (17 tables)
 #define TRC_NIB1_ROW    48u                       // bytes per lane, single table
 #define TRC_NIB2_ROW    80u                       // bytes per lane, two tables (Turbo-VLC coders): 20 dwords, conflict free like the others
+#define TRC_NIB3_ROW    112u                      // bytes per lane, three tables (vnibble coders): 28 dwords, lane*28 mod 64 hits 16 distinct bank groups
 #define TRC_NIB_BYTES   (TRC_NIBK_BYTES + 64u * TRC_NIB_ROW)      // 36352 per wave
 #define TRC_NIB1_BYTES  (TRC_NIBK_BYTES + 64u * TRC_NIB1_ROW)     // 3584 per wave
 #define TRC_NIB2_BYTES  (TRC_NIBK_BYTES + 64u * TRC_NIB2_ROW)     // 5632 per wave
+#define TRC_NIB3_BYTES  (TRC_NIBK_BYTES + 64u * TRC_NIB3_ROW)     // 7680 per wave
 
 struct NibTable { u32 d[8]; };                    // 16 x u16, entry 2k in the low half of d[k]
 
@@ -36,10 +38,10 @@ __device__ __forceinline__ u32 trc_pk(u32 lo, u32 hi) { return (lo & 0xffffu) | 
 __device__ __forceinline__ trc_s2 trc_as_s2(u32 v) { return __builtin_bit_cast(trc_s2, v); }
 __device__ __forceinline__ u32 trc_as_u32(trc_s2 v) { return __builtin_bit_cast(u32, v); }
 
-// NT = tables per lane: 17 (byte model), 1 (nibble coders), 2 (Turbo-VLC coders)
+// NT = tables per lane: 17 (byte model), 1 (nibble coders), 2 (Turbo-VLC coders), 3 (vnibble coders)
 template <int NT>
 struct NibModel {
-    static constexpr u32 ROW = NT == 17 ? TRC_NIB_ROW : NT == 1 ? TRC_NIB1_ROW : TRC_NIB2_ROW;
+    static constexpr u32 ROW = NT == 17 ? TRC_NIB_ROW : NT == 1 ? TRC_NIB1_ROW : NT == 3 ? TRC_NIB3_ROW : TRC_NIB2_ROW;
     u8 *kb;                                       // this wave's K table
     u8 *row;                                      // this lane's tables
     // smem = this wave's model area (TRC_NIB_BYTES / TRC_NIB1_BYTES); every lane of the wave must call
@@ -96,6 +98,13 @@ struct NibModel {
         u32 c0, c1; bounds(tb, x, c0, c1);
         NibTable T = load(tb); adapt(T, x); store(tb, T);
         return (c0 << TRC_PROB_BITS) | (c1 - c0);
+    }
+    // the same where `on`; elsewhere the table stays as it is and the record is 0 (freq 0: never coded)
+    __device__ __forceinline__ u32 record_if(bool on, u8 *tb, u32 x) const
+    {
+        u32 r = 0;
+        if (on) r = record(tb, x);
+        return r;
     }
 };
 

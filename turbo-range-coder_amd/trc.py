@@ -19,10 +19,12 @@ LIB = os.environ.get("TRC_LIB") or os.path.join(PKG, "libturborc_hip.so")   # TR
 ANS4S, RCS1, RCS2, RCA, ANSA, RCB, RCAI, RCA4, RCAI4, ANSA4, RCSM, ANSO1, ANSB = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13
 VLCU16, VLCU32, VLCV16, VLCV32, VLCVZ16, VLCVZ32 = 14, 15, 16, 17, 18, 19   # Turbo-VLC integer coders
 VLAU16, VLAUZ16, VLAV16, VLAVZ16, VLAV32, VLAVZ32 = 20, 21, 22, 23, 24, 25   # ... over the CDF rANS
+RCV8, RCVI8 = 26, 27                                                          # "vnibble" coders (turborc -e48 / -e49)
 CODEC_NAMES = {ANS4S: "anscdf4s", RCS1: "rccdfs", RCS2: "rccdfs2", RCA: "rccdf", ANSA: "anscdf", RCB: "rcs", RCAI: "rccdfi",
                RCA4: "rccdf4", RCAI4: "rccdf4i", ANSA4: "anscdf4", RCSM: "rccdfsm", ANSO1: "anscdf1", ANSB: "ansb",
                VLCU16: "rccdfu16", VLCU32: "rccdfu32", VLCV16: "rccdfv16", VLCV32: "rccdfv32", VLCVZ16: "rccdfvz16", VLCVZ32: "rccdfvz32",
-               VLAU16: "anscdfu16", VLAUZ16: "anscdfuz16", VLAV16: "anscdfv16", VLAVZ16: "anscdfvz16", VLAV32: "anscdfv32", VLAVZ32: "anscdfvz32"}
+               VLAU16: "anscdfu16", VLAUZ16: "anscdfuz16", VLAV16: "anscdfv16", VLAVZ16: "anscdfvz16", VLAV32: "anscdfv32", VLAVZ32: "anscdfvz32",
+               RCV8: "rccdf8", RCVI8: "rccdfi8"}
 VLC_CODECS = (VLCU16, VLCU32, VLCV16, VLCV32, VLCVZ16, VLCVZ32, VLAU16, VLAUZ16, VLAV16, VLAVZ16, VLAV32, VLAVZ32)
 VLC_ELEM = {VLCU16: 2, VLCU32: 4, VLCV16: 2, VLCV32: 4, VLCVZ16: 2, VLCVZ32: 4,
             VLAU16: 2, VLAUZ16: 2, VLAV16: 2, VLAVZ16: 2, VLAV32: 4, VLAVZ32: 4}
@@ -30,7 +32,7 @@ NIBBLE_CODECS = (RCA4, RCAI4, ANSA4)                           # `turborc -n` co
 STATIC = (ANS4S, RCS1, RCS2, RCSM)
 TABLES_READY = 0x100                                          # include/trc_hip.h
 DIR_READY = 0x200
-AVAILABLE = (ANS4S, RCS1, RCS2, RCB, RCA, ANSA, RCAI, RCA4, RCAI4, ANSA4, RCSM, ANSO1, ANSB) + VLC_CODECS          # codecs with HIP kernels behind them (grows per round)
+AVAILABLE = (ANS4S, RCS1, RCS2, RCB, RCA, ANSA, RCAI, RCA4, RCAI4, ANSA4, RCSM, ANSO1, ANSB) + VLC_CODECS + (RCV8, RCVI8)          # codecs with HIP kernels behind them (grows per round)
 PAD = 256
 HDR = 32
 
@@ -194,11 +196,13 @@ class DeviceCoder:
 _HOST_ENC = {ANS4S: "anscdf4senc", RCS1: "rccdfsenc", RCS2: "rccdfs2enc", RCA: "rccdfenc", ANSA: "anscdfenc", RCB: "rcsenc", RCAI: "rccdfienc",
              RCA4: "rccdf4enc", RCAI4: "rccdf4ienc", ANSA4: "anscdf4enc", RCSM: "rccdfsmenc", ANSO1: "anscdf1enc", ANSB: "ansbc",
              VLCU16: "rccdfuenc16", VLCU32: "rccdfuenc32", VLCV16: "rccdfvenc16", VLCV32: "rccdfvenc32", VLCVZ16: "rccdfvzenc16", VLCVZ32: "rccdfvzenc32",
-             VLAU16: "anscdfuenc16", VLAUZ16: "anscdfuzenc16", VLAV16: "anscdfvenc16", VLAVZ16: "anscdfvzenc16", VLAV32: "anscdfvenc32", VLAVZ32: "anscdfvzenc32"}
+             VLAU16: "anscdfuenc16", VLAUZ16: "anscdfuzenc16", VLAV16: "anscdfvenc16", VLAVZ16: "anscdfvzenc16", VLAV32: "anscdfvenc32", VLAVZ32: "anscdfvzenc32",
+             RCV8: "rccdfenc8", RCVI8: "rccdfienc8"}
 _HOST_DEC = {ANS4S: "anscdf4sdec", RCS1: "rccdfsbdec", RCS2: "rccdfsb2dec", RCA: "rccdfdec", ANSA: "anscdfdec", RCB: "rcsdec", RCAI: "rccdfidec",
              RCA4: "rccdf4dec", RCAI4: "rccdf4idec", ANSA4: "anscdf4dec", RCSM: "rccdfsmbdec", ANSO1: "anscdf1dec", ANSB: "ansbd",
              VLCU16: "rccdfudec16", VLCU32: "rccdfudec32", VLCV16: "rccdfvdec16", VLCV32: "rccdfvdec32", VLCVZ16: "rccdfvzdec16", VLCVZ32: "rccdfvzdec32",
-             VLAU16: "anscdfudec16", VLAUZ16: "anscdfuzdec16", VLAV16: "anscdfvdec16", VLAVZ16: "anscdfvzdec16", VLAV32: "anscdfvdec32", VLAVZ32: "anscdfvzdec32"}
+             VLAU16: "anscdfudec16", VLAUZ16: "anscdfuzdec16", VLAV16: "anscdfvdec16", VLAVZ16: "anscdfvzdec16", VLAV32: "anscdfvdec32", VLAVZ32: "anscdfvzdec32",
+             RCV8: "rccdfdec8", RCVI8: "rccdfidec8"}
 
 
 def _host_fn(name, codec):
