@@ -349,26 +349,128 @@ extern "C" const char *trc_kernel_name(int codec, int decode)
 }
 
 // --------------------------------------------------- layer 1: reference prototypes (host pointers) ---
+// A TurboRC-style caller hands over pageable host buffers and times the whole call, so this layer is a PCIe pipeline:
+//   * the buffer is cut into slices (whole groups of 64 chunks, ~16 MB); slice i+1 is on its way to the GPU while slice i
+//     is coded and slice i-1 travels back: three streams (H2D, kernels, D2H) tied by events, both DMA directions busy at
+//     once (PCIe Gen5 x16 measured on the MI355X box: 57 GB/s one way, 48 GB/s each way when both run);
+//   * a hipMemcpyAsync on pageable memory returns only when the copy is done (measured: two directions from one thread
+//     = 28 GB/s each), so transfers go through pinned staging buffers, filled and emptied by a small pool of copy threads
+//     (one thread moves 28 GB/s, four 110 GB/s); registering the caller's buffers instead costs 5.5 ms per 100 MB and a
+//     registration must not outlive memory the caller may free;
+//   * one context per DEVICE (the caller's current device at the time of the call), each with its own lock: calls on one
+//     device serialise, calls on different devices do not.
+#include <condition_variable>
+#include <thread>
+#include <vector>
 namespace {
+// ---- copy threads: memcpy(dst, src, len) split over the pool, caller blocks until done --------------------------
+class CopyPool {
+public:
+    // never destroyed: its threads are detached and wait on the condition variable for the life of the process
+    // (destroying a condition variable with waiters blocks in glibc: a process would hang at exit).
+    // Two pools: 0 fills the staging buffers on the way in, 1 empties them on the way out -- both directions at once.
+    static CopyPool &get(int which) { static CopyPool *p[2] = { new CopyPool, new CopyPool }; return *p[which]; }
+    // start a copy on the pool's threads and return; wait() blocks until it is done (one copy in flight per pool)
+    void start(void *dst, const void *src, size_t len)
+    {
+        wait();
+        if (len == 0) return;
+        if (nthr_ == 0) { memcpy(dst, src, len); return; }
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            dst_ = (uint8_t *)dst; src_ = (const uint8_t *)src; len_ = len; next_ = 0; pending_ = nthr_; gen_++;
+        }
+        cv_.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [&] { return pending_ == 0; });
+    }
+    // copy with the caller's help, blocking
+    void copy(void *dst, const void *src, size_t len)
+    {
+        if (len < (1u << 20)) { wait(); memcpy(dst, src, len); return; }
+        start(dst, src, len);
+        work();
+        wait();
+    }
+private:
+    static constexpr size_t PIECE = 1u << 19;
+    CopyPool()
+    {
+        const char *e = getenv("TRC_COPY_THREADS");
+        nthr_ = e ? atoi(e) : 6;                                            // per pool (+ the calling thread in copy())
+        if (nthr_ < 0) nthr_ = 0;
+        if (nthr_ > 15) nthr_ = 15;
+        for (int i = 0; i < nthr_; i++) std::thread([this] { loop(); }).detach();
+    }
+    void work()
+    {
+        for (;;) {
+            size_t o;
+            { std::lock_guard<std::mutex> lk(mu_); if (next_ >= len_) return; o = next_; next_ += PIECE; }
+            memcpy(dst_ + o, src_ + o, len_ - o < PIECE ? len_ - o : PIECE);
+        }
+    }
+    void loop()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            { std::unique_lock<std::mutex> lk(mu_); cv_.wait(lk, [&] { return gen_ != seen; }); seen = gen_; }
+            work();
+            { std::lock_guard<std::mutex> lk(mu_); if (--pending_ == 0) done_.notify_all(); }
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    uint8_t *dst_ = nullptr; const uint8_t *src_ = nullptr;
+    size_t len_ = 0, next_ = 0;
+    int nthr_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+};
+
+#define TRC_NSLOT 3                                  // staging slots per direction
 struct HostCtx {
     std::mutex mu;
     bool init = false;
-    hipStream_t stream = nullptr;
+    int dev = -1;
+    hipStream_t s_in = nullptr, s_k = nullptr, s_out = nullptr;
     uint8_t *d_in = nullptr;   size_t cap_in = 0;      // plain bytes (encode input / decode output)
     uint8_t *d_cont = nullptr; size_t cap_cont = 0;    // container: hdr | clen[] | payload
     uint8_t *d_work = nullptr; size_t cap_work = 0;
-    uint8_t *d_small = nullptr;                        // cdf (1 KiB) | total (8) | status (4)
+    uint8_t *d_small = nullptr;                        // cdf (1 KiB) | totals (8 B x 4096 slices at 2048) | status
+    uint8_t *pin_in[TRC_NSLOT] = {}, *pin_out[TRC_NSLOT] = {}; size_t cap_pin = 0;
+    uint64_t *pin_tot = nullptr;                       // pinned: per-slice totals
+    hipEvent_t ev_in[TRC_NSLOT] = {}, ev_k[TRC_NSLOT] = {}, ev_out[TRC_NSLOT] = {};
 };
-HostCtx g_ctx;
+#define TRC_MAX_DEV 64
+HostCtx g_ctxs[TRC_MAX_DEV];
 
-int ctx_init(HostCtx &c)
+int ctx_get(HostCtx *&out)
 {
-    if (c.init) return TRC_OK;
-    int ndev = 0;
+    int ndev = 0, dev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(TRC_E_NODEV, "no HIP device: libturborc_hip has no CPU coding path");
-    HIPCHK(hipStreamCreate(&c.stream));
-    HIPCHK(hipMalloc((void **)&c.d_small, 4096));
+    HIPCHK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= TRC_MAX_DEV) return fail(TRC_E_ARG, "device %d out of range", dev);
+    out = &g_ctxs[dev];
+    return TRC_OK;
+}
+int ctx_init(HostCtx &c, int dev)
+{
+    if (c.init) return TRC_OK;
+    c.dev = dev;
+    HIPCHK(hipStreamCreateWithFlags(&c.s_in, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c.s_k, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c.s_out, hipStreamNonBlocking));
+    HIPCHK(hipMalloc((void **)&c.d_small, 65536));
+    HIPCHK(hipHostMalloc((void **)&c.pin_tot, 4096 * sizeof(uint64_t)));
+    for (int i = 0; i < TRC_NSLOT; i++) {
+        HIPCHK(hipEventCreateWithFlags(&c.ev_in[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c.ev_k[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c.ev_out[i], hipEventDisableTiming));
+    }
     c.init = true;
     return TRC_OK;
 }
@@ -383,6 +485,23 @@ int grow(uint8_t **p, size_t *cap, size_t need)
     *cap = want;
     return TRC_OK;
 }
+int grow_pins(HostCtx &c, size_t need)
+{
+    need = up256(need + TRC_PAD);
+    if (c.cap_pin >= need) return TRC_OK;
+    for (int i = 0; i < TRC_NSLOT; i++) {
+        if (c.pin_in[i]) HIPCHK(hipHostFree(c.pin_in[i]));
+        if (c.pin_out[i]) HIPCHK(hipHostFree(c.pin_out[i]));
+        c.pin_in[i] = c.pin_out[i] = nullptr;
+    }
+    c.cap_pin = 0;
+    for (int i = 0; i < TRC_NSLOT; i++) {
+        HIPCHK(hipHostMalloc((void **)&c.pin_in[i], need));
+        HIPCHK(hipHostMalloc((void **)&c.pin_out[i], need));
+    }
+    c.cap_pin = need;
+    return TRC_OK;
+}
 // cdfnum = index of the terminating 1<<15 (cdf is strictly increasing from 0)
 int host_cdfnum(const cdf_t *cdf)
 {
@@ -393,16 +512,32 @@ int host_cdfnum(const cdf_t *cdf)
     }
     return -1;
 }
+// chunks per slice: whole groups of 64 chunks, ~16 MB of input (TRC_HOST_SLICE overrides the byte target; 8-32 MB
+// measure alike on the MI355X box, 4 MB is 30 % slower: per-slice synchronisation)
+size_t slice_chunks(uint32_t chunk, size_t nchunks)
+{
+    static const size_t target = getenv("TRC_HOST_SLICE") ? (size_t)strtoull(getenv("TRC_HOST_SLICE"), 0, 10) : (size_t)16 << 20;
+    size_t groups = target / ((size_t)chunk * 64);
+    if (groups < 1) groups = 1;
+    size_t per = groups * 64;
+    while ((nchunks + per - 1) / per > 2048) per *= 2;                    // the totals area holds 2048 slices
+    return per;
+}
 }  // namespace
+
+#define HCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fail(TRC_E_HIP, "%s -> %s", #x, hipGetErrorString(e_)); return 0; } } while (0)
 
 // ---- host-pointer encode/decode shared by every reference-signature export --------------------
 static size_t host_encode(int codec, const unsigned char *in, size_t inlen, unsigned char *out,
                           const cdf_t *cdf, int cdfnum)
 {
-    HostCtx &c = g_ctx;
-    std::lock_guard<std::mutex> lk(c.mu);
     if (inlen == 0) return 0;
-    if (ctx_init(c)) return 0;
+    HostCtx *cp = nullptr;
+    if (ctx_get(cp)) return 0;
+    HostCtx &c = *cp;
+    std::lock_guard<std::mutex> lk(c.mu);
+    int dev = 0; HCHK(hipGetDevice(&dev));
+    if (ctx_init(c, dev)) return 0;
     uint32_t chunk = trc_get_chunk();
     if (codec == TRC_ANSB && chunk > TRC_ANSB_CHUNK_MAX) chunk = TRC_ANSB_CHUNK_MAX;
     const size_t nchunks = (inlen + chunk - 1) / chunk, dir = 4 * nchunks, hdrsz = sizeof(trc_container_hdr);
@@ -410,39 +545,93 @@ static size_t host_encode(int codec, const unsigned char *in, size_t inlen, unsi
         if (cdfnum <= 0) cdfnum = host_cdfnum(cdf);
         if (cdfnum <= 0 || cdfnum > 256) { fail(TRC_E_CDF, "bad CDF (need cdf[0]=0 < ... < cdf[cdfnum]=32768)"); return 0; }
     } else cdfnum = 0;
-    const size_t wb = trc_work_bytes(codec, inlen, chunk);
-    if (grow(&c.d_in, &c.cap_in, inlen) || grow(&c.d_cont, &c.cap_cont, hdrsz + dir + inlen + 64) || grow(&c.d_work, &c.cap_work, wb)) return 0;
+    const size_t per = slice_chunks(chunk, nchunks), nsl = (nchunks + per - 1) / per;
+    const size_t slice_bytes = per * (size_t)chunk;
+    const size_t wb = trc_work_bytes(codec, slice_bytes < inlen ? slice_bytes : inlen, chunk);
+    if (grow(&c.d_in, &c.cap_in, inlen) || grow(&c.d_cont, &c.cap_cont, hdrsz + dir + inlen + 64) || grow(&c.d_work, &c.cap_work, wb) ||
+        grow_pins(c, slice_bytes + 4 * per + 64)) return 0;
     uint16_t *d_cdf = (uint16_t *)c.d_small;
-    uint64_t *d_total = (uint64_t *)(c.d_small + 2048);
-#define HCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fail(TRC_E_HIP, "%s -> %s", #x, hipGetErrorString(e_)); return 0; } } while (0)
-    HCHK(hipMemcpyAsync(c.d_in, in, inlen, hipMemcpyHostToDevice, c.stream));
-    if (cdfnum) HCHK(hipMemcpyAsync(d_cdf, cdf, (cdfnum + 1) * sizeof(cdf_t), hipMemcpyHostToDevice, c.stream));
+    uint64_t *d_tot = (uint64_t *)(c.d_small + 2048);
     uint32_t *d_clen = (uint32_t *)(c.d_cont + hdrsz);
     uint8_t *d_payload = c.d_cont + hdrsz + dir;
-    if (trc_encode_dev(codec, c.d_in, inlen, chunk, cdfnum ? d_cdf : nullptr, (unsigned)cdfnum, d_clen, d_payload, d_total,
-                       c.d_work, c.cap_work, c.stream)) return 0;
-    uint64_t total = 0;
-    HCHK(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, c.stream));
-    HCHK(hipStreamSynchronize(c.stream));
-    const size_t clen_total = hdrsz + dir + (size_t)total;
-    if (clen_total >= inlen) { memcpy(out, in, inlen); return inlen; }      // reference convention: == inlen => raw
+    int flags = 0;
+    if (cdfnum) {
+        HCHK(hipMemcpyAsync(d_cdf, cdf, (cdfnum + 1) * sizeof(cdf_t), hipMemcpyHostToDevice, c.s_k));
+        if (trc_tables_dev(d_cdf, (unsigned)cdfnum, c.d_work, c.cap_work, c.s_k)) return 0;
+        flags = TRC_TABLES_READY;
+    }
+    // Slice i: stage (copy threads) -> H2D (s_in) -> encode (s_k) -> size known (host) -> D2H (s_out) -> unstage.  The loop
+    // runs three stages at once: it stages slice i+1 and fetches slice i-1 while slice i is being coded.
+    size_t ppos = 0;                 // payload bytes already placed in `out`
+    size_t dpos = 0;                 // device payload offset of the next slice (each slice's payload starts 2-byte aligned: sums of even lengths... kept explicit)
+    bool raw = false;
+    const size_t lim = inlen > hdrsz + dir ? inlen - hdrsz - dir : 0;      // payload bytes above which the call returns raw
+    auto slice_len = [&](size_t i) { const size_t o = i * slice_bytes; return inlen - o < slice_bytes ? inlen - o : slice_bytes; };
+    auto put_in = [&](size_t i) -> bool {                                   // stage + H2D of slice i
+        const int k = (int)(i % TRC_NSLOT);
+        const size_t o = i * slice_bytes, l = slice_len(i);
+        if (i >= TRC_NSLOT && hipEventSynchronize(c.ev_in[k]) != hipSuccess) return false;   // slot free: its last H2D is done
+        CopyPool::get(0).copy(c.pin_in[k], in + o, l);
+        if (hipMemcpyAsync(c.d_in + o, c.pin_in[k], l, hipMemcpyHostToDevice, c.s_in) != hipSuccess) return false;
+        return hipEventRecord(c.ev_in[k], c.s_in) == hipSuccess;
+    };
+    struct Pending { size_t i, pos, tot; bool live; } pend = { 0, 0, 0, false };
+    auto fetch = [&](Pending &p) -> bool {                                  // unstage slice p.i (its D2H was enqueued earlier): starts the copy, returns
+        if (!p.live) return true;
+        const int k = (int)(p.i % TRC_NSLOT);
+        if (hipEventSynchronize(c.ev_out[k]) != hipSuccess) return false;
+        const size_t nc = (p.i + 1) * per <= nchunks ? per : nchunks - p.i * per;
+        memcpy(out + hdrsz + 4 * p.i * per, c.pin_out[k], 4 * nc);
+        CopyPool::get(1).start(out + hdrsz + dir + p.pos, c.pin_out[k] + 4 * per, p.tot);
+        p.live = false;
+        return true;
+    };
+    if (!put_in(0)) { fail(TRC_E_HIP, "host encode: staging failed"); return 0; }
+    for (size_t i = 0; i < nsl; i++) {
+        const int k = (int)(i % TRC_NSLOT);
+        const size_t o = i * slice_bytes, l = slice_len(i), c0 = i * per;
+        HCHK(hipStreamWaitEvent(c.s_k, c.ev_in[k], 0));
+        if (trc_encode_dev(codec | flags, c.d_in + o, l, chunk, cdfnum ? d_cdf : nullptr, (unsigned)cdfnum, d_clen + c0, d_payload + dpos,
+                           d_tot + i, c.d_work, c.cap_work, c.s_k)) return 0;
+        HCHK(hipMemcpyAsync(c.pin_tot + i, d_tot + i, 8, hipMemcpyDeviceToHost, c.s_k));
+        HCHK(hipEventRecord(c.ev_k[k], c.s_k));
+        if (i + 1 < nsl && !put_in(i + 1)) { fail(TRC_E_HIP, "host encode: staging failed"); return 0; }   // overlaps slice i's kernels and slice i-1's way back
+        if (!fetch(pend)) { fail(TRC_E_HIP, "host encode: fetch failed"); return 0; }                         // slice i-1 has arrived: the out-pool copies it to `out` ...
+        HCHK(hipEventSynchronize(c.ev_k[k]));                                                                 // ... while this thread waits for slice i's size
+        const size_t tot = (size_t)c.pin_tot[i];
+        if (raw || ppos + tot >= lim) { raw = true; dpos += (tot + 1) & ~(size_t)1; continue; }               // (keep going: cheap, and the state stays simple)
+        const size_t nc = c0 + per <= nchunks ? per : nchunks - c0;
+        // (slot k's previous content, slice i-3, left it two fetches ago: start() waits for the copy before it)
+        HCHK(hipStreamWaitEvent(c.s_out, c.ev_k[k], 0));
+        HCHK(hipMemcpyAsync(c.pin_out[k], d_clen + c0, 4 * nc, hipMemcpyDeviceToHost, c.s_out));
+        HCHK(hipMemcpyAsync(c.pin_out[k] + 4 * per, d_payload + dpos, tot, hipMemcpyDeviceToHost, c.s_out));
+        HCHK(hipEventRecord(c.ev_out[k], c.s_out));
+        pend = { i, ppos, tot, true };
+        ppos += tot;
+        dpos += (tot + 1) & ~(size_t)1;
+    }
+    if (!fetch(pend)) { fail(TRC_E_HIP, "host encode: fetch failed"); return 0; }
+    CopyPool::get(1).wait();
+    HCHK(hipStreamSynchronize(c.s_in));
+    if (raw) { memcpy(out, in, inlen); return inlen; }                      // reference convention: == inlen => raw
     trc_container_hdr h;
     memset(&h, 0, sizeof h);
     h.magic = TRC_MAGIC; h.codec = (uint8_t)codec; h.version = 1; h.cdfnum = (uint16_t)cdfnum;
-    h.chunk = chunk; h.nchunks = (uint32_t)nchunks; h.n = inlen; h.payload = total;
+    h.chunk = chunk; h.nchunks = (uint32_t)nchunks; h.n = inlen; h.payload = ppos;
     memcpy(out, &h, hdrsz);
-    HCHK(hipMemcpyAsync(out + hdrsz, c.d_cont + hdrsz, dir + (size_t)total, hipMemcpyDeviceToHost, c.stream));
-    HCHK(hipStreamSynchronize(c.stream));
-    return clen_total;
+    return hdrsz + dir + ppos;
 }
 
 static size_t host_decode(int codec, const unsigned char *in, size_t outlen, unsigned char *out,
                           const cdf_t *cdf, int cdfnum)
 {
-    HostCtx &c = g_ctx;
-    std::lock_guard<std::mutex> lk(c.mu);
     if (outlen == 0) return 0;
-    if (ctx_init(c)) return 0;
+    HostCtx *cp = nullptr;
+    if (ctx_get(cp)) return 0;
+    HostCtx &c = *cp;
+    std::lock_guard<std::mutex> lk(c.mu);
+    int dev = 0; HCHK(hipGetDevice(&dev));
+    if (ctx_init(c, dev)) return 0;
     trc_container_hdr h;
     memcpy(&h, in, sizeof h);
     if (h.magic != TRC_MAGIC || h.version != 1 || h.codec != codec || h.n != outlen ||
@@ -450,7 +639,8 @@ static size_t host_decode(int codec, const unsigned char *in, size_t outlen, uns
         fail(TRC_E_ARG, "not a TRC1 container for codec %d / length %zu (raw streams must be memcpy'd by the caller)", codec, outlen);
         return 0;
     }
-    const size_t hdrsz = sizeof h, dir = 4 * (size_t)h.nchunks;
+    const size_t hdrsz = sizeof h, nchunks = h.nchunks, dir = 4 * nchunks;
+    const uint32_t chunk = h.chunk;
     // the prototype carries no input length: what is read from `in` is bounded by the caller's own outlen (header
     // fields were checked against it above) and the directory must add up to the payload the header states
     if (trc_container_check(in, hdrsz + dir + (size_t)h.payload, codec, outlen)) return 0;
@@ -458,15 +648,74 @@ static size_t host_decode(int codec, const unsigned char *in, size_t outlen, uns
         if (cdfnum <= 0) cdfnum = host_cdfnum(cdf);
         if (cdfnum <= 0 || cdfnum > 256) { fail(TRC_E_CDF, "bad CDF"); return 0; }
     } else cdfnum = 0;
-    const size_t wb = trc_work_bytes(codec, outlen, h.chunk);
-    if (grow(&c.d_in, &c.cap_in, outlen) || grow(&c.d_cont, &c.cap_cont, hdrsz + dir + outlen + 64) || grow(&c.d_work, &c.cap_work, wb)) return 0;
+    const size_t per = slice_chunks(chunk, nchunks), nsl = (nchunks + per - 1) / per;
+    const size_t slice_bytes = per * (size_t)chunk;
+    const size_t wb = trc_work_bytes(codec, slice_bytes < outlen ? slice_bytes : outlen, chunk);
+    if (grow(&c.d_in, &c.cap_in, outlen) || grow(&c.d_cont, &c.cap_cont, hdrsz + dir + outlen + 64 + 2 * nsl) || grow(&c.d_work, &c.cap_work, wb) ||
+        grow_pins(c, slice_bytes + 4 * per + 64)) return 0;
     uint16_t *d_cdf = (uint16_t *)c.d_small;
-    HCHK(hipMemcpyAsync(c.d_cont + hdrsz, in + hdrsz, dir + (size_t)h.payload, hipMemcpyHostToDevice, c.stream));
-    if (cdfnum) HCHK(hipMemcpyAsync(d_cdf, cdf, (cdfnum + 1) * sizeof(cdf_t), hipMemcpyHostToDevice, c.stream));
-    if (trc_decode_dev(codec, (const uint32_t *)(c.d_cont + hdrsz), c.d_cont + hdrsz + dir, outlen, h.chunk,
-                       cdfnum ? d_cdf : nullptr, (unsigned)cdfnum, c.d_in, c.d_work, c.cap_work, c.stream)) return 0;
-    HCHK(hipMemcpyAsync(out, c.d_in, outlen, hipMemcpyDeviceToHost, c.stream));
-    HCHK(hipStreamSynchronize(c.stream));
+    uint32_t *d_clen = (uint32_t *)(c.d_cont + hdrsz);
+    uint8_t *d_payload = c.d_cont + hdrsz + dir;
+    int flags = 0;
+    if (cdfnum) {
+        HCHK(hipMemcpyAsync(d_cdf, cdf, (cdfnum + 1) * sizeof(cdf_t), hipMemcpyHostToDevice, c.s_k));
+        if (trc_tables_dev(d_cdf, (unsigned)cdfnum, c.d_work, c.cap_work, c.s_k)) return 0;
+        flags = TRC_TABLES_READY;
+    }
+    // payload bytes of every slice from the directory (the decoders clamp an entry above the chunk length to "raw")
+    std::vector<size_t> pstart(nsl + 1, 0);
+    for (size_t i = 0; i < nsl; i++) {
+        const size_t c0 = i * per, c1 = c0 + per < nchunks ? c0 + per : nchunks;
+        size_t sum = 0;
+        for (size_t k = c0; k < c1; k++) {
+            uint32_t l; memcpy(&l, in + hdrsz + 4 * k, 4);
+            const size_t len = (k + 1 == nchunks) ? outlen - k * (size_t)chunk : chunk;
+            sum += l < len ? l : len;
+        }
+        pstart[i + 1] = pstart[i] + sum;
+    }
+    auto slice_len = [&](size_t i) { const size_t o = i * slice_bytes; return outlen - o < slice_bytes ? outlen - o : slice_bytes; };
+    auto put_in = [&](size_t i) -> bool {                                   // stage + H2D of slice i's directory and payload
+        const int k = (int)(i % TRC_NSLOT);
+        const size_t c0 = i * per, nc = c0 + per <= nchunks ? per : nchunks - c0, pl = pstart[i + 1] - pstart[i];
+        if (i >= TRC_NSLOT && hipEventSynchronize(c.ev_in[k]) != hipSuccess) return false;
+        memcpy(c.pin_in[k], in + hdrsz + 4 * c0, 4 * nc);
+        CopyPool::get(0).copy(c.pin_in[k] + 4 * per, in + hdrsz + dir + pstart[i], pl);
+        // (payload offsets may be odd only for corrupt directories; the device layer wants 2-byte alignment: keep the slice's own offset even)
+        if (hipMemcpyAsync(d_clen + c0, c.pin_in[k], 4 * nc, hipMemcpyHostToDevice, c.s_in) != hipSuccess) return false;
+        if (hipMemcpyAsync(d_payload + ((pstart[i] + 1) & ~(size_t)1) + 2 * i, c.pin_in[k] + 4 * per, pl, hipMemcpyHostToDevice, c.s_in) != hipSuccess) return false;
+        return hipEventRecord(c.ev_in[k], c.s_in) == hipSuccess;
+    };
+    struct Pending { size_t i; bool live; } pend = { 0, false };
+    auto fetch = [&](Pending &p) -> bool {
+        if (!p.live) return true;
+        const int k = (int)(p.i % TRC_NSLOT);
+        if (hipEventSynchronize(c.ev_out[k]) != hipSuccess) return false;
+        CopyPool::get(1).start(out + p.i * slice_bytes, c.pin_out[k], slice_len(p.i));
+        p.live = false;
+        return true;
+    };
+    if (!put_in(0)) { fail(TRC_E_HIP, "host decode: staging failed"); return 0; }
+    for (size_t i = 0; i < nsl; i++) {
+        const int k = (int)(i % TRC_NSLOT);
+        const size_t o = i * slice_bytes, l = slice_len(i), c0 = i * per;
+        HCHK(hipStreamWaitEvent(c.s_k, c.ev_in[k], 0));
+        if (i >= TRC_NSLOT) HCHK(hipStreamWaitEvent(c.s_k, c.ev_out[k], 0));   // (d_in + o is private to the slice: nothing to wait for; kept for symmetry of the slots)
+        if (trc_decode_dev(codec | flags, d_clen + c0, d_payload + ((pstart[i] + 1) & ~(size_t)1) + 2 * i, l, chunk, cdfnum ? d_cdf : nullptr, (unsigned)cdfnum,
+                           c.d_in + o, c.d_work, c.cap_work, c.s_k)) return 0;
+        HCHK(hipEventRecord(c.ev_k[k], c.s_k));
+        // slice i's way back is queued BEFORE slice i-1 is copied out of its staging slot (different slots): the D2H
+        // engine never waits for the host
+        HCHK(hipStreamWaitEvent(c.s_out, c.ev_k[k], 0));
+        HCHK(hipMemcpyAsync(c.pin_out[k], c.d_in + o, l, hipMemcpyDeviceToHost, c.s_out));
+        HCHK(hipEventRecord(c.ev_out[k], c.s_out));
+        if (!fetch(pend)) { fail(TRC_E_HIP, "host decode: fetch failed"); return 0; }                         // slice i-1: out-pool copies it to `out` ...
+        if (i + 1 < nsl && !put_in(i + 1)) { fail(TRC_E_HIP, "host decode: staging failed"); return 0; }   // ... while slice i+1 is staged by the in-pool
+        pend = { i, true };
+    }
+    if (!fetch(pend)) { fail(TRC_E_HIP, "host decode: fetch failed"); return 0; }
+    CopyPool::get(1).wait();
+    HCHK(hipStreamSynchronize(c.s_in));
     return outlen;
 }
 
@@ -503,20 +752,23 @@ extern "C" {
 // cdfini: reference rccdf.c:50-68.  Returns (int)inlen; -1 where the reference would die().
 int cdfini(unsigned char *in, size_t inlen, cdf_t *cdf, unsigned cdfnum)
 {
-    HostCtx &c = g_ctx;
-    std::lock_guard<std::mutex> lk(c.mu);
     if (!inlen || cdfnum < 1 || cdfnum > 256) { fail(TRC_E_ARG, "cdfini: inlen=%zu cdfnum=%u", inlen, cdfnum); return -1; }
-    if (ctx_init(c)) return -1;
+    HostCtx *cp = nullptr;
+    if (ctx_get(cp)) return -1;
+    HostCtx &c = *cp;
+    std::lock_guard<std::mutex> lk(c.mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || ctx_init(c, dev)) return -1;
     if (grow(&c.d_in, &c.cap_in, inlen) || grow(&c.d_work, &c.cap_work, 4096)) return -1;
     uint16_t *d_cdf = (uint16_t *)c.d_small;
-    int32_t *d_status = (int32_t *)(c.d_small + 2056);
+    int32_t *d_status = (int32_t *)(c.d_small + 32768);
 #define ICHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fail(TRC_E_HIP, "%s -> %s", #x, hipGetErrorString(e_)); return -1; } } while (0)
-    ICHK(hipMemcpyAsync(c.d_in, in, inlen, hipMemcpyHostToDevice, c.stream));
-    if (trc_cdfini_dev(c.d_in, inlen, d_cdf, cdfnum, d_status, c.d_work, c.stream)) return -1;
+    ICHK(hipMemcpyAsync(c.d_in, in, inlen, hipMemcpyHostToDevice, c.s_k));
+    if (trc_cdfini_dev(c.d_in, inlen, d_cdf, cdfnum, d_status, c.d_work, c.s_k)) return -1;
     int32_t st = -1;
-    ICHK(hipMemcpyAsync(&st, d_status, 4, hipMemcpyDeviceToHost, c.stream));
-    ICHK(hipMemcpyAsync(cdf, d_cdf, (cdfnum + 1) * sizeof(cdf_t), hipMemcpyDeviceToHost, c.stream));
-    ICHK(hipStreamSynchronize(c.stream));
+    ICHK(hipMemcpyAsync(&st, d_status, 4, hipMemcpyDeviceToHost, c.s_k));
+    ICHK(hipMemcpyAsync(cdf, d_cdf, (cdfnum + 1) * sizeof(cdf_t), hipMemcpyDeviceToHost, c.s_k));
+    ICHK(hipStreamSynchronize(c.s_k));
     if (st < 0) { fail(TRC_E_CDF, "cdfini: distribution cannot be normalised to a strictly increasing 15-bit CDF"); return -1; }
     return (int)inlen;
 }
