@@ -1,0 +1,131 @@
+/* trcgather.c -- plain-C multi-GPU driver: one process per GPU, chunk ranges sharded over the ranks, static rANS, results
+ * gathered onto rank 0 over RCCL through the library's own entry points (trc_hist_allreduce_dev, trc_exchange_dev) --
+ * what a TurboRC-style C caller needs to run `--gpus N` without any Python.
+ *
+ *   trcgather --gpus N [--size BYTES] [--chunk BYTES] [--steps K]
+ *
+ * The parent forks N ranks; rank r takes HIP device r.  Rank 0 creates the RCCL unique id and hands it to the others
+ * through a file.  Every rank generates the same synthetic input (so rank 0 can verify), codes its contiguous range of
+ * whole chunks with the CDF of the WHOLE input (histogram all-reduce), and the per-rank directory slices and payloads
+ * are gathered onto rank 0, where the assembled container is decoded in one piece and compared with the input.
+ * Prints encode+gather MB/s (MB = 10^6, input-referred, best of K).  With --gpus 1 the exchange degenerates to the
+ * size all-gather and a device copy (the 1-GPU self-test the test suite runs). */
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/wait.h>
+#include <time.h>
+#include <unistd.h>
+#include "../include/trc_hip.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "rank %d: %s -> %s\n", rank, #x, hipGetErrorString(e_)); exit(3); } } while (0)
+#define NK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { fprintf(stderr, "rank %d: %s -> %s\n", rank, #x, ncclGetErrorString(r_)); exit(3); } } while (0)
+#define TK(x) do { if ((x) != 0) { fprintf(stderr, "rank %d: %s -> %s\n", rank, #x, trc_last_error()); exit(3); } } while (0)
+static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+static size_t up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static int run_rank(int rank, int world, size_t n, uint32_t chunk, int steps, const char *idfile)
+{
+    CK(hipSetDevice(rank));
+    ncclUniqueId id;
+    if (rank == 0) {
+        NK(ncclGetUniqueId(&id));
+        char tmp[512]; snprintf(tmp, sizeof tmp, "%s.tmp", idfile);
+        FILE *f = fopen(tmp, "wb"); fwrite(&id, sizeof id, 1, f); fclose(f); rename(tmp, idfile);
+    } else {
+        FILE *f = 0;
+        for (int i = 0; i < 6000 && !(f = fopen(idfile, "rb")); i++) usleep(10000);
+        if (!f || fread(&id, sizeof id, 1, f) != 1) { fprintf(stderr, "rank %d: no unique id\n", rank); return 3; }
+        fclose(f);
+    }
+    ncclComm_t comm;
+    NK(ncclCommInitRank(&comm, world, id, rank));
+    hipStream_t s; CK(hipStreamCreate(&s));
+
+    /* the whole input on every rank's host (for rank 0's check); Zipf-like bytes from a splitmix64 stream */
+    unsigned char *h = (unsigned char *)malloc(n + 512);
+    uint64_t z = 0x9E3779B97F4A7C15ull;
+    for (size_t i = 0; i < n; i++) {
+        z += 0x9E3779B97F4A7C15ull; uint64_t x = z; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; x ^= x >> 31;
+        const unsigned u = (unsigned)(x >> 40) & 0xffff, v = (unsigned)(((uint64_t)u * u) >> 16);   /* skewed: 4th power of a uniform value */
+        h[i] = (unsigned char)(((uint64_t)v * v) >> 24);
+    }
+    const size_t nch = (n + chunk - 1) / chunk, per = nch / world, rem = nch % world;
+    const size_t c0 = rank * per + (rank < (int)rem ? rank : rem), mych = per + (rank < (int)rem ? 1 : 0);
+    const size_t off = c0 * chunk, mylen = mych ? ((c0 + mych) * (size_t)chunk < n ? mych * (size_t)chunk : n - off) : 0;
+
+    unsigned char *d_in, *d_payload, *d_work, *d_all_payload = 0, *d_out = 0, *d_meta;
+    uint32_t *d_clen, *d_all_clen = 0; uint64_t *d_total, *d_hist; uint16_t *d_cdf; int32_t *d_status;
+    const size_t wb = trc_work_bytes(TRC_ANS4S, mylen ? mylen : chunk, chunk), wball = trc_work_bytes(TRC_ANS4S, n, chunk);
+    CK(hipMalloc((void **)&d_in, up(mylen + 512))); CK(hipMalloc((void **)&d_payload, up(mylen + 512)));
+    CK(hipMalloc((void **)&d_clen, up(4 * mych + 256))); CK(hipMalloc((void **)&d_total, 256)); CK(hipMalloc((void **)&d_hist, 4096));
+    CK(hipMalloc((void **)&d_cdf, 1024)); CK(hipMalloc((void **)&d_status, 256)); CK(hipMalloc((void **)&d_meta, 16 * (world + 1) + 256));
+    CK(hipMalloc((void **)&d_work, rank == 0 ? (wball > wb ? wball : wb) + 256 : wb + 256));
+    if (rank == 0) { CK(hipMalloc((void **)&d_all_payload, up(n + 512))); CK(hipMalloc((void **)&d_all_clen, up(4 * nch + 256))); CK(hipMalloc((void **)&d_out, up(n + 512))); }
+    CK(hipMemsetAsync(d_in, 0, up(mylen + 512), s));
+    CK(hipMemcpyAsync(d_in, h + off, mylen, hipMemcpyHostToDevice, s));
+    CK(hipMemsetAsync(d_total, 0, 8, s));
+
+    /* one CDF for the whole job */
+    TK(trc_hist_dev(d_in, mylen, d_hist, s));
+    TK(trc_hist_allreduce_dev(comm, d_hist, s));
+    TK(trc_cdf_from_hist_dev(d_hist, n, d_cdf, 256, d_status, s));
+    int32_t st = 0; CK(hipMemcpyAsync(&st, d_status, 4, hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s));
+    if (st < 0) { fprintf(stderr, "rank %d: cdfini failed\n", rank); return 3; }
+
+    uint64_t *sizes = (uint64_t *)malloc(16 * world);
+    trc_batch b; memset(&b, 0, sizeof b);
+    b.d_clen = d_clen; b.nchunks = mych; b.d_payload = d_payload; b.d_total = d_total; b.d_clen_all = d_all_clen; b.d_payload_all = d_all_payload;
+    double best = 1e30;
+    for (int k = 0; k < steps + 1; k++) {                       /* first pass untimed (connections, allocations) */
+        CK(hipStreamSynchronize(s));
+        double t0 = now();
+        if (mylen) TK(trc_encode_dev(TRC_ANS4S, d_in, mylen, chunk, d_cdf, 256, d_clen, d_payload, d_total, d_work, wb, s));
+        TK(trc_exchange_dev(comm, 1, &b, sizes, d_meta, s));
+        CK(hipStreamSynchronize(s));
+        double t1 = now();
+        if (k && t1 - t0 < best) best = t1 - t0;
+    }
+    int rc = 0;
+    if (rank == 0) {
+        uint64_t total = 0, chunks = 0;
+        for (int r = 0; r < world; r++) { total += sizes[2 * r]; chunks += sizes[2 * r + 1]; }
+        if (chunks != nch) { printf("FAILED: gathered %llu chunks, expected %zu\n", (unsigned long long)chunks, nch); rc = 1; }
+        TK(trc_decode_dev(TRC_ANS4S, d_all_clen, d_all_payload, n, chunk, d_cdf, 256, d_out, d_work, wball, s));
+        unsigned char *back = (unsigned char *)malloc(n);
+        CK(hipMemcpyAsync(back, d_out, n, hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s));
+        if (memcmp(back, h, n)) { printf("FAILED: the gathered container does not decode to the input\n"); rc = 1; }
+        printf("%d GPU(s): %zu bytes -> %llu (%.2f%%), encode + gather %.1f MB/s%s\n", world, n, (unsigned long long)(32 + 4 * nch + total),
+               100.0 * (32 + 4 * nch + total) / n, n / best / 1e6, rc ? "" : "  [container verified on rank 0]");
+        unlink(idfile);
+    }
+    ncclCommDestroy(comm);
+    return rc;
+}
+
+int main(int argc, char **argv)
+{
+    int world = 1, steps = 3; size_t n = 100u * 1000 * 1000; uint32_t chunk = 512;
+    for (int i = 1; i < argc; i++) {
+        if (!strcmp(argv[i], "--gpus") && i + 1 < argc) world = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--size") && i + 1 < argc) n = (size_t)strtoull(argv[++i], 0, 10);
+        else if (!strcmp(argv[i], "--chunk") && i + 1 < argc) chunk = (uint32_t)atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--steps") && i + 1 < argc) steps = atoi(argv[++i]);
+        else { fprintf(stderr, "usage: trcgather --gpus N [--size BYTES] [--chunk BYTES] [--steps K]\n"); return 2; }
+    }
+    if (world < 1 || world > 64 || !n) return 2;
+    char idfile[256]; snprintf(idfile, sizeof idfile, "/tmp/trcgather_%d.id", (int)getpid());
+    if (world == 1) return run_rank(0, 1, n, chunk, steps, idfile);
+    pid_t pids[64];
+    for (int r = 0; r < world; r++) {
+        pids[r] = fork();                                       /* fork BEFORE any HIP call: each rank initialises its own runtime */
+        if (pids[r] == 0) _exit(run_rank(r, world, n, chunk, steps, idfile));
+    }
+    int bad = 0;
+    for (int r = 0; r < world; r++) { int st = 0; waitpid(pids[r], &st, 0); if (!WIFEXITED(st) || WEXITSTATUS(st)) bad = 1; }
+    return bad;
+}

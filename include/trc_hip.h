@@ -66,7 +66,9 @@ enum trc_codec {
 #define TRC_MAGIC        0x31435254u   /* "TRC1" */
 #define TRC_CHUNK_MIN    256u
 #define TRC_CHUNK_MAX    65536u        /* chunk must be a multiple of 64 in [MIN, MAX] */
-#define TRC_CHUNK_DEFAULT 4096u
+#define TRC_CHUNK_DEFAULT 1024u        /* the parallel unit is the chunk: at 100 MB per GPU 4096 leaves 1.5 waves per CU (static rANS
+                                          147 GB/s), 1024 six (385 GB/s), 512 twelve (514 GB/s); payload ratio on text 63.50 / 63.94 /
+                                          64.52 %.  Gigabyte inputs fill the chip at 4096 too: pick by input size. */
 #define TRC_ANSB_CHUNK_MAX 8192u       /* TRC_ANSB only: one 8192-byte block of the reference per chunk */
 #define TRC_PAD          256u          /* readable slack the device entry points need after every buffer */
 
@@ -144,6 +146,28 @@ int trc_encode_dev(int codec, const void *d_in, size_t n, uint32_t chunk,
 int trc_decode_dev(int codec, const uint32_t *d_clen, const void *d_payload, size_t n, uint32_t chunk,
                    const uint16_t *d_cdf, unsigned cdfnum,
                    void *d_out, void *d_work, size_t work_bytes, void *stream);
+
+/* ---- multi-GPU: the gather of results over RCCL (xGMI), plain C ------------------------------------------------
+ * One process per GPU; every rank codes a contiguous range of whole chunks with the calls above (no data-path
+ * collective).  Static coders first agree on one CDF: trc_hist_dev on the shard, trc_hist_allreduce_dev (256 x u64
+ * summed in place), trc_cdf_from_hist_dev with the total length -- the gathered container then equals the single-GPU
+ * container of the whole input bit for bit.
+ * trc_exchange_dev gathers `nbatch` consecutive results at once, batch j onto rank j % world (nbatch = 1: the plain
+ * gather onto rank 0; nbatch = world: every directed xGMI link carries one payload, all at the same time).  One
+ * all-gather of the sizes, a host sync to read them, then ONE grouped ncclSend/ncclRecv call.
+ *   nccl_comm   an ncclComm_t (passed as void*: RCCL is resolved at run time, this header needs no RCCL header)
+ *   b[j]        batch j: this rank's result (d_clen[nchunks], d_payload, d_total as trc_encode_dev left them) and, on the
+ *               batch's root, the receive buffers: d_clen_all (all ranks' directory slices in rank order) and
+ *               d_payload_all (all ranks' payloads in rank order = the container's payload area)
+ *   h_sizes     host, uint64[world * nbatch * 2] <- {payload bytes, chunks} of rank r, batch j at [(r*nbatch + j)*2]
+ *   d_meta      device scratch, 16 * nbatch * (world + 1) bytes                                                    */
+#define TRC_EXCHANGE_MAX_BATCH 64
+typedef struct trc_batch {
+    const uint32_t *d_clen; size_t nchunks; const void *d_payload; const uint64_t *d_total;
+    uint32_t *d_clen_all; void *d_payload_all;
+} trc_batch;
+int trc_exchange_dev(void *nccl_comm, int nbatch, const trc_batch *b, uint64_t *h_sizes, void *d_meta, void *stream);
+int trc_hist_allreduce_dev(void *nccl_comm, uint64_t *d_hist, void *stream);
 
 /* Validate a TRC1 container held in buf[0..buflen) BEFORE handing it to a reference-named decoder: those prototypes
  * carry no input length, so a caller reading untrusted files must check that everything the decoder will touch lies

@@ -195,7 +195,7 @@ def test_host_pointer_layer(torch_cuda, codec):
         _, cdf, cdfnum = T.orc_cdfini(d)
         assert trc.host_encode(codec, d, cdf, cdfnum).size == 40
     finally:
-        trc.lib().trc_set_chunk(4096)
+        trc.lib().trc_set_chunk(1024)
 
 
 @pytest.mark.parametrize("codec", trc.AVAILABLE, ids=lambda c: trc.CODEC_NAMES[c])
@@ -538,4 +538,18 @@ def test_every_alias_entry_point_is_called(torch_cuda, codec):
                 assert np.array_equal(clen, exp_clen) and np.array_equal(payload, exp_payload), en
                 assert np.array_equal(trc.host_decode(codec, comp, n, cdf, cdfnum, name=dn), d), dn
     finally:
-        trc.lib().trc_set_chunk(4096)
+        trc.lib().trc_set_chunk(1024)
+
+
+def test_c_gather_driver_single_gpu(torch_cuda):
+    """harness/trcgather.c -- the plain-C one-process-per-GPU driver (histogram all-reduce, per-rank coding, gather over
+    RCCL through trc_exchange_dev) -- with one rank: the size all-gather, the root's own piece and the whole-container
+    decode run; transfers between ranks need a multi-GPU node (the schedule itself is tests/test_shard_gloo.py's)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "harness", "trcgather")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "harness")])
+    for args in (["--size", "30000001", "--chunk", "512"], ["--size", "5000", "--chunk", "4096"]):
+        r = subprocess.run([exe, "--gpus", "1", "--steps", "2"] + args, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "container verified" in r.stdout and "FAILED" not in r.stdout, r.stdout + r.stderr

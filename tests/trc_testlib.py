@@ -350,7 +350,7 @@ BENCH_CONFIGS = [
     dict(name="rccdf-bwt100m-512", codec=RCA, kind="bwt", seed=3, n=100 * 1000 * 1000, chunk=512),             # config 3, `-e46`
     dict(name="anscdf-bwt100m-512", codec=ANSA, kind="bwt", seed=3, n=100 * 1000 * 1000, chunk=512),           # config 3, `-e56`
     dict(name="rcs-text100m-512", codec=RCB, kind="text", seed=7, n=100 * 1000 * 1000, chunk=512),             # config 4, `-e1`
-    dict(name="anscdf4s-text100m-4096", codec=ANS4S, kind="text", seed=7, n=100 * 1000 * 1000, chunk=4096),    # library default chunk
+    dict(name="anscdf4s-text100m-4096", codec=ANS4S, kind="text", seed=7, n=100 * 1000 * 1000, chunk=4096),    # the chunk size of the large-input regime
 ]
 
 

@@ -27,6 +27,15 @@ static int fail(int code, const char *fmt, ...)
     fprintf(stderr, "turborc_hip: ERROR: %s\n", g_err);
     return code;
 }
+// the same for the other translation units of the library (trc_rccl.hip)
+int trc_fail(int code, const char *fmt, ...)
+{
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    fprintf(stderr, "turborc_hip: ERROR: %s\n", g_err);
+    return code;
+}
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(TRC_E_HIP, "%s -> %s", #x, hipGetErrorString(e_)); } while (0)
 
 extern "C" const char *trc_last_error(void) { return g_err; }
