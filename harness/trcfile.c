@@ -7,8 +7,10 @@
  * File = "TRCF" | u8 id | u8 cdfnum-1 | u16 0 | u64 raw length | u64 stored length | [cdf: (cdfnum+1) x u16, static coders]
  *        | stored bytes (the library's TRC1 container, or the raw input when it does not compress: the reference's
  *        "returned length == input length means stored" convention, include/turborc.h:46-59).
- * The reference's own file mode (hd_t / hdb_t, turborc.c:666-733,1044-1167) writes whole-buffer streams that only its
- * serial decoders can read; this tool does not read or write that format. */
+ *   trcfile C <in> <out> [bsize]  compress to the REFERENCE's file format (codec 1 = rcsenc per block; see below)
+ *   trcfile D <in> <out>          decompress a reference-format file of codec 1 / predictor "s" with blocks <= 65536
+ * The reference's own file mode (hd_t / hdb_t, turborc.c:666-733,1044-1167) codes every block as one serial stream; with
+ * blocks that are legal chunk sizes a block IS a chunk, and the two tools read each other's files (C / D below). */
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -112,6 +114,102 @@ int main(int argc, char **argv)
         fclose(f);
         return 0;
     }
-    fprintf(stderr, "usage: trcfile c <id> <in> <out> | trcfile d <in> <out>\n");
+    /* ---- the REFERENCE's own file format (hd_t / hdb_t, turborc.c:666-733; block loop :1044-1167) for file codec 1 with
+     * the "s" predictor (`turborc -1 -b<bsize>B in out`): header u32 = codec << 12 | 0x154 (| bsize << 20 if bsize < 4096)
+     * [u32 bsize] u16 = lev << 10 | prm2 << 6 | prm1 << 2 | (prdid - 1); per block u32 = clen << 2 | big << 1 | last
+     * [u16 clen >> 30] [u32 inlen if last] then clen bytes = rcsenc(block), or the block itself when clen == inlen.
+     * A block of the reference IS a chunk here when bsize is a legal chunk size (multiple of 64 in [256, 65536]): the
+     * per-chunk payload equals rcsenc(block) bit for bit, so files written by `trcfile C` are read by the reference's
+     * `turborc -d`, and `trcfile D` reads what `turborc -1 -b65536B` wrote -- every block of the file coded or decoded by
+     * one launch. */
+    if ((argc == 4 || argc == 5) && !strcmp(argv[1], "C")) {
+        const unsigned bsize = argc == 5 ? (unsigned)strtoul(argv[4], 0, 10) : 65536u;
+        size_t n;
+        if (trc_set_chunk(bsize)) { fprintf(stderr, "block size must be a legal chunk size: %s\n", trc_last_error()); return 2; }
+        unsigned char *in = slurp(argv[2], &n);
+        if (!in) return 2;
+        const size_t cap = trc_container_bound(n, bsize) + 1024;
+        unsigned char *out = malloc(cap);
+        if (!out) { perror("malloc"); return 2; }
+        /* the container is wanted whatever its size: a 70-byte file is one coded block of 60 bytes for the reference, while
+         * the reference-named call would hand back "raw" because 32 + 4 + 60 > 70 */
+        size_t l = n ? trc_encode_host(TRC_RCB, in, n, bsize, out, cap, 0, 0) : 0;
+        if (n && !l) { fprintf(stderr, "encode failed: %s\n", trc_last_error()); return 1; }
+        l = n + 1;                                             /* (never the "whole call raw" case below) */
+        FILE *f = fopen(argv[3], "wb");
+        if (!f) { perror(argv[3]); return 2; }
+        const uint32_t u32 = 1u << 12 | 0x154u | (bsize < 4096u ? bsize << 20 : 0u);
+        const uint16_t u16 = 8u << 10 | 6u << 6 | 5u << 2 | 0u;      /* lev 8, prm2 6, prm1 5 (the reference's defaults), predictor "s" */
+        fwrite(&u32, 4, 1, f);
+        if (bsize >= 4096u) fwrite(&bsize, 4, 1, f);
+        fwrite(&u16, 2, 1, f);
+        const size_t nblk = (n + bsize - 1) / bsize;
+        const unsigned char *dir = out + 32, *pay = out + 32 + 4 * nblk;   /* TRC1 container: hdr | clen[] | payloads */
+        for (size_t b = 0; b < nblk; b++) {
+            const uint32_t inlen = (uint32_t)(n - b * bsize < bsize ? n - b * bsize : bsize);
+            uint32_t clen = inlen;
+            if (l != n) memcpy(&clen, dir + 4 * b, 4);
+            const uint32_t h = clen << 2 | (inlen < bsize);
+            fwrite(&h, 4, 1, f);
+            if (inlen < bsize) fwrite(&inlen, 4, 1, f);
+            if (l != n) { fwrite(pay, 1, clen, f); pay += clen; }
+            else fwrite(in + b * bsize, 1, inlen, f);          /* the whole call came back raw: stored blocks */
+        }
+        fclose(f);
+        printf("%zu bytes -> reference-format file, %zu blocks of %u\n", n, nblk, bsize);
+        return 0;
+    }
+    if (argc == 4 && !strcmp(argv[1], "D")) {
+        size_t fl;
+        unsigned char *fb = slurp(argv[2], &fl);
+        if (!fb) return 2;
+        if (fl < 6) { fprintf(stderr, "not a TurboRC file\n"); return 2; }
+        uint32_t u32; memcpy(&u32, fb, 4);
+        size_t pos = 4;
+        if ((u32 & 0xfffu) != 0x154u || ((u32 >> 12) & 0xffu) != 1u) { fprintf(stderr, "not a TurboRC file of codec 1\n"); return 2; }
+        uint32_t bsize = u32 >> 20;
+        if (!bsize) { if (fl < 10) return 2; memcpy(&bsize, fb + 4, 4); pos = 8; }
+        uint16_t u16; memcpy(&u16, fb + pos, 2); pos += 2;
+        if ((u16 & 3u) != 0u) { fprintf(stderr, "predictor %u: only \"s\" (rcsenc) is on the GPU path\n", (u16 & 3u) + 1u); return 2; }
+        if (trc_set_chunk(bsize)) { fprintf(stderr, "block size %u is not a legal chunk size (write with -b65536B or smaller multiples of 64)\n", bsize); return 2; }
+        /* pass 1: walk the blocks, collect the directory */
+        size_t nblk = 0, n = 0, paybytes = 0, p = pos;
+        int allraw = 1;
+        while (p + 4 <= fl) {
+            uint32_t h; memcpy(&h, fb + p, 4); p += 4;
+            if (h & 2u) { fprintf(stderr, "blocks above 1 GB are not supported\n"); return 2; }
+            uint32_t inlen = bsize;
+            if (h & 1u) { if (p + 4 > fl) { fprintf(stderr, "truncated file\n"); return 2; } memcpy(&inlen, fb + p, 4); p += 4; }
+            const uint32_t clen = h >> 2;
+            if (clen > fl - p || inlen > bsize || clen > inlen) { fprintf(stderr, "corrupt block header\n"); return 2; }
+            if (clen != inlen) allraw = 0;
+            p += clen; paybytes += clen; n += inlen; nblk++;
+            if (inlen < bsize) break;
+        }
+        unsigned char *cont = malloc(32 + 4 * nblk + paybytes + 1024), *out = malloc(n + 1024);
+        if (!cont || !out) { perror("malloc"); return 2; }
+        trc_container_hdr hdr; memset(&hdr, 0, sizeof hdr);
+        hdr.magic = TRC_MAGIC; hdr.codec = TRC_RCB; hdr.version = 1; hdr.chunk = bsize; hdr.nchunks = (uint32_t)nblk; hdr.n = n; hdr.payload = paybytes;
+        memcpy(cont, &hdr, 32);
+        unsigned char *dirp = cont + 32, *payp = cont + 32 + 4 * nblk;
+        p = pos;
+        for (size_t b = 0; b < nblk; b++) {
+            uint32_t h; memcpy(&h, fb + p, 4); p += 4;
+            if (h & 1u) p += 4;
+            const uint32_t clen = h >> 2;
+            memcpy(dirp + 4 * b, &clen, 4);
+            memcpy(payp, fb + p, clen); payp += clen; p += clen;
+        }
+        if (n) {
+            if (allraw) memcpy(out, cont + 32 + 4 * nblk, n);                 /* nothing coded: stored blocks */
+            else if (trc_container_check(cont, 32 + 4 * nblk + paybytes, TRC_RCB, n) || rcsdec(cont, n, out) != n) { fprintf(stderr, "decode failed: %s\n", trc_last_error()); return 1; }
+        }
+        FILE *f = fopen(argv[3], "wb");
+        if (!f) { perror(argv[3]); return 2; }
+        fwrite(out, 1, n, f);
+        fclose(f);
+        return 0;
+    }
+    fprintf(stderr, "usage: trcfile c <id> <in> <out> | trcfile d <in> <out> | trcfile C <in> <out> [bsize] | trcfile D <in> <out>   (C/D: the reference's file format, codec 1)\n");
     return 2;
 }

@@ -169,6 +169,15 @@ typedef struct trc_batch {
 int trc_exchange_dev(void *nccl_comm, int nbatch, const trc_batch *b, uint64_t *h_sizes, void *d_meta, void *stream);
 int trc_hist_allreduce_dev(void *nccl_comm, uint64_t *d_hist, void *stream);
 
+/* Host-pointer encode that ALWAYS returns the TRC1 container, with an explicit chunk size -- for callers that repackage the
+ * per-chunk payloads themselves (harness/trcfile.c writes the reference's file format from it) and therefore must not get
+ * the reference convention "return == n means out is a raw copy" applied to the container as a whole.  out must hold
+ * trc_container_bound(n, chunk) bytes (header + directory + n: every chunk stored raw).  Returns the container size, 0 on
+ * error.  Decode with the reference-named decoder of the codec, or trc_decode_dev. */
+size_t trc_container_bound(size_t n, uint32_t chunk);
+size_t trc_encode_host(int codec, const void *in, size_t n, uint32_t chunk, void *out, size_t outcap,
+                       const uint16_t *cdf, unsigned cdfnum);
+
 /* Validate a TRC1 container held in buf[0..buflen) BEFORE handing it to a reference-named decoder: those prototypes
  * carry no input length, so a caller reading untrusted files must check that everything the decoder will touch lies
  * inside its buffer.  Checks header fields, codec (0 = any), the original length (outlen, (size_t)-1 = any), that the

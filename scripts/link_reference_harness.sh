@@ -36,6 +36,12 @@ gcc ${CF/-mavx -mpopcnt/-march=haswell} -falign-loops=32 -c "$REF/anscdf.c" -o a
 gcc ${CF/-mavx -mpopcnt/-march=haswell} -c "$REF/transpose.c" -o transpose_avx2.o &
 wait
 
+# ---- the unmodified reference tool (all reference objects, no library): the other side of the file-format interop test
+# (tests/test_gpu_parity.py::test_reference_file_format_interop); CPU only
+OBJS0=""
+for f in $LIBSRC anscdfs anscdfx transpose_avx2 turborc; do OBJS0="$OBJS0 $f.o"; done
+gcc $OBJS0 -lrt -lpthread -lm -o turborc_ref
+
 # ---- 2. hot symbols = (globals the four hot-path objects define) x (what the library exports) ----------------
 nm -D --defined-only "$LIBDIR/libturborc_hip.so" | awk '$2 ~ /^[TDB]$/ {print $3}' | sort -u > lib_exports.txt
 : > hot.txt
@@ -93,7 +99,8 @@ fi
 if [ $fail -eq 0 ] && [ "${1:-}" = "--install" ]; then
     mkdir -p "$ROOT/oracle/_ref"
     gcc $OBJS -L"$LIBDIR" -lturborc_hip -Wl,-rpath,'$ORIGIN/../../turbo-range-coder_amd' -lrt -lpthread -lm -o "$ROOT/oracle/_ref/turborc_hip"
-    echo "installed oracle/_ref/turborc_hip"
+    cp turborc_ref "$ROOT/oracle/_ref/turborc_ref"
+    echo "installed oracle/_ref/turborc_hip and oracle/_ref/turborc_ref"
 fi
 [ $fail -eq 0 ] && echo "OK: $OUT/turborc_hip = reference turborc.c + reference non-hot objects + libturborc_hip.so; hot ids bind to the library"
 exit $fail

@@ -49,6 +49,12 @@ def cap(codec, chunk):
     return min(chunk, 8192) if codec == trc.ANSB else chunk
 
 
+def host_chunk(codec, chunk):
+    """chunk size the host-pointer layer really uses for the configured one: the bitwise rANS is capped at one reference
+    block, the order-1 coder never goes below 4096 (its 256 x 17 tables need data to learn from)"""
+    return min(chunk, 8192) if codec == trc.ANSB else max(chunk, 4096) if codec == trc.ANSO1 else chunk
+
+
 def to_dev(torch, a):
     return torch.from_numpy(np.concatenate([a, np.zeros(512, np.uint8)])).to("cuda:0")
 
@@ -181,8 +187,8 @@ def test_host_pointer_layer(torch_cuda, codec):
             comp = trc.host_encode(codec, d, cdf, cdfnum)
             assert comp.size < n
             hdr, clen, payload = trc.parse_container(comp)
-            assert hdr["magic"] == 0x31435254 and hdr["codec"] == codec and hdr["chunk"] == chunk and hdr["n"] == n
-            exp_payload, exp_clen, _ = T.orc_chunked_enc(codec, d, chunk, cdf, cdfnum)
+            assert hdr["magic"] == 0x31435254 and hdr["codec"] == codec and hdr["chunk"] == host_chunk(codec, chunk) and hdr["n"] == n
+            exp_payload, exp_clen, _ = T.orc_chunked_enc(codec, d, host_chunk(codec, chunk), cdf, cdfnum)
             assert np.array_equal(clen, exp_clen) and np.array_equal(payload, exp_payload)
             assert comp.size == 32 + 4 * clen.size + payload.size
             assert np.array_equal(trc.host_decode(codec, comp, n, cdf, cdfnum), d)
@@ -449,8 +455,9 @@ def test_reference_harness_runs_on_the_gpu_library(torch_cuda, tmp_path):
     nch = trc.nchunks(n, chunk)
     for i, codec in ids.items():
         assert i in got, (i, r.stdout[-3000:])
-        _, exp_clen, _ = T.orc_chunked_enc(codec, d, chunk, cdf, m1)       # the harness passes cdfnum = max symbol + 1
-        assert got[i] == 32 + 4 * nch + int(exp_clen.sum()), (i, got[i])
+        hc = host_chunk(codec, chunk)
+        _, exp_clen, _ = T.orc_chunked_enc(codec, d, hc, cdf, m1)          # the harness passes cdfnum = max symbol + 1
+        assert got[i] == 32 + 4 * trc.nchunks(n, hc) + int(exp_clen.sum()), (i, got[i])
     # `turborc -n`: values 0..15 -> the one-table coders and the static rANS id 65 (harness gate m<16)
     r = subprocess.run([exe, "-n", "-I1", "-J1", "-e42,45,46,47,56,65", str(src)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "ERROR" not in r.stdout and "ERROR" not in r.stderr, r.stdout[-3000:] + r.stderr[-2000:]
@@ -531,7 +538,7 @@ def test_every_alias_entry_point_is_called(torch_cuda, codec):
         for kind, n in (("zipf", 50001), ("nibble", 20000)):
             d = fit(codec, gen(kind, n, 57))
             _, cdf, cdfnum = T.orc_cdfini(d)
-            exp_payload, exp_clen, _ = T.orc_chunked_enc(codec, d, chunk, cdf, cdfnum)
+            exp_payload, exp_clen, _ = T.orc_chunked_enc(codec, d, host_chunk(codec, chunk), cdf, cdfnum)
             for en, dn in ALIASES[codec]:
                 comp = trc.host_encode(codec, d, cdf, cdfnum, name=en)
                 _, clen, payload = trc.parse_container(comp)
@@ -553,3 +560,32 @@ def test_c_gather_driver_single_gpu(torch_cuda):
     for args in (["--size", "30000001", "--chunk", "512"], ["--size", "5000", "--chunk", "4096"]):
         r = subprocess.run([exe, "--gpus", "1", "--steps", "2"] + args, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "container verified" in r.stdout and "FAILED" not in r.stdout, r.stdout + r.stderr
+
+
+def test_reference_file_format_interop(torch_cuda, tmp_path):
+    """the reference's own file container (hd_t / hdb_t, turborc.c:666-733, block loop :1044-1167) for file
+    codec 1 (rcsenc per block).  With blocks that are legal chunk sizes a block IS a chunk, so
+      * a file written by `trcfile C` (GPU, one launch for all blocks) is decompressed by the UNMODIFIED reference tool
+        (oracle/_ref/turborc_ref, CPU), and is byte-identical to what the reference writes itself;
+      * a file written by the reference (`turborc -01 -b65536B`) is decompressed by `trcfile D` on the GPU."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = os.path.join(root, "oracle", "_ref", "turborc_ref")
+    exe = os.path.join(root, "harness", "trcfile")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/turborc_ref not built (scripts/link_reference_harness.sh --install, build container only)")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "harness")])
+    for kind, n, bs in (("text", 3000001, 65536), ("zipf", 65536 * 3, 65536), ("uniform", 200000, 65536), ("runs", 100000, 4096), ("text", 70, 65536)):
+        src, ours, theirs, back = tmp_path / "in.bin", tmp_path / "ours.rc", tmp_path / "theirs.rc", tmp_path / "back.bin"
+        gen(kind, n, 77).tofile(src)
+        r = subprocess.run([exe, "C", str(src), str(ours), str(bs)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        r = subprocess.run([ref, "-01", "-b%dB" % bs, str(src), str(theirs)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert open(ours, "rb").read() == open(theirs, "rb").read(), (kind, n, "files differ")
+        r = subprocess.run([ref, "-d", str(ours), str(back)], capture_output=True, text=True, timeout=120)     # reference reads ours
+        assert r.returncode == 0 and open(back, "rb").read() == open(src, "rb").read(), (kind, n, r.stdout + r.stderr)
+        os.remove(back)
+        r = subprocess.run([exe, "D", str(theirs), str(back)], capture_output=True, text=True, timeout=120)   # we read the reference's
+        assert r.returncode == 0 and open(back, "rb").read() == open(src, "rb").read(), (kind, n, r.stdout + r.stderr)

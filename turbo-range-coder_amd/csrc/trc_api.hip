@@ -537,8 +537,10 @@ size_t slice_chunks(uint32_t chunk, size_t nchunks)
 #define HCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fail(TRC_E_HIP, "%s -> %s", #x, hipGetErrorString(e_)); return 0; } } while (0)
 
 // ---- host-pointer encode/decode shared by every reference-signature export --------------------
+// chunk_override / outcap != 0: the trc_encode_host form -- explicit chunk size, and the container is returned whatever its
+// size (no folding into "== inlen means raw"); out holds outcap bytes
 static size_t host_encode(int codec, const unsigned char *in, size_t inlen, unsigned char *out,
-                          const cdf_t *cdf, int cdfnum)
+                          const cdf_t *cdf, int cdfnum, uint32_t chunk_override = 0, size_t outcap = 0)
 {
     if (inlen == 0) return 0;
     HostCtx *cp = nullptr;
@@ -547,9 +549,12 @@ static size_t host_encode(int codec, const unsigned char *in, size_t inlen, unsi
     std::lock_guard<std::mutex> lk(c.mu);
     int dev = 0; HCHK(hipGetDevice(&dev));
     if (ctx_init(c, dev)) return 0;
-    uint32_t chunk = trc_get_chunk();
+    uint32_t chunk = chunk_override ? chunk_override : trc_get_chunk();
+    if (!chunk_ok(chunk)) { fail(TRC_E_ARG, "chunk %u: must be a multiple of 64 in [%u,%u]", chunk, TRC_CHUNK_MIN, TRC_CHUNK_MAX); return 0; }
     if (codec == TRC_ANSB && chunk > TRC_ANSB_CHUNK_MAX) chunk = TRC_ANSB_CHUNK_MAX;
+    if (codec == TRC_ANSO1 && chunk < 4096u && !chunk_override) chunk = 4096u;    // 256 x 17 tables per chunk: nothing to learn from in fewer bytes (and 136 KiB of workspace each)
     const size_t nchunks = (inlen + chunk - 1) / chunk, dir = 4 * nchunks, hdrsz = sizeof(trc_container_hdr);
+    if (outcap && outcap < hdrsz + dir + inlen) { fail(TRC_E_ARG, "encode_host: out holds %zu bytes, the container may need %zu", outcap, hdrsz + dir + inlen); return 0; }
     if (is_static(codec)) {
         if (cdfnum <= 0) cdfnum = host_cdfnum(cdf);
         if (cdfnum <= 0 || cdfnum > 256) { fail(TRC_E_CDF, "bad CDF (need cdf[0]=0 < ... < cdf[cdfnum]=32768)"); return 0; }
@@ -574,7 +579,7 @@ static size_t host_encode(int codec, const unsigned char *in, size_t inlen, unsi
     size_t ppos = 0;                 // payload bytes already placed in `out`
     size_t dpos = 0;                 // device payload offset of the next slice (each slice's payload starts 2-byte aligned: sums of even lengths... kept explicit)
     bool raw = false;
-    const size_t lim = inlen > hdrsz + dir ? inlen - hdrsz - dir : 0;      // payload bytes above which the call returns raw
+    const size_t lim = outcap ? (size_t)-1 : inlen > hdrsz + dir ? inlen - hdrsz - dir : 0;      // payload bytes above which the call returns raw
     auto slice_len = [&](size_t i) { const size_t o = i * slice_bytes; return inlen - o < slice_bytes ? inlen - o : slice_bytes; };
     auto put_in = [&](size_t i) -> bool {                                   // stage + H2D of slice i
         const int k = (int)(i % TRC_NSLOT);
@@ -726,6 +731,19 @@ static size_t host_decode(int codec, const unsigned char *in, size_t outlen, uns
     CopyPool::get(1).wait();
     HCHK(hipStreamSynchronize(c.s_in));
     return outlen;
+}
+
+extern "C" size_t trc_container_bound(size_t n, uint32_t chunk)
+{
+    if (!chunk_ok(chunk)) return 0;
+    return sizeof(trc_container_hdr) + 4 * ((n + chunk - 1) / chunk) + n;
+}
+extern "C" size_t trc_encode_host(int codec, const void *in, size_t n, uint32_t chunk, void *out, size_t outcap,
+                                  const uint16_t *cdf, unsigned cdfnum)
+{
+    if (!codec_ok(codec)) { fail(TRC_E_ARG, "codec %d not available", codec); return 0; }
+    if (!outcap) { fail(TRC_E_ARG, "encode_host: outcap must be given"); return 0; }
+    return host_encode(codec, (const unsigned char *)in, n, (unsigned char *)out, (const cdf_t *)cdf, (int)cdfnum, chunk, outcap);
 }
 
 // ---- container validation for untrusted input (the reference prototypes carry no input length) ------
