@@ -179,6 +179,10 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cold", action="store_true", help="skip the value_cold pass (flags off)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the exchange code even with 1 rank (self-test)")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="N = 1 only: steps kept in flight on as many streams / contexts (default 1: kernels run alone, so their event "
+                         "timings are their own; 2-3 hide the payload gather and the launch gaps behind the next step's coder: "
+                         "+9 %% at chunk 512, +31 %% at chunk 1024, profiles/r02_notes.md -- with longer per-kernel times)")
     args = ap.parse_args()
 
     import hashlib
@@ -249,6 +253,17 @@ def main():
     def decode(result, dir_ready=None):
         dc.decode(d_out, n, dir_ready=DIRR if dir_ready is None else dir_ready)   # the encode just left this directory's group sums in the workspace
 
+    # --inflight N (one GPU): N contexts (workspace, result buffers, output) on N streams, step k on context k mod N
+    inflight = max(1, args.inflight) if not use_dist else 1
+    extra = []
+    if inflight > 1:
+        for _ in range(inflight - 1):
+            c2 = trc.DeviceCoder(codec, n, chunk, dev)
+            if codec in trc.STATIC:
+                c2.cdf.copy_(dc.cdf); c2.cdfnum = dc.cdfnum; c2._tables()
+            extra.append((c2, torch.zeros(n + 512, dtype=torch.uint8, device=dev), torch.cuda.Stream(device=dev)))
+        torch.cuda.synchronize(dev)
+
     own = (dc.clen, dc.payload, dc.total)
     pipe = None
     if use_dist:
@@ -264,8 +279,15 @@ def main():
 
     def step(k, last):
         if pipe is None:
-            encode(own)
-            decode(own)
+            i = k % inflight
+            if i == 0:
+                encode(own)
+                decode(own)
+            else:
+                c2, o2, s2 = extra[i - 1]
+                with torch.cuda.stream(s2):
+                    c2.encode(d_in, n)
+                    c2.decode(o2, n, dir_ready=DIRR)
         else:
             pipe.step(k, last, encode, decode)
 
@@ -304,6 +326,9 @@ def main():
 
     # ---- after the clock: the same steps with nothing carried over between calls (N = 1) ---------------------------
     cold = None
+    if not args.no_verify:
+        for c2, o2, s2 in extra:
+            assert torch.equal(o2[:n], d_in[:n]), "round trip failed (second context)"
     if world == 1 and pipe is None and not args.no_cold:
         trc.timing_enable(True)                                # same launches as the timed region (event pairs on the coder kernels)
         ready, dc.tables_ready = dc.tables_ready, 0            # tables derived from the CDF inside every call
@@ -371,7 +396,7 @@ def main():
             "config": {"workload": "%s: %d B/GPU, %s, chunk %d B, 1 lane = 1 chunk, 64 chunks/wave"
                                    % (wname, n, CODEC_INFO[args.codec][0], chunk),
                        "codec": args.codec, "chunk": chunk, "bytes_per_gpu": n, "compressed_bytes_per_gpu": total_c,
-                       "ratio": round(total_c / n, 5), "exchange": ("none" if world == 1 else "rccl gather of every step's payloads, root rotating over the ranks, %d steps per grouped exchange" % G if rotate else "rccl gather of payloads to rank 0")},
+                       "ratio": round(total_c / n, 5), "steps_in_flight": inflight, "exchange": ("none" if world == 1 else "rccl gather of every step's payloads, root rotating over the ranks, %d steps per grouped exchange" % G if rotate else "rccl gather of payloads to rank 0")},
             "flags": ["TABLES_READY", "DIR_READY"] if (codec in trc.STATIC and DIRR) else (["DIR_READY"] if DIRR else (["TABLES_READY"] if codec in trc.STATIC else [])),
             "value_cold": round(cold[0], 1) if cold else None,
             "ms_per_step_cold": round(cold[1], 4) if cold else None,

@@ -229,6 +229,9 @@ __device__ __forceinline__ u32 ans_get(u32 &st, const u8 *lut, const uint2 *dtab
     si.rpos += rn ? 2u : 0u;
     return x;
 }
+// (Also measured and dropped in round 2: the same step with integer LDS addresses and a carry-driven halfword cursor --
+// 12 instead of 14 VALU per symbol in the listing, 78 against 74-75 us in three A/B pairs.  The decoder does not wait for
+// VALU issue slots; see profiles/r02_notes.md.)
 // (A hand-issued form of this step -- both states' LUT bytes and both candidate ring words requested up front, counted
 // s_waitcnt, SDWA address selects -- was built and measured in round 2: bit-exact, 11 instead of 14 VALU per symbol, and
 // SLOWER, 77-79 us against 74-75 us for 100 MB at chunk 512: the compiler's schedule overlaps consecutive pairs where the
