@@ -46,6 +46,21 @@ struct LaneOut32 {
     }
 };
 
+// The same sink without a window: every word is stored where it belongs as it is released (4-byte scattered stores,
+// merged into lines by L2).  For the bitwise coder, whose time is its instruction count: a lane releases a word every
+// ~6 input bytes, a store per wave and byte is ~2 % of the TA's time, and the window's seven selects per byte are gone.
+struct LaneOutDirect {
+    u8 *dst;             // this lane's region (4-byte aligned)
+    u32 wpos;            // bytes appended
+    __device__ __forceinline__ void start(u8 *d) { dst = d; wpos = 0; }
+    __device__ __forceinline__ void put32_if(bool take, u32 v)
+    {
+        if (take) { *(u32 *)(dst + wpos) = v; wpos += 4u; }
+    }
+    __device__ __forceinline__ void put32(u32 v) { *(u32 *)(dst + wpos) = v; wpos += 4u; }
+    __device__ __forceinline__ void put32_slow(u32 v) { put32(v); }
+};
+
 // UNIT = bytes per consumed unit (4: range coders, 2: rANS)
 template <int UNIT>
 struct LaneIn {

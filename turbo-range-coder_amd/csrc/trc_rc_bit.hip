@@ -19,6 +19,7 @@
 //   decoder  the path depends on the decoded bits; both children of the current node are requested before the bit is
 //            resolved, so the next probability is already on its way while the current step computes.
 #include "trc_rc.h"
+#include "trc_nibmodel.h"
 #include "trc_lane_io.h"
 #include "trc_launch.h"
 
@@ -46,8 +47,14 @@ __global__ __launch_bounds__(64) void trc_rcb_enc_kernel(
     const int lim = trc_rc_limit(len);
 
     QuadIn qin; qin.base = in + (u64)wc.c0 * chunk;
-    LaneOut32 so; so.start(scratch + (u64)c * stride);
-    RcEnc e; e.start();
+    LaneOutDirect so; so.start(scratch + (u64)c * stride);
+    // The coder state of rcbe_ (turborc_.h:417-421) as 32-bit halves: range = rhi:rlo, low = lhi:llo.  The reference finds a
+    // carry by comparing `low` with its value at the last renormalisation; here the carry-out of every `low +=` is ORed
+    // into a lane mask (`cy`, an SGPR pair: SALU work), which is the same event -- between two renormalisations `low`
+    // grows by less than the range it had at the first, so it wraps at most once.
+    u32 rlo = ~0u, rhi = ~0u, llo = 0, lhi = 0;
+    bool cy = false;
+    TrcCarry cw; cw.start();
     bool ovf = alive && lim <= 0;
     // `live`: this lane is still coding.  A lane that is not (dead lane, incompressible chunk, past the end of a short
     // last chunk) keeps running the same arithmetic on its own registers and its own model column -- nothing of it is
@@ -56,54 +63,95 @@ __global__ __launch_bounds__(64) void trc_rcb_enc_kernel(
     bool live = alive && !ovf;
     u32 out_len = alive ? len : 0u;                            // raw until proven otherwise
 
-    // one byte.  The body is a 4-trip loop over bit pairs (renorm + two steps) so that the kernel stays small in the
-    // instruction cache.  A renormalisation SHIFTS the state at once, but the word it produces is only remembered
-    // (`pend`): a lane emits a word every ~6 bytes, and the emit logic (held-back word, carry, 16-byte register window,
-    // its store) is by far the largest block of the loop, so it runs ONCE per byte -- for the one word almost every
-    // lane has at most -- instead of at each of the four renormalisation points.  A second word inside one byte (>= 32
-    // bits of range spent on <= 6 bits) first flushes the remembered one, in order, behind a wave-uniform branch.
+    // One byte = 4 x (renormalisation point + two bits), unrolled.  With one wave per SIMD (32 KiB of model per wave) the
+    // kernel's time is its instruction count -- scalar mask logic and branches included (profiles/r02_notes.md) -- so:
+    //  * everything that does not depend on the coder state is done for the whole byte up front: the eight nodes of the
+    //    byte's path ((0x100|x) >> (8-k)) are all different, so their probabilities are read in one batch, adapted two at
+    //    a time with packed 16-bit arithmetic (the update p -= ((p - (bit<<15)) >> 5) + bit keeps only 16 bits: in 16-bit
+    //    lanes the logical shift of the 32-bit form is an arithmetic one) and written back where they came from;
+    //  * a bit step is ~12 VALU operations: cut = (range >> 15) * p as alignbit / shift / 32x32->64 mad / 24-bit mad; bit
+    //    selects as and-or under sign masks of the bit (no VCC); low += (bit ? 0 : cut) keeping the carry-out;
+    //    range = bit ? cut : range - cut;
+    //  * a renormalisation point only SHIFTS the state and leaves behind (mask, word, carry) in registers of its own; the
+    //    emit logic (held-back word, carry, store) runs ONCE per byte for the one word a lane has at most -- a lane emits a
+    //    word every ~6 bytes.  Lanes with two or more words in one byte (>= 32 bits of range spent on <= 6 bits) are
+    //    found by one test per byte and served point by point behind a wave-uniform branch.
     const u32 mcol = trc_lds_addr(smem) + lane * 2u;           // this lane's model column as an LDS byte address
     auto put_byte = [&](u32 x) {
-        const u32 path = (0x100u | x) << 7;                    // node k of the byte's path, times the row stride: (path >> (8-k)) & ~127
-        u32 pp0, pp1, pp2, pp3;                                // the eight probabilities, two per register
-        {
-            const u32 a0 = trc_ldsr16(mcol + 128u), a1 = trc_ldsr16(((path >> 7) & ~127u) + mcol);
-            const u32 a2 = trc_ldsr16(((path >> 6) & ~127u) + mcol), a3 = trc_ldsr16(((path >> 5) & ~127u) + mcol);
-            const u32 a4 = trc_ldsr16(((path >> 4) & ~127u) + mcol), a5 = trc_ldsr16(((path >> 3) & ~127u) + mcol);
-            const u32 a6 = trc_ldsr16(((path >> 2) & ~127u) + mcol), a7 = trc_ldsr16(((path >> 1) & ~127u) + mcol);
-            pp0 = a0 | a1 << 16; pp1 = a2 | a3 << 16; pp2 = a4 | a5 << 16; pp3 = a6 | a7 << 16;
+        const u32 t = 0x100u | x;
+        u32 ad[8];
+        ad[0] = mcol + 128u;
+#pragma unroll
+        for (int k = 1; k < 8; k++) ad[k] = ((t >> (8 - k)) << 7) + mcol;
+        u32 pr[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) pr[k] = trc_ldsr16(ad[k]);
+        const u32 nx = ~x;
+        u32 P[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            P[j] = pr[2 * j] | pr[2 * j + 1] << 16;
+            const u32 B = __builtin_amdgcn_ubfe(x, 7 - 2 * j, 1) | __builtin_amdgcn_ubfe(x, 6 - 2 * j, 1) << 16;    // the pair's two bits, one per half
+            const trc_s2 pv = trc_as_s2(P[j]), bv = trc_as_s2(B);
+            const trc_s2 np = pv - (((pv - trc_as_s2(B << 15)) >> (trc_s2)5) + bv);
+            const u32 NP = trc_as_u32(np);
+            trc_ldsw16(ad[2 * j], NP); trc_ldsw16(ad[2 * j + 1], NP >> 16);
         }
-        u32 xs = x << 24, node = 1;
-        bool pend = false, pcy = false;
-        u32 pw = 0;
-#pragma nounroll
-        for (u32 j = 0; j < 4; j++) {
+        bool rnj[4], cyj[4];
+        u32 pwj[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
             {                                                  // renorm before bits 7,5,3,1 only (_RCENORM2)
-                const bool rn = e.range < TRC_TOP32;
-                if (__ballot(rn && pend)) {                    // second word within this byte (rare): the first one goes out now
-                    e.cw.emit_if(so, rn && pend && live, pcy, pw);
-                    pend = pend && !rn;
-                }
-                pcy = rn ? e.mark > e.low : pcy;
-                pw = rn ? (u32)(e.low >> 32) : pw;
-                pend = pend || rn;
-                e.low = rn ? e.low << 32 : e.low;
-                e.range = rn ? e.range << 32 : e.range;
-                e.mark = rn ? e.low : e.mark;
+                const bool rn = rhi == 0u;
+                rnj[j] = rn; cyj[j] = rn && cy; pwj[j] = lhi;
+                cy = cy && !rn;
+                lhi = rn ? llo : lhi; llo = rn ? 0u : llo;
+                rhi = rn ? rlo : rhi; rlo = rn ? 0u : rlo;
             }
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                const u32 p = h ? pp0 >> 16 : pp0 & 0xffffu;
-                const u32 bit = xs >> 31; xs <<= 1;
-                const u64 cut = (e.range >> TRC_PROB_BITS) * p;                  // rcbe_
-                e.low += bit ? 0 : cut;
-                e.range = bit ? cut : e.range - cut;
-                trc_ldsw16((node << 7) + mcol, rcb_adapt(p, bit));
-                node = node * 2 + bit;
+                const int k = 2 * j + h;
+                const u32 prob = h ? P[j] >> 16 : P[j] & 0xffffu;
+                const u32 m = (u32)__builtin_amdgcn_sbfe((int)x, 7 - k, 1);        // bit 1: all ones
+                const u32 nm = (u32)__builtin_amdgcn_sbfe((int)nx, 7 - k, 1);      // bit 0: all ones
+                const u32 slo = __builtin_amdgcn_alignbit(rhi, rlo, TRC_PROB_BITS), shi = rhi >> TRC_PROB_BITS;
+                const u64 c64 = (u64)slo * prob;
+                const u32 clo = (u32)c64, chi = __umul24(shi, prob) + (u32)(c64 >> 32);    // shi < 2^17, prob < 2^16
+                u32 k1, k2;
+                llo = __builtin_addc(llo, clo & nm, 0u, &k1);
+                lhi = __builtin_addc(lhi, chi & nm, k1, &k2);
+                cy = cy || (k2 != 0u);
+                u32 b1, b2;
+                const u32 tlo = __builtin_subc(rlo, clo, 0u, &b1), thi = __builtin_subc(rhi, chi, b1, &b2);
+                rlo = (clo & m) | (tlo & nm); rhi = (chi & m) | (thi & nm);
             }
-            pp0 = pp1; pp1 = pp2; pp2 = pp3;
         }
-        e.cw.emit_if(so, pend && live, pcy, pw);
+        const bool two = (rnj[0] && (rnj[1] || rnj[2] || rnj[3])) || (rnj[1] && (rnj[2] || rnj[3])) || (rnj[2] && rnj[3]);
+        if (__ballot(two && live)) {                           // rare: some lane has several words in this byte
+#pragma unroll
+            for (int j = 0; j < 4; j++) cw.emit_if(so, rnj[j] && live, cyj[j], pwj[j]);
+        } else {
+            const bool pend = rnj[0] || rnj[1] || rnj[2] || rnj[3];
+            const bool pcy = cyj[0] || cyj[1] || cyj[2] || cyj[3];
+            const u32 pw = rnj[3] ? pwj[3] : rnj[2] ? pwj[2] : rnj[1] ? pwj[1] : pwj[0];
+            cw.emit_if(so, pend && live, pcy, pw);
+        }
+    };
+    // rceflush (turborc_.h:118-128) on the same state, then everything still held back
+    auto finish = [&]() {
+        u64 low = ((u64)lhi << 32) | llo;
+        u64 rg = ((u64)rhi << 32) | rlo;
+        bool c0 = cy;
+        if (rg < TRC_TOP32) { cw.emit(so, c0, (u32)(low >> 32)); low <<= 32; rg <<= 32; c0 = false; }
+        if (rg > ((u64)1 << 33)) {
+            const u64 nl = low + TRC_TOP32;
+            cw.emit(so, c0 || nl < low, (u32)(nl >> 32));
+        } else {
+            const u64 nl = low + 1;
+            cw.emit(so, c0 || nl < low, (u32)(nl >> 32));
+            cw.emit(so, false, (u32)nl);
+        }
+        cw.release(so);
     };
 
     const u32 S = chunk / TRC_SEG;
@@ -116,27 +164,26 @@ __global__ __launch_bounds__(64) void trc_rcb_enc_kernel(
         for (u32 k = 0; k < 4; k++) {
             uint4 v = pc0; pc0 = pc1; pc1 = pc2; pc2 = pc3;
             if (!__ballot(live)) continue;
+            const u32 p0 = s * TRC_SEG + k * 16u;
+            const bool ends = __ballot(live && len - p0 < 16u) != 0;     // a short last chunk ends inside this piece (once per grid)
 #pragma nounroll
             for (u32 d = 0; d < 4; d++) {
                 const u32 w = v.x; v.x = v.y; v.y = v.z; v.z = v.w;
-                const u32 q0 = s * TRC_SEG + k * 16u + d * 4u;
+                const u32 q0 = p0 + d * 4u;
 #pragma nounroll
                 for (u32 i = 0; i < 4; i++) {
-                    if (__ballot(live && q0 + i == len)) {     // a short last chunk ends here: decide and flush it now (once per grid)
-                        if (live && q0 + i == len) {
-                            if ((int)(4u * e.cw.nwords) < lim) { e.finish(so); out_len = so.wpos; so.finish(true); }
-                            live = false;                      // (else: incompressible, out_len stays the raw length)
-                        }
+                    if (ends && live && q0 + i == len) {       // decide and flush it at its byte boundary
+                        if ((int)(4u * cw.nwords) < lim) { finish(); out_len = so.wpos; }
+                        live = false;                          // (else: incompressible, out_len stays the raw length)
                     }
                     put_byte((w >> (8 * i)) & 255u);
                 }
-                ovf = ovf || (live && (int)(4u * e.cw.nwords) >= lim);           // OVERFLOW per byte, monotone
+                ovf = ovf || (live && (int)(4u * cw.nwords) >= lim);           // OVERFLOW per dword, monotone
                 live = live && !ovf;
             }
         }
     }
-    if (live) { e.finish(so); out_len = so.wpos; }
-    so.finish(live);
+    if (live) { finish(); out_len = so.wpos; }
     if (alive) clen[c] = out_len;
     const u32 gs = trc_wave_sum(out_len);
     if (lane == 0) gsum[wc.c0 >> 6] = gs;
