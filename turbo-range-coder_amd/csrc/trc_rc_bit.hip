@@ -23,7 +23,13 @@
 #include "trc_lane_io.h"
 #include "trc_launch.h"
 
+#ifdef RCB_ABL_HALFMODEL                                   // timing experiment (profiles/r02_notes.md): nodes mod 128, twice the waves; output wrong
+#define RCB_MODEL_BYTES (128u * 64u * 2u)
+#define RCB_AMASK 0x3fffu
+#else
 #define RCB_MODEL_BYTES (256u * 64u * 2u)                  // [ctx][lane] u16
+#define RCB_AMASK 0x7fffu
+#endif
 #define RCB_WAVE_LDS    RCB_MODEL_BYTES
 
 __device__ __forceinline__ u32 rcb_adapt(u32 p, u32 bit) { return (p - (((p - (bit << TRC_PROB_BITS)) >> 5) + bit)) & 0xffffu; }
@@ -35,7 +41,7 @@ __global__ __launch_bounds__(64) void trc_rcb_enc_kernel(
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const u32 lane = threadIdx.x;
     u16 *mb = (u16 *)smem + lane;                              // mb[ctx * 64]
-    for (u32 i = 0; i < 256; i++) mb[i * 64] = (u16)(TRC_PROB_ONE >> 1);
+    for (u32 i = 0; i < RCB_MODEL_BYTES / 128u; i++) mb[i * 64] = (u16)(TRC_PROB_ONE >> 1);
 
     WaveChunks wc;
     wc.c0 = blockIdx.x * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(64) void trc_rcb_enc_kernel(
         u32 ad[8];
         ad[0] = mcol + 128u;
 #pragma unroll
-        for (int k = 1; k < 8; k++) ad[k] = ((t >> (8 - k)) << 7) + mcol;
+        for (int k = 1; k < 8; k++) ad[k] = (((t >> (8 - k)) << 7) & RCB_AMASK) + mcol;
         u32 pr[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) pr[k] = trc_ldsr16(ad[k]);
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(64) void trc_rcb_dec_kernel(
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const u32 lane = threadIdx.x;
     u16 *mb = (u16 *)smem + lane;
-    for (u32 i = 0; i < 256; i++) mb[i * 64] = (u16)(TRC_PROB_ONE >> 1);
+    for (u32 i = 0; i < RCB_MODEL_BYTES / 128u; i++) mb[i * 64] = (u16)(TRC_PROB_ONE >> 1);
 
     WaveChunks wc;
     wc.c0 = blockIdx.x * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
@@ -231,13 +237,13 @@ __global__ __launch_bounds__(64) void trc_rcb_dec_kernel(
             for (int h = 0; h < 2; h++) {
                 // both children are requested before this bit is known (below the last level the index wraps into the
                 // model and the values are unused)
-                const u32 lc = ((ctx << 8) & 0x7f00u) + mcol;  // row 2*ctx (mod 256), 128 bytes per row
+                const u32 lc = ((ctx << 8) & (RCB_AMASK & 0x7f00u)) + mcol;  // row 2*ctx (mod 256), 128 bytes per row
                 const u32 pl = trc_ldsr16(lc), pr = trc_ldsr16(lc + 128u);
                 const u64 cut = (dc.range >> TRC_PROB_BITS) * p;
                 const bool one = dc.code < cut;                // rcbd_
                 dc.range = one ? cut : dc.range - cut;        // (lanes that are not decoding run along on their own registers
                 dc.code = one ? dc.code : dc.code - cut;       //  and model column: only `act` lanes consume stream words)
-                trc_ldsw16((ctx << 7) + mcol, rcb_adapt(p, one ? 1u : 0u));
+                trc_ldsw16(((ctx << 7) & RCB_AMASK) + mcol, rcb_adapt(p, one ? 1u : 0u));
                 ctx = ctx * 2 + (one ? 1u : 0u);
                 p = one ? pr : pl;
             }
