@@ -86,11 +86,15 @@ struct NibModel {
     __device__ __forceinline__ void adapt(NibTable &T, u32 x) const
     {
         const NibTable K = load(kb + x * 32u);
+        // three passes over the eight dwords, not eight three-step chains: on gfx950 a packed shift that reads the result of
+        // the packed subtract right before it costs a wait state (the compiler fills it with an s_nop)
+        trc_s2 d[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const trc_s2 v = trc_as_s2(T.d[k]);
-            T.d[k] = trc_as_u32(v + ((trc_as_s2(K.d[k]) - v) >> (trc_s2)7));
-        }
+        for (int k = 0; k < 8; k++) d[k] = trc_as_s2(K.d[k]) - trc_as_s2(T.d[k]);
+#pragma unroll
+        for (int k = 0; k < 8; k++) d[k] = d[k] >> (trc_s2)7;
+#pragma unroll
+        for (int k = 0; k < 8; k++) T.d[k] = trc_as_u32(trc_as_s2(T.d[k]) + d[k]);
     }
     // encoder side: {c0 << 15 | freq} of symbol x under table tb, then the table adapts
     __device__ __forceinline__ u32 record(u8 *tb, u32 x) const
@@ -108,20 +112,27 @@ struct NibModel {
     }
 };
 
-// decoder side: the symbol x whose interval holds q (t[x] <= q < t[x+1], 0 <= q < 32768) and its bounds, by binary
-// search over the register copy (entry 16 = 32768 appended)
-__device__ __forceinline__ u32 trc_nib_find(const NibTable &T, u32 q, u32 &c0, u32 &c1)
+// decoder side: the symbol x with t[x] <= q < t[x+1] and its bounds, by binary search over the register copy (entry 16
+// = 32768 appended).  `ge(e)` answers "q >= e" for a 16-bit table entry e: the rANS decoders compare the slot itself, the
+// range decoders compare code >= (range >> 15) * e -- the same predicate as floor(code / (range >> 15)) >= e without
+// the division (trc_rc.h).
+template <class GE>
+__device__ __forceinline__ u32 trc_nib_search(const NibTable &T, GE ge, u32 &c0, u32 &c1)
 {
-    const bool b3 = q >= (T.d[4] & 0xffffu);
+    const bool b3 = ge(T.d[4] & 0xffffu);
     const u32 e0 = b3 ? T.d[4] : T.d[0], e1 = b3 ? T.d[5] : T.d[1], e2 = b3 ? T.d[6] : T.d[2],
               e3 = b3 ? T.d[7] : T.d[3], e4 = b3 ? TRC_PROB_ONE : T.d[4];
-    const bool b2 = q >= (e2 & 0xffffu);
+    const bool b2 = ge(e2 & 0xffffu);
     const u32 f0 = b2 ? e2 : e0, f1 = b2 ? e3 : e1, f2 = b2 ? e4 : e2;
-    const bool b1 = q >= (f1 & 0xffffu);
+    const bool b1 = ge(f1 & 0xffffu);
     const u32 g0 = b1 ? f1 : f0, g1 = b1 ? f2 : f1;
     const u32 gh = g0 >> 16;
-    const bool b0 = q >= gh;
+    const bool b0 = ge(gh);
     c0 = b0 ? gh : (g0 & 0xffffu);
     c1 = b0 ? (g1 & 0xffffu) : gh;
     return (b3 ? 8u : 0u) + (b2 ? 4u : 0u) + (b1 ? 2u : 0u) + (b0 ? 1u : 0u);
+}
+__device__ __forceinline__ u32 trc_nib_find(const NibTable &T, u32 q, u32 &c0, u32 &c1)
+{
+    return trc_nib_search(T, [q](u32 e) { return q >= e; }, c0, c1);
 }

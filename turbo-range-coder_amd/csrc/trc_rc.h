@@ -102,13 +102,22 @@ struct RcDec {
         t = dn ? t - 1u : up ? t + 1u : t;
         return t > TRC_PROB_ONE - 1 ? TRC_PROB_ONE - 1 : t;              // corrupt input: stay inside the table
     }
+    // The adaptive decoders do not need the quotient itself, only the table entry it falls behind: with r = range >> 15,
+    // floor(code / r) >= e  <=>  code >= r * e, so the reference's search over code / r (cdflget16, turborc_.h:172-190) is a
+    // binary search with four 49 x 16-bit products instead of a division and four compares (r * e < 2^64: e <= 2^15).
+    // A corrupt stream (code / r >= 2^15) ends at the last symbol, as the reference's clamped quotient does.
+    struct GeScaled {
+        u64 r, code;
+        __device__ __forceinline__ bool operator()(u32 e) const { return code >= r * e; }
+    };
+    __device__ __forceinline__ GeScaled scaled() const { return GeScaled{ range >> TRC_PROB_BITS, code }; }
     // _rccdfupdate + renorm where act, nothing where !act (range is still the unshifted one)
     template <class SI>
     __device__ __forceinline__ void consume_if(SI &si, bool act, u32 c0, u32 c1)
     {
         const u64 r = range >> TRC_PROB_BITS;
         const u64 rp = r * c0;
-        const u64 range2 = r * c1 - rp, code2 = code - rp;
+        const u64 range2 = r * (u32)(c1 - c0), code2 = code - rp;           // (one 49 x 16-bit product: r*c1 - r*c0 with the difference taken first)
         const bool rn = act && range2 < TRC_TOP32;
         const u32 w = si.peek32();
         range = act ? (rn ? range2 << 32 : range2) : range;

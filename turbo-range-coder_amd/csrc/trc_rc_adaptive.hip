@@ -175,18 +175,16 @@ __global__ __launch_bounds__(64) void trc_rca_dec_kernel(
     // trips out of every byte (one wave per SIMD: nothing else hides them).
     NibTable T0 = m.load(m.table(0));
     auto get0 = [&](RcDec &dq, LaneIn<4> &sq, bool act) -> u32 {
-        const u32 q = dq.quotient15();
         u32 c0, c1;
-        const u32 x = trc_nib_find(T0, q, c0, c1);
+        const u32 x = trc_nib_search(T0, dq.scaled(), c0, c1);
         dq.consume_if(sq, act, c0, c1);
         m.adapt(T0, x);
         return x;
     };
     auto get = [&](RcDec &dq, LaneIn<4> &sq, u8 *tb, bool act) -> u32 {
-        const u32 q = dq.quotient15();
         NibTable T = m.load(tb);
         u32 c0, c1;
-        const u32 x = trc_nib_find(T, q, c0, c1);              // == first i with t[i+1]*r > code, else 15 (cdflget16)
+        const u32 x = trc_nib_search(T, dq.scaled(), c0, c1);  // == first i with t[i+1]*r > code, else 15 (cdflget16)
         dq.consume_if(sq, act, c0, c1);
         m.adapt(T, x); m.store(tb, T);
         return x;
@@ -221,9 +219,8 @@ __global__ __launch_bounds__(64) void trc_rca_dec_kernel(
 #pragma unroll
                         for (int pr = 0; pr < 2; pr++) {       // both symbols searched in the table before the pair
                             const bool act0 = coded && q0 + 2u * (u32)pr < len, act1 = coded && q0 + 2u * (u32)pr + 1u < len;
-                            const u32 t0 = d0.quotient15(), t1 = d1.quotient15();
                             u32 a0, a1, b0, b1;
-                            const u32 x0 = trc_nib_find(T0, t0, a0, a1), x1 = trc_nib_find(T0, t1, b0, b1);
+                            const u32 x0 = trc_nib_search(T0, d0.scaled(), a0, a1), x1 = trc_nib_search(T0, d1.scaled(), b0, b1);
                             d0.consume_if(s0, act0, a0, a1);
                             d1.consume_if(s1, act1, b0, b1);
                             m.adapt(T0, x0); m.adapt(T0, x1);

@@ -139,10 +139,9 @@ __global__ __launch_bounds__(64) void trc_vlc_dec_kernel(
     u32 bpos = 0, prev = 0;
 
     auto get = [&](u8 *tb, bool act) -> u32 {
-        const u32 q = dc.quotient15();
         NibTable Tb = m.load(tb);
         u32 c0, c1;
-        const u32 x = trc_nib_find(Tb, q, c0, c1);
+        const u32 x = trc_nib_search(Tb, dc.scaled(), c0, c1);
         dc.consume_if(si, act, c0, c1);
         m.adapt(Tb, x); m.store(tb, Tb);
         return x;

@@ -144,9 +144,8 @@ __global__ __launch_bounds__(64) void trc_rcv_dec_kernel(
     NibTable T0 = m.load(m.table(0)), T1 = T0, T2 = T0;        // all tables start alike
     // one symbol where `on`: search the register table, consume, adapt (nothing moves where !on)
     auto get = [&](RcDec &dq, LaneIn<4> &sq, NibTable &T, bool on) -> u32 {
-        const u32 q = dq.quotient15();
         u32 c0, c1;
-        const u32 x = trc_nib_find(T, q, c0, c1);
+        const u32 x = trc_nib_search(T, dq.scaled(), c0, c1);
         dq.consume_if(sq, on, c0, c1);
         if (on) m.adapt(T, x);
         return x;
