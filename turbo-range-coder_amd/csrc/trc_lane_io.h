@@ -59,6 +59,7 @@ struct LaneOutDirect {
     }
     __device__ __forceinline__ void put32(u32 v) { *(u32 *)(dst + wpos) = v; wpos += 4u; }
     __device__ __forceinline__ void put32_slow(u32 v) { put32(v); }
+    __device__ __forceinline__ void finish(bool) {}
 };
 
 // UNIT = bytes per consumed unit (4: range coders, 2: rANS)

@@ -75,6 +75,53 @@ struct RcEnc {
     }
 };
 
+// The same encoder for the model-bound kernels (one wave per SIMD: their time is their instruction count).  Differences:
+//  * a carry is the carry-out of `low +=` ORed into a flag, not a compare against the value of `low` at the last
+//    renormalisation (same event: between two renormalisations `low` grows by less than the range it had at the first);
+//  * a renormalisation only SHIFTS the state and remembers (word, carry); the emit logic runs in `flush`, which the caller
+//    invokes after every SECOND symbol: two consecutive symbols cannot both renormalise (after one, range >= 2^17 << 32 =
+//    2^49, and one more symbol leaves at least (2^49 >> 15) * 1 = 2^34 >= 2^32), so one remembered word is enough.
+struct RcEncD {
+    static constexpr u32 WBYTES = 4;
+    u64 range, low;
+    bool cy, pend, pcy;
+    u32 pw;
+    TrcCarry cw;
+    __device__ __forceinline__ void start() { range = ~(u64)0; low = 0; cy = pend = pcy = false; pw = 0; cw.start(); }
+    __device__ __forceinline__ void sym_rec(bool act, u32 c0, u32 f)    // _rccdfenc_ + renorm where act, nothing where !act
+    {
+        const u64 r = range >> TRC_PROB_BITS;
+        const u64 low2 = low + r * (act ? c0 : 0u);
+        const bool cyn = cy || low2 < low;
+        const u64 range2 = r * f;
+        const bool rn = act && range2 < TRC_TOP32;
+        pw = rn ? (u32)(low2 >> 32) : pw;
+        pcy = rn ? cyn : pcy;
+        pend = pend || rn;
+        cy = cyn && !rn;
+        low = rn ? low2 << 32 : low2;
+        range = act ? (rn ? range2 << 32 : range2) : range;
+    }
+    template <class SO>
+    __device__ __forceinline__ void flush(SO &so) { cw.emit_if(so, pend, pcy, pw); pend = false; }
+    template <class SO>
+    __device__ __forceinline__ void finish(SO &so)                      // rceflush, then release everything still held back
+    {
+        flush(so);
+        bool c0 = cy;
+        if (range < TRC_TOP32) { cw.emit(so, c0, (u32)(low >> 32)); low <<= 32; range <<= 32; c0 = false; }
+        if (range > ((u64)1 << 33)) {
+            const u64 nl = low + TRC_TOP32;
+            cw.emit(so, c0 || nl < low, (u32)(nl >> 32));
+        } else {
+            const u64 nl = low + 1;
+            cw.emit(so, c0 || nl < low, (u32)(nl >> 32));
+            cw.emit(so, false, (u32)nl);
+        }
+        cw.release(so);
+    }
+};
+
 struct RcDec {
     u64 range, code;
     __device__ __forceinline__ void start(u32 w0, u32 w1) { range = ~(u64)0; code = ((u64)w0 << 32) | w1; }

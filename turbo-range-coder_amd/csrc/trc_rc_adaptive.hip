@@ -49,10 +49,10 @@ __global__ __launch_bounds__(64) void trc_rca_enc_kernel(
     const u32 off1 = 4u + len / 2u;                            // stream-1 base inside `out` (rccdf.c:215,279)
 
     QuadIn qin; qin.base = in + (u64)wc.c0 * chunk;
-    LaneOut32 o0, o1;
+    LaneOutDirect o0, o1;
     o0.start(scratch + (u64)c * stride + (NS == 2 ? 4u : 0u));
     o1.start(NS == 2 ? scratch2 + (u64)c * stride2 : scratch);
-    RcEnc e0, e1; e0.start(); e1.start();
+    RcEncD e0, e1; e0.start(); e1.start();
     bool ovf = alive && NS == 1 && lim <= 0;
 
     const u32 S = chunk / TRC_SEG;
@@ -94,22 +94,27 @@ __global__ __launch_bounds__(64) void trc_rca_enc_kernel(
                         rc[2 * pr + 1] = (b0 << TRC_PROB_BITS) | (b1 - b0);
                     }
                 }
-                // ---- range coder: predicated steps
+                // ---- range coder: predicated steps; an encoder's remembered word goes out after every second symbol
                 if (!NIB) {
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const bool act = run && q0 + (u32)i < len;
-                        e0.sym_if(o0, act, rc[2 * i] >> TRC_PROB_BITS, rc[2 * i] & 0x7fffu);
-                        if (NS == 1) e0.sym_if(o0, act, rc[2 * i + 1] >> TRC_PROB_BITS, rc[2 * i + 1] & 0x7fffu);
-                        else         e1.sym_if(o1, act, rc[2 * i + 1] >> TRC_PROB_BITS, rc[2 * i + 1] & 0x7fffu);
+                        e0.sym_rec(act, rc[2 * i] >> TRC_PROB_BITS, rc[2 * i] & 0x7fffu);
+                        if (NS == 1) { e0.sym_rec(act, rc[2 * i + 1] >> TRC_PROB_BITS, rc[2 * i + 1] & 0x7fffu); e0.flush(o0); }
+                        else {
+                            e1.sym_rec(act, rc[2 * i + 1] >> TRC_PROB_BITS, rc[2 * i + 1] & 0x7fffu);
+                            if (i & 1) { e0.flush(o0); e1.flush(o1); }
+                        }
                     }
                 } else {
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const bool act = run && q0 + (u32)i < len;
-                        if (NS == 1 || !(i & 1)) e0.sym_if(o0, act, rc[i] >> TRC_PROB_BITS, rc[i] & 0x7fffu);
-                        else                     e1.sym_if(o1, act, rc[i] >> TRC_PROB_BITS, rc[i] & 0x7fffu);
+                        if (NS == 1 || !(i & 1)) e0.sym_rec(act, rc[i] >> TRC_PROB_BITS, rc[i] & 0x7fffu);
+                        else                     e1.sym_rec(act, rc[i] >> TRC_PROB_BITS, rc[i] & 0x7fffu);
+                        if (NS == 1 && (i & 1)) e0.flush(o0);
                     }
+                    if (NS == 2) { e0.flush(o0); e1.flush(o1); }
                 }
                 // ---- incompressibility tests (all monotone in the word counts)
                 if (NS == 1) ovf = ovf || (run && q0 < len && (int)(4u * e0.cw.nwords) >= lim);
