@@ -44,9 +44,9 @@ __global__ __launch_bounds__(64) void trc_vlc_enc_kernel(
     const int lim = trc_rc_limit(len);
 
     QuadIn qin; qin.base = in + (u64)wc.c0 * chunk;
-    LaneOut32 so; so.start(scratch + (u64)c * stride + 4u);
+    LaneOutDirect so; so.start(scratch + (u64)c * stride + 4u);
     LaneBitsDown bo; bo.start(scratch + (u64)(c + 1u) * stride);
-    RcEnc e; e.start();
+    RcEncD e; e.start();
     u32 prev = 0;
     bool ovf = false;
 
@@ -64,8 +64,9 @@ __global__ __launch_bounds__(64) void trc_vlc_enc_kernel(
         const u32 r0 = m.record(m.table(0), y0 & 15u);
         u32 r1 = 1u;
         if (act && two) r1 = m.record(m.table(1), y1);          // table 1 adapts only where its symbol is coded
-        e.sym_if(so, act, r0 >> TRC_PROB_BITS, r0 & 0x7fffu);
-        e.sym_if(so, act && two, r1 >> TRC_PROB_BITS, r1 & 0x7fffu);
+        e.sym_rec(act, r0 >> TRC_PROB_BITS, r0 & 0x7fffu);
+        e.sym_rec(act && two, r1 >> TRC_PROB_BITS, r1 & 0x7fffu);
+        e.flush(so);                                            // at most one word per two steps (trc_rc.h RcEncD)
     };
 
     const u32 S = chunk / TRC_SEG;

@@ -41,10 +41,10 @@ __global__ __launch_bounds__(64) void trc_rcv_enc_kernel(
     const u32 off1 = 4u + (u32)(((u64)len * 37u) / 64u);       // stream-1 base inside `out` (rccdf.c:374)
 
     QuadIn qin; qin.base = in + (u64)wc.c0 * chunk;
-    LaneOut32 o0, o1;
+    LaneOutDirect o0, o1;
     o0.start(scratch + (u64)c * stride + (NS == 2 ? 4u : 0u));
     o1.start(NS == 2 ? scratch2 + (u64)c * stride2 : scratch);
-    RcEnc e0, e1; e0.start(); e1.start();
+    RcEncD e0, e1; e0.start(); e1.start();
     bool ovf = alive && NS == 1 && lim <= 0;
 
     const u32 S = chunk / TRC_SEG;
@@ -78,10 +78,16 @@ __global__ __launch_bounds__(64) void trc_rcv_enc_kernel(
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const bool act = run && q0 + (u32)i < len;
-                    e0.sym_if(o0, act, ra[i] >> TRC_PROB_BITS, ra[i] & 0x7fffu);
-                    if (NS == 1) e0.sym_if(o0, act && rb[i] != 0u, rb[i] >> TRC_PROB_BITS, rb[i] & 0x7fffu);
-                    else         e1.sym_if(o1, act && rb[i] != 0u, rb[i] >> TRC_PROB_BITS, rb[i] & 0x7fffu);
-                    e0.sym_if(o0, act && rc[i] != 0u, rc[i] >> TRC_PROB_BITS, rc[i] & 0x7fffu);
+                    // (an encoder's remembered word goes out after every second step: trc_rc.h RcEncD)
+                    e0.sym_rec(act, ra[i] >> TRC_PROB_BITS, ra[i] & 0x7fffu);
+                    if (NS == 1) {
+                        if (i & 1) e0.flush(o0);                               // steps 3i, 3i+1, 3i+2 of the period: flush after the odd ones
+                        e0.sym_rec(act && rb[i] != 0u, rb[i] >> TRC_PROB_BITS, rb[i] & 0x7fffu);
+                        if (!(i & 1)) e0.flush(o0);
+                    } else e1.sym_rec(act && rb[i] != 0u, rb[i] >> TRC_PROB_BITS, rb[i] & 0x7fffu);
+                    e0.sym_rec(act && rc[i] != 0u, rc[i] >> TRC_PROB_BITS, rc[i] & 0x7fffu);
+                    if (NS == 1) { if (i & 1) e0.flush(o0); }
+                    else { e0.flush(o0); if (i & 1) e1.flush(o1); }
                 }
                 // ---- incompressibility tests (monotone in the word counts)
                 if (NS == 1) ovf = ovf || (run && q0 < len && (int)(4u * e0.cw.nwords) >= lim);
