@@ -105,6 +105,8 @@ struct RcEncD {
     template <class SO>
     __device__ __forceinline__ void flush(SO &so) { cw.emit_if(so, pend, pcy, pw); pend = false; }
     template <class SO>
+    __device__ __forceinline__ void sym(SO &so, u32 c0, u32 f) { sym_rec(true, c0, f); flush(so); }   // one symbol, emitted at once
+    template <class SO>
     __device__ __forceinline__ void finish(SO &so)                      // rceflush, then release everything still held back
     {
         flush(so);

@@ -18,7 +18,7 @@
 #define RCS_WAVE_LDS(NS) ((NS) * TRC_SRING_BYTES + TRC_SEL_BYTES)     // chunk bytes travel through in-register quad transposes
 
 template <int GEO> struct RcGeo;
-template <> struct RcGeo<0> { typedef RcEnc Enc; typedef RcDec Dec; };
+template <> struct RcGeo<0> { typedef RcEncD Enc; typedef RcDec Dec; };
 template <> struct RcGeo<1> { typedef RcEncSm Enc; typedef RcDecSm Dec; };
 
 template <int NS, int GEO>
@@ -74,7 +74,16 @@ __global__ __launch_bounds__(64) void trc_rcs_enc_kernel(
                 for (u32 d = 0; d < 4; d++) {
                     const u32 wd = v.x; v.x = v.y; v.y = v.z; v.z = v.w;
                     const u32 t0 = tab[wd & 255u], t1 = tab[(wd >> 8) & 255u], t2 = tab[(wd >> 16) & 255u], t3 = tab[wd >> 24];
-                    if (NS == 1) {
+                    if constexpr (GEO == 0) {                   // 64-bit geometry: at most one word per two symbols (trc_rc.h RcEncD)
+                        if (NS == 1) {
+                            e0.sym_rec(true, t0 & 0xffffu, t0 >> 16); e0.sym_rec(true, t1 & 0xffffu, t1 >> 16); e0.flush(so0);
+                            e0.sym_rec(true, t2 & 0xffffu, t2 >> 16); e0.sym_rec(true, t3 & 0xffffu, t3 >> 16); e0.flush(so0);
+                        } else {
+                            e0.sym_rec(true, t0 & 0xffffu, t0 >> 16); e1.sym_rec(true, t1 & 0xffffu, t1 >> 16);
+                            e0.sym_rec(true, t2 & 0xffffu, t2 >> 16); e1.sym_rec(true, t3 & 0xffffu, t3 >> 16);
+                            e0.flush(so0); e1.flush(so1);
+                        }
+                    } else if (NS == 1) {
                         e0.sym(so0, t0 & 0xffffu, t0 >> 16); e0.sym(so0, t1 & 0xffffu, t1 >> 16);
                         e0.sym(so0, t2 & 0xffffu, t2 >> 16); e0.sym(so0, t3 & 0xffffu, t3 >> 16);
                     } else {
