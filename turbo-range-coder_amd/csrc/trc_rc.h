@@ -160,6 +160,18 @@ struct RcDec {
         __device__ __forceinline__ bool operator()(u32 e) const { return code >= r * e; }
     };
     __device__ __forceinline__ GeScaled scaled() const { return GeScaled{ range >> TRC_PROB_BITS, code }; }
+    // the same step with the stream word handed in and the "renormalised" flag handed back: two consecutive symbols cannot
+    // both renormalise (see RcEncD), so a caller decodes a PAIR against one look-ahead word and advances its stream once
+    __device__ __forceinline__ bool consume_w(bool act, u32 c0, u32 c1, u32 w)
+    {
+        const u64 r = range >> TRC_PROB_BITS;
+        const u64 rp = r * c0;
+        const u64 range2 = r * (u32)(c1 - c0), code2 = code - rp;
+        const bool rn = act && range2 < TRC_TOP32;
+        range = act ? (rn ? range2 << 32 : range2) : range;
+        code = act ? (rn ? (code2 << 32) | w : code2) : code;
+        return rn;
+    }
     // _rccdfupdate + renorm where act, nothing where !act (range is still the unshifted one)
     template <class SI>
     __device__ __forceinline__ void consume_if(SI &si, bool act, u32 c0, u32 c1)

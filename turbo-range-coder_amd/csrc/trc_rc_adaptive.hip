@@ -179,20 +179,21 @@ __global__ __launch_bounds__(64) void trc_rca_dec_kernel(
     // lives in registers for the whole chunk and never travels to LDS, which takes two of the four dependent LDS round
     // trips out of every byte (one wave per SIMD: nothing else hides them).
     NibTable T0 = m.load(m.table(0));
-    auto get0 = [&](RcDec &dq, LaneIn<4> &sq, bool act) -> u32 {
+    // a symbol of a pair: `w` is the pair's look-ahead word, the return value's bit 4 says "renormalised"
+    auto get0 = [&](RcDec &dq, u32 w, bool act) -> u32 {
         u32 c0, c1;
         const u32 x = trc_nib_search(T0, dq.scaled(), c0, c1);
-        dq.consume_if(sq, act, c0, c1);
+        const bool rn = dq.consume_w(act, c0, c1, w);
         m.adapt(T0, x);
-        return x;
+        return x | (rn ? 16u : 0u);
     };
-    auto get = [&](RcDec &dq, LaneIn<4> &sq, u8 *tb, bool act) -> u32 {
+    auto get = [&](RcDec &dq, u32 w, u8 *tb, bool act) -> u32 {
         NibTable T = m.load(tb);
         u32 c0, c1;
         const u32 x = trc_nib_search(T, dq.scaled(), c0, c1);  // == first i with t[i+1]*r > code, else 15 (cdflget16)
-        dq.consume_if(sq, act, c0, c1);
+        const bool rn = dq.consume_w(act, c0, c1, w);
         m.adapt(T, x); m.store(tb, T);
-        return x;
+        return x | (rn ? 16u : 0u);
     };
 
     QuadOut qout; qout.base = out + (u64)wc.c0 * chunk;
@@ -209,17 +210,38 @@ __global__ __launch_bounds__(64) void trc_rca_dec_kernel(
                 for (u32 d = 0; d < 4; d++) {
                     const u32 q0 = p0 + d * 4u;
                     u32 w = 0;
-                    if (!NIB) {
+                    // every stream advances once per PAIR of its symbols (at most one of the two renormalises)
+                    if (!NIB && NS == 1) {
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
                             const bool act = coded && q0 + (u32)i < len;
-                            const u32 h = get0(d0, s0, act);
-                            const u32 l = NS == 1 ? get(d0, s0, m.table(1u + h), act) : get(d1, s1, m.table(1u + h), act);
-                            w |= (h << 4 | l) << (8 * i);
+                            const u32 sw = s0.peek32();
+                            const u32 h = get0(d0, sw, act);
+                            const u32 l = get(d0, sw, m.table(1u + (h & 15u)), act);
+                            s0.skip_if(((h | l) & 16u) != 0u);
+                            w |= ((h & 15u) << 4 | (l & 15u)) << (8 * i);
+                        }
+                    } else if (!NIB) {
+#pragma unroll
+                        for (int pr = 0; pr < 2; pr++) {
+                            const bool acta = coded && q0 + 2u * (u32)pr < len, actb = coded && q0 + 2u * (u32)pr + 1u < len;
+                            const u32 w0 = s0.peek32(), w1 = s1.peek32();
+                            const u32 ha = get0(d0, w0, acta);
+                            const u32 la = get(d1, w1, m.table(1u + (ha & 15u)), acta);
+                            const u32 hb = get0(d0, w0, actb);
+                            const u32 lb = get(d1, w1, m.table(1u + (hb & 15u)), actb);
+                            s0.skip_if(((ha | hb) & 16u) != 0u); s1.skip_if(((la | lb) & 16u) != 0u);
+                            w |= (((ha & 15u) << 4 | (la & 15u)) | ((hb & 15u) << 4 | (lb & 15u)) << 8) << (16 * pr);
                         }
                     } else if (NS == 1) {
 #pragma unroll
-                        for (int i = 0; i < 4; i++) w |= get0(d0, s0, coded && q0 + (u32)i < len) << (8 * i);
+                        for (int pr = 0; pr < 2; pr++) {
+                            const u32 sw = s0.peek32();
+                            const u32 a = get0(d0, sw, coded && q0 + 2u * (u32)pr < len);
+                            const u32 b = get0(d0, sw, coded && q0 + 2u * (u32)pr + 1u < len);
+                            s0.skip_if(((a | b) & 16u) != 0u);
+                            w |= ((a & 15u) | (b & 15u) << 8) << (16 * pr);
+                        }
                     } else {
 #pragma unroll
                         for (int pr = 0; pr < 2; pr++) {       // both symbols searched in the table before the pair
