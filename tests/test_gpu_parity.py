@@ -396,6 +396,31 @@ def test_c_harness_links_and_roundtrips(torch_cuda):
         assert r.stdout.count("Turbo vlc") == (7 if args[0] == "--int16" else 5), r.stdout
 
 
+def test_host_layer_slice_plan(torch_cuda, tmp_path):
+    """the host-pointer layer cuts a call into slices (ramping up from 1/8 of the slice target and down again) and pipelines
+    them over three streams: with a tiny slice target (many slices, ramps included) the files the file tool writes are
+    byte-identical to the ones of the default plan (a few MB = one slice), and they round-trip"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "harness", "trcfile")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "harness")])
+    src = tmp_path / "in.bin"
+    gen("text", 5000003, 33).tofile(src)
+    for cid in (65, 45, 46, 1):
+        outs = []
+        for tag, env in (("one", {}), ("many", {"TRC_HOST_SLICE": "131072"}), ("flat", {"TRC_HOST_SLICE": "131072", "TRC_HOST_NO_RAMP": "1"})):
+            packed, back = tmp_path / ("p%d%s" % (cid, tag)), tmp_path / ("b%d%s" % (cid, tag))
+            e = dict(os.environ, **env)
+            r = subprocess.run([exe, "c", str(cid), str(src), str(packed)], capture_output=True, text=True, timeout=120, env=e)
+            assert r.returncode == 0, r.stdout + r.stderr
+            r = subprocess.run([exe, "d", str(packed), str(back)], capture_output=True, text=True, timeout=120, env=e)
+            assert r.returncode == 0, r.stdout + r.stderr
+            assert np.array_equal(np.fromfile(back, dtype=np.uint8), np.fromfile(src, dtype=np.uint8)), (cid, tag)
+            outs.append(np.fromfile(packed, dtype=np.uint8))
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]), cid
+
+
 def test_file_tool_roundtrips(torch_cuda, tmp_path):
     """harness/trcfile.c: compress / decompress files through the reference-named functions"""
     import subprocess

@@ -521,15 +521,35 @@ int host_cdfnum(const cdf_t *cdf)
     }
     return -1;
 }
-// chunks per slice: whole groups of 64 chunks, ~16 MB of input (TRC_HOST_SLICE overrides the byte target; 8-32 MB
-// measure alike on the MI355X box, 4 MB is 30 % slower: per-slice synchronisation)
-size_t slice_chunks(uint32_t chunk, size_t nchunks)
+// Slice plan of a host-pointer call: whole groups of 64 chunks, ~16 MB of input per slice in the middle of the call
+// (TRC_HOST_SLICE overrides the byte target; 8-32 MB measure alike on the MI355X box, 4 MB throughout is 30 % slower: per-slice
+// synchronisation), ramping up from 1/8 of that at the start and down to 1/8 at the end: the first H2D copy and the last
+// D2H copy + unstaging are the part of the pipeline nothing overlaps with, so they are kept short.
+// first[i] = first chunk of slice i, first[nsl] = nchunks; returns the largest slice in chunks.
+size_t slice_plan(uint32_t chunk, size_t nchunks, std::vector<size_t> &first)
 {
     static const size_t target = getenv("TRC_HOST_SLICE") ? (size_t)strtoull(getenv("TRC_HOST_SLICE"), 0, 10) : (size_t)16 << 20;
+    static const bool ramp = !getenv("TRC_HOST_NO_RAMP");
     size_t groups = target / ((size_t)chunk * 64);
     if (groups < 1) groups = 1;
     size_t per = groups * 64;
-    while ((nchunks + per - 1) / per > 2048) per *= 2;                    // the totals area holds 2048 slices
+    while ((nchunks + per - 1) / per > 2000) per *= 2;                    // the totals area holds 2048 slices
+    auto part = [&](int sh) { size_t g = (per / 64) >> sh; return (g < 1 ? 1 : g) * 64; };
+    first.clear();
+    size_t c = 0;
+    std::vector<size_t> tail;
+    size_t left = nchunks;
+    if (ramp && nchunks > 4 * per) {                                        // up: per/8, per/4, per/2; the same coming down
+        for (int sh = 3; sh >= 1; sh--) { first.push_back(c); c += part(sh); }
+        for (int sh = 3; sh >= 1; sh--) tail.push_back(part(sh));
+        left = nchunks - c;
+        size_t t = 0; for (size_t x : tail) t += x;
+        left -= t;
+    }
+    for (size_t done = 0; done < left; done += per) first.push_back(c + done);
+    c += left;
+    for (size_t k = tail.size(); k-- > 0;) { first.push_back(c); c += tail[k]; }      // largest first: per/2, per/4, per/8
+    first.push_back(nchunks);
     return per;
 }
 }  // namespace
@@ -559,7 +579,8 @@ static size_t host_encode(int codec, const unsigned char *in, size_t inlen, unsi
         if (cdfnum <= 0) cdfnum = host_cdfnum(cdf);
         if (cdfnum <= 0 || cdfnum > 256) { fail(TRC_E_CDF, "bad CDF (need cdf[0]=0 < ... < cdf[cdfnum]=32768)"); return 0; }
     } else cdfnum = 0;
-    const size_t per = slice_chunks(chunk, nchunks), nsl = (nchunks + per - 1) / per;
+    std::vector<size_t> sc;
+    const size_t per = slice_plan(chunk, nchunks, sc), nsl = sc.size() - 1;
     const size_t slice_bytes = per * (size_t)chunk;
     const size_t wb = trc_work_bytes(codec, slice_bytes < inlen ? slice_bytes : inlen, chunk);
     if (grow(&c.d_in, &c.cap_in, inlen) || grow(&c.d_cont, &c.cap_cont, hdrsz + dir + inlen + 64) || grow(&c.d_work, &c.cap_work, wb) ||
@@ -580,10 +601,11 @@ static size_t host_encode(int codec, const unsigned char *in, size_t inlen, unsi
     size_t dpos = 0;                 // device payload offset of the next slice (each slice's payload starts 2-byte aligned: sums of even lengths... kept explicit)
     bool raw = false;
     const size_t lim = outcap ? (size_t)-1 : inlen > hdrsz + dir ? inlen - hdrsz - dir : 0;      // payload bytes above which the call returns raw
-    auto slice_len = [&](size_t i) { const size_t o = i * slice_bytes; return inlen - o < slice_bytes ? inlen - o : slice_bytes; };
+    auto slice_off = [&](size_t i) { return sc[i] * (size_t)chunk; };
+    auto slice_len = [&](size_t i) { const size_t o = slice_off(i), e = i + 1 == nsl ? inlen : slice_off(i + 1); return e - o; };
     auto put_in = [&](size_t i) -> bool {                                   // stage + H2D of slice i
         const int k = (int)(i % TRC_NSLOT);
-        const size_t o = i * slice_bytes, l = slice_len(i);
+        const size_t o = slice_off(i), l = slice_len(i);
         if (i >= TRC_NSLOT && hipEventSynchronize(c.ev_in[k]) != hipSuccess) return false;   // slot free: its last H2D is done
         CopyPool::get(0).copy(c.pin_in[k], in + o, l);
         if (hipMemcpyAsync(c.d_in + o, c.pin_in[k], l, hipMemcpyHostToDevice, c.s_in) != hipSuccess) return false;
@@ -594,8 +616,8 @@ static size_t host_encode(int codec, const unsigned char *in, size_t inlen, unsi
         if (!p.live) return true;
         const int k = (int)(p.i % TRC_NSLOT);
         if (hipEventSynchronize(c.ev_out[k]) != hipSuccess) return false;
-        const size_t nc = (p.i + 1) * per <= nchunks ? per : nchunks - p.i * per;
-        memcpy(out + hdrsz + 4 * p.i * per, c.pin_out[k], 4 * nc);
+        const size_t nc = sc[p.i + 1] - sc[p.i];
+        memcpy(out + hdrsz + 4 * sc[p.i], c.pin_out[k], 4 * nc);
         CopyPool::get(1).start(out + hdrsz + dir + p.pos, c.pin_out[k] + 4 * per, p.tot);
         p.live = false;
         return true;
@@ -603,7 +625,7 @@ static size_t host_encode(int codec, const unsigned char *in, size_t inlen, unsi
     if (!put_in(0)) { fail(TRC_E_HIP, "host encode: staging failed"); return 0; }
     for (size_t i = 0; i < nsl; i++) {
         const int k = (int)(i % TRC_NSLOT);
-        const size_t o = i * slice_bytes, l = slice_len(i), c0 = i * per;
+        const size_t o = slice_off(i), l = slice_len(i), c0 = sc[i];
         HCHK(hipStreamWaitEvent(c.s_k, c.ev_in[k], 0));
         if (trc_encode_dev(codec | flags, c.d_in + o, l, chunk, cdfnum ? d_cdf : nullptr, (unsigned)cdfnum, d_clen + c0, d_payload + dpos,
                            d_tot + i, c.d_work, c.cap_work, c.s_k)) return 0;
@@ -614,7 +636,7 @@ static size_t host_encode(int codec, const unsigned char *in, size_t inlen, unsi
         HCHK(hipEventSynchronize(c.ev_k[k]));                                                                 // ... while this thread waits for slice i's size
         const size_t tot = (size_t)c.pin_tot[i];
         if (raw || ppos + tot >= lim) { raw = true; dpos += (tot + 1) & ~(size_t)1; continue; }               // (keep going: cheap, and the state stays simple)
-        const size_t nc = c0 + per <= nchunks ? per : nchunks - c0;
+        const size_t nc = sc[i + 1] - c0;
         // (slot k's previous content, slice i-3, left it two fetches ago: start() waits for the copy before it)
         HCHK(hipStreamWaitEvent(c.s_out, c.ev_k[k], 0));
         HCHK(hipMemcpyAsync(c.pin_out[k], d_clen + c0, 4 * nc, hipMemcpyDeviceToHost, c.s_out));
@@ -662,7 +684,8 @@ static size_t host_decode(int codec, const unsigned char *in, size_t outlen, uns
         if (cdfnum <= 0) cdfnum = host_cdfnum(cdf);
         if (cdfnum <= 0 || cdfnum > 256) { fail(TRC_E_CDF, "bad CDF"); return 0; }
     } else cdfnum = 0;
-    const size_t per = slice_chunks(chunk, nchunks), nsl = (nchunks + per - 1) / per;
+    std::vector<size_t> sc;
+    const size_t per = slice_plan(chunk, nchunks, sc), nsl = sc.size() - 1;
     const size_t slice_bytes = per * (size_t)chunk;
     const size_t wb = trc_work_bytes(codec, slice_bytes < outlen ? slice_bytes : outlen, chunk);
     if (grow(&c.d_in, &c.cap_in, outlen) || grow(&c.d_cont, &c.cap_cont, hdrsz + dir + outlen + 64 + 2 * nsl) || grow(&c.d_work, &c.cap_work, wb) ||
@@ -679,7 +702,7 @@ static size_t host_decode(int codec, const unsigned char *in, size_t outlen, uns
     // payload bytes of every slice from the directory (the decoders clamp an entry above the chunk length to "raw")
     std::vector<size_t> pstart(nsl + 1, 0);
     for (size_t i = 0; i < nsl; i++) {
-        const size_t c0 = i * per, c1 = c0 + per < nchunks ? c0 + per : nchunks;
+        const size_t c0 = sc[i], c1 = sc[i + 1];
         size_t sum = 0;
         for (size_t k = c0; k < c1; k++) {
             uint32_t l; memcpy(&l, in + hdrsz + 4 * k, 4);
@@ -688,10 +711,11 @@ static size_t host_decode(int codec, const unsigned char *in, size_t outlen, uns
         }
         pstart[i + 1] = pstart[i] + sum;
     }
-    auto slice_len = [&](size_t i) { const size_t o = i * slice_bytes; return outlen - o < slice_bytes ? outlen - o : slice_bytes; };
+    auto slice_off = [&](size_t i) { return sc[i] * (size_t)chunk; };
+    auto slice_len = [&](size_t i) { const size_t o = slice_off(i), e = i + 1 == nsl ? outlen : slice_off(i + 1); return e - o; };
     auto put_in = [&](size_t i) -> bool {                                   // stage + H2D of slice i's directory and payload
         const int k = (int)(i % TRC_NSLOT);
-        const size_t c0 = i * per, nc = c0 + per <= nchunks ? per : nchunks - c0, pl = pstart[i + 1] - pstart[i];
+        const size_t c0 = sc[i], nc = sc[i + 1] - c0, pl = pstart[i + 1] - pstart[i];
         if (i >= TRC_NSLOT && hipEventSynchronize(c.ev_in[k]) != hipSuccess) return false;
         memcpy(c.pin_in[k], in + hdrsz + 4 * c0, 4 * nc);
         CopyPool::get(0).copy(c.pin_in[k] + 4 * per, in + hdrsz + dir + pstart[i], pl);
@@ -705,14 +729,14 @@ static size_t host_decode(int codec, const unsigned char *in, size_t outlen, uns
         if (!p.live) return true;
         const int k = (int)(p.i % TRC_NSLOT);
         if (hipEventSynchronize(c.ev_out[k]) != hipSuccess) return false;
-        CopyPool::get(1).start(out + p.i * slice_bytes, c.pin_out[k], slice_len(p.i));
+        CopyPool::get(1).start(out + slice_off(p.i), c.pin_out[k], slice_len(p.i));
         p.live = false;
         return true;
     };
     if (!put_in(0)) { fail(TRC_E_HIP, "host decode: staging failed"); return 0; }
     for (size_t i = 0; i < nsl; i++) {
         const int k = (int)(i % TRC_NSLOT);
-        const size_t o = i * slice_bytes, l = slice_len(i), c0 = i * per;
+        const size_t o = slice_off(i), l = slice_len(i), c0 = sc[i];
         HCHK(hipStreamWaitEvent(c.s_k, c.ev_in[k], 0));
         if (i >= TRC_NSLOT) HCHK(hipStreamWaitEvent(c.s_k, c.ev_out[k], 0));   // (d_in + o is private to the slice: nothing to wait for; kept for symmetry of the slots)
         if (trc_decode_dev(codec | flags, d_clen + c0, d_payload + ((pstart[i] + 1) & ~(size_t)1) + 2 * i, l, chunk, cdfnum ? d_cdf : nullptr, (unsigned)cdfnum,
