@@ -622,7 +622,9 @@ static size_t host_encode(int codec, const unsigned char *in, size_t inlen, unsi
         p.live = false;
         return true;
     };
-    if (!put_in(0)) { fail(TRC_E_HIP, "host encode: staging failed"); return 0; }
+    // staging runs TWO slices ahead of the coder (three staging slots): with one slice of look-ahead the H2D engine had
+    // nothing queued while the host staged the next slice -- the period was staging + coding instead of the copy time
+    if (!put_in(0) || (nsl > 1 && !put_in(1))) { fail(TRC_E_HIP, "host encode: staging failed"); return 0; }
     for (size_t i = 0; i < nsl; i++) {
         const int k = (int)(i % TRC_NSLOT);
         const size_t o = slice_off(i), l = slice_len(i), c0 = sc[i];
@@ -631,7 +633,7 @@ static size_t host_encode(int codec, const unsigned char *in, size_t inlen, unsi
                            d_tot + i, c.d_work, c.cap_work, c.s_k)) return 0;
         HCHK(hipMemcpyAsync(c.pin_tot + i, d_tot + i, 8, hipMemcpyDeviceToHost, c.s_k));
         HCHK(hipEventRecord(c.ev_k[k], c.s_k));
-        if (i + 1 < nsl && !put_in(i + 1)) { fail(TRC_E_HIP, "host encode: staging failed"); return 0; }   // overlaps slice i's kernels and slice i-1's way back
+        if (i + 2 < nsl && !put_in(i + 2)) { fail(TRC_E_HIP, "host encode: staging failed"); return 0; }   // overlaps slice i's kernels, slice i+1's H2D and slice i-1's way back
         if (!fetch(pend)) { fail(TRC_E_HIP, "host encode: fetch failed"); return 0; }                         // slice i-1 has arrived: the out-pool copies it to `out` ...
         HCHK(hipEventSynchronize(c.ev_k[k]));                                                                 // ... while this thread waits for slice i's size
         const size_t tot = (size_t)c.pin_tot[i];
@@ -733,7 +735,7 @@ static size_t host_decode(int codec, const unsigned char *in, size_t outlen, uns
         p.live = false;
         return true;
     };
-    if (!put_in(0)) { fail(TRC_E_HIP, "host decode: staging failed"); return 0; }
+    if (!put_in(0) || (nsl > 1 && !put_in(1))) { fail(TRC_E_HIP, "host decode: staging failed"); return 0; }   // two slices ahead, as in host_encode
     for (size_t i = 0; i < nsl; i++) {
         const int k = (int)(i % TRC_NSLOT);
         const size_t o = slice_off(i), l = slice_len(i), c0 = sc[i];
@@ -748,7 +750,7 @@ static size_t host_decode(int codec, const unsigned char *in, size_t outlen, uns
         HCHK(hipMemcpyAsync(c.pin_out[k], c.d_in + o, l, hipMemcpyDeviceToHost, c.s_out));
         HCHK(hipEventRecord(c.ev_out[k], c.s_out));
         if (!fetch(pend)) { fail(TRC_E_HIP, "host decode: fetch failed"); return 0; }                         // slice i-1: out-pool copies it to `out` ...
-        if (i + 1 < nsl && !put_in(i + 1)) { fail(TRC_E_HIP, "host decode: staging failed"); return 0; }   // ... while slice i+1 is staged by the in-pool
+        if (i + 2 < nsl && !put_in(i + 2)) { fail(TRC_E_HIP, "host decode: staging failed"); return 0; }   // ... while slice i+2 is staged by the in-pool
         pend = { i, true };
     }
     if (!fetch(pend)) { fail(TRC_E_HIP, "host decode: fetch failed"); return 0; }
