@@ -189,6 +189,21 @@ __global__ __launch_bounds__(896) void trc_rcs_dec_kernel(
         }
     };
 
+    // two symbols of one stream (64-bit geometry): at most one of them renormalises (trc_rc.h RcEncD), so the pair shares
+    // one look-ahead word (one ring read) and one stream advance
+    auto get2 = [&](Dec &d, StreamIn &si, u32 &xa, u32 &xb) {
+        if constexpr (GEO == 0) {
+            const u32 w = si.peek32();
+            xa = lut[d.quotient15()];
+            const u32 ta = tab[xa];
+            const bool ra = d.consume_w(true, ta & 0xffffu, (ta & 0xffffu) + (ta >> 16), w);
+            xb = lut[d.quotient15()];
+            const u32 tb = tab[xb];
+            const bool rb = d.consume_w(true, tb & 0xffffu, (tb & 0xffffu) + (tb >> 16), w);
+            si.skip_if(ra || rb);
+        } else { xa = get(d, si); xb = get(d, si); }
+    };
+
     const u32 S = chunk / TRC_SEG;
     const u32 pairs = len & ~1u;
     u8 *dst = out + (u64)c * chunk;
@@ -207,7 +222,8 @@ __global__ __launch_bounds__(896) void trc_rcs_dec_kernel(
 #pragma nounroll
                     for (u32 d = 0; d < 4; d++) {
                         u32 x0, x1, x2, x3;
-                        if (NS == 1) { x0 = get(d0, s0); x1 = get(d0, s0); x2 = get(d0, s0); x3 = get(d0, s0); }
+                        if (NS == 1) { get2(d0, s0, x0, x1); get2(d0, s0, x2, x3); }
+                        else if (GEO == 0) { get2(d0, s0, x0, x2); get2(d1, s1, x1, x3); }      // the streams are independent of each other
                         else         { x0 = get(d0, s0); x1 = get(d1, s1); x2 = get(d0, s0); x3 = get(d1, s1); }
                         v.x = v.y; v.y = v.z; v.z = v.w; v.w = x0 | (x1 << 8) | (x2 << 16) | (x3 << 24);
                     }
