@@ -85,6 +85,22 @@ struct LaneIn {
     }
     __device__ __forceinline__ u32 peek32() const { return word(); }
     __device__ __forceinline__ u32 peek16() const { const u32 w = word(); return (rpos & 2u) ? w >> 16 : w & 0xffffu; }
+    // the words at rpos (a) and rpos + 4 (b), for callers that keep their own look-ahead (UNIT == 4: rpos is a multiple of 4)
+    __device__ __forceinline__ void two_words(u32 &a, u32 &b) const
+    {
+        const bool b0 = rpos & 4u, b1 = rpos & 8u;
+        const u32 lo = b0 ? cur.y : cur.x, hi = b0 ? cur.w : cur.z;
+        const u32 t0 = b0 ? cur.z : cur.y, t1 = b0 ? nxt.x : cur.w;
+        a = b1 ? hi : lo;
+        b = b1 ? t1 : t0;
+    }
+    // consume `bytes` (0, 4 or 8) at once
+    __device__ __forceinline__ void advance(u32 bytes)
+    {
+        const u32 before = rpos;
+        rpos += bytes;
+        if ((before ^ rpos) & ~15u) { cur = nxt; nxt = trc_ld16_a2(src + trc_min((rpos & ~15u) + 16u, lim)); }
+    }
     __device__ __forceinline__ void skip_if(bool take)
     {
         rpos += take ? (u32)UNIT : 0u;

@@ -26,7 +26,9 @@
 #ifdef RCB_ABL_HALFMODEL                                   // timing experiment (profiles/r02_notes.md): nodes mod 128, twice the waves; output wrong
 #define RCB_MODEL_BYTES (128u * 64u * 2u)
 #define RCB_AMASK 0x3fffu
+#define RCB_A(x) ((x) & RCB_AMASK)
 #else
+#define RCB_A(x) (x)
 #define RCB_MODEL_BYTES (256u * 64u * 2u)                  // [ctx][lane] u16
 #define RCB_AMASK 0x7fffu
 #endif
@@ -217,38 +219,63 @@ __global__ __launch_bounds__(64) void trc_rcb_dec_kernel(
     const bool coded = alive && cl != len;
 
     LaneIn<4> si; si.prime(payload + off, coded, cl);
-    RcDec dc;
-    { const u32 a = si.peek32(); si.skip_if(coded); const u32 b = si.peek32(); si.skip_if(coded); dc.start(a, b); }
+    // rcbd_ (turborc_.h:447-452) on 32-bit halves: range = rhi:rlo, code = chi:clo (rcdinit: two words)
+    u32 rlo = ~0u, rhi = ~0u, chi, clo;
+    si.two_words(chi, clo);
+    si.advance(coded ? 8u : 0u);
+    // The stream side of a byte: two look-ahead words (w0 at the stream position, w1 behind it) are fetched once per byte; a
+    // renormalisation point takes w0 and moves w1 up -- no window select, no position arithmetic at the four points.  A byte
+    // that renormalises more than twice (>= 64 bits of range spent on <= 6 bits) refills behind a wave-uniform test.
+    u32 w0, w1;
+    si.two_words(w0, w1);
+    u32 p1 = (u32)(TRC_PROB_ONE >> 1);                         // probability of node 1, read back at the end of every byte
 
     const u32 mcol = trc_lds_addr(smem) + lane * 2u;           // this lane's model column as an LDS byte address
+    const u32 negm = 0u - mcol;
     auto get_byte = [&](bool act) -> u32 {
-        u32 ctx = 1;
-        u32 p = trc_ldsr16(mcol + 128u);
-#pragma nounroll
-        for (u32 j = 0; j < 4; j++) {
-            {                                                  // renorm before bits 7,5,3,1 only
-                const bool rn = act && dc.range < TRC_TOP32;
-                const u32 w = si.peek32();
-                dc.range = rn ? dc.range << 32 : dc.range;
-                dc.code = rn ? (dc.code << 32) | w : dc.code;
-                si.skip_if(rn);
-            }
+        u32 a = mcol + 128u;                                   // LDS address of the current node (row stride 128 B)
+        u32 p = p1;
+        u32 cnt = 0;                                           // words taken in this byte
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                // both children are requested before this bit is known (below the last level the index wraps into the
-                // model and the values are unused)
-                const u32 lc = ((ctx << 8) & (RCB_AMASK & 0x7f00u)) + mcol;  // row 2*ctx (mod 256), 128 bytes per row
-                const u32 pl = trc_ldsr16(lc), pr = trc_ldsr16(lc + 128u);
-                const u64 cut = (dc.range >> TRC_PROB_BITS) * p;
-                const bool one = dc.code < cut;                // rcbd_
-                dc.range = one ? cut : dc.range - cut;        // (lanes that are not decoding run along on their own registers
-                dc.code = one ? dc.code : dc.code - cut;       //  and model column: only `act` lanes consume stream words)
-                trc_ldsw16(((ctx << 7) & RCB_AMASK) + mcol, rcb_adapt(p, one ? 1u : 0u));
-                ctx = ctx * 2 + (one ? 1u : 0u);
-                p = one ? pr : pl;
+        for (int k = 0; k < 8; k++) {
+            if (!(k & 1)) {                                    // renorm before bits 7,5,3,1 only
+                if (k >= 4) {
+                    if (__ballot(cnt == 2u)) {                 // rare: both look-ahead words are gone
+                        si.advance(cnt == 2u ? 8u : 0u);
+                        u32 n0, n1; si.two_words(n0, n1);
+                        w0 = cnt == 2u ? n0 : w0; w1 = cnt == 2u ? n1 : w1;
+                        cnt = cnt == 2u ? 0u : cnt;
+                    }
+                }
+                const bool rn = act && rhi == 0u;
+                rhi = rn ? rlo : rhi; rlo = rn ? 0u : rlo;
+                chi = rn ? clo : chi; clo = rn ? w0 : clo;
+                w0 = rn ? w1 : w0;
+                cnt += rn ? 1u : 0u;
             }
+            // both children are requested before this bit is known (not below the last level)
+            const u32 c0 = (a << 1) + negm;                    // row 2*ctx
+            u32 pl = 0, pr = 0;
+            if (k < 7) { pl = trc_ldsr16(RCB_A(c0)); pr = trc_ldsr16(RCB_A(c0) + 128u); }
+            const u32 slo = __builtin_amdgcn_alignbit(rhi, rlo, TRC_PROB_BITS), shi = rhi >> TRC_PROB_BITS;
+            const u64 c64 = (u64)slo * p;
+            const u32 cl = (u32)c64, ch = __umul24(shi, p) + (u32)(c64 >> 32);
+            u32 b1, b2, e1, e2;
+            const u32 dlo = __builtin_subc(clo, cl, 0u, &b1), dhi = __builtin_subc(chi, ch, b1, &b2);
+            const u32 tlo = __builtin_subc(rlo, cl, 0u, &e1), thi = __builtin_subc(rhi, ch, e1, &e2);
+            const bool one = b2 != 0u;                         // code < cut
+            rlo = one ? cl : tlo; rhi = one ? ch : thi;        // (lanes that are not decoding run along on their own registers
+            clo = one ? clo : dlo; chi = one ? chi : dhi;      //  and model column: only `act` lanes consume stream words)
+            trc_ldsw16(RCB_A(a), rcb_adapt(p, one ? 1u : 0u));
+            a = c0 + (one ? 128u : 0u);
+            p = one ? pr : pl;
         }
-        return ctx & 255u;
+        p1 = trc_ldsr16(mcol + 128u);                          // node 1 as the next byte will find it
+        if (__ballot(cnt != 0u)) {                             // the stream moves once per byte
+            si.advance(cnt << 2);
+            si.two_words(w0, w1);
+        }
+        return ((a + negm) >> 7) & 255u;
     };
 
     QuadOut qout; qout.base = out + (u64)wc.c0 * chunk;
