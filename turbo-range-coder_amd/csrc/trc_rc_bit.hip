@@ -263,12 +263,15 @@ __global__ __launch_bounds__(64) void trc_rcb_dec_kernel(
             u32 b1, b2, e1, e2;
             const u32 dlo = __builtin_subc(clo, cl, 0u, &b1), dhi = __builtin_subc(chi, ch, b1, &b2);
             const u32 tlo = __builtin_subc(rlo, cl, 0u, &e1), thi = __builtin_subc(rhi, ch, e1, &e2);
-            const bool one = b2 != 0u;                         // code < cut
-            rlo = one ? cl : tlo; rhi = one ? ch : thi;        // (lanes that are not decoding run along on their own registers
-            clo = one ? clo : dlo; chi = one ? chi : dhi;      //  and model column: only `act` lanes consume stream words)
-            trc_ldsw16(RCB_A(a), rcb_adapt(p, one ? 1u : 0u));
-            a = c0 + (one ? 128u : 0u);
-            p = one ? pr : pl;
+            // the bit is the borrow of code - cut; everything that depends on it is a bit-select under its mask (written as
+            // ?: the compiler turned the group of selects into a divergent branch)
+            const u32 m = 0u - b2;                             // code < cut: all ones
+            rlo = (cl & m) | (tlo & ~m); rhi = (ch & m) | (thi & ~m);      // (lanes that are not decoding run along on their own
+            clo = (clo & m) | (dlo & ~m); chi = (chi & m) | (dhi & ~m);    //  registers and model column: only `act` lanes consume words)
+            const u32 t5 = (p | (m & 0xffff8000u)) >> 5;       // p - (bit << 15) in 32 bits (p < 2^15: the or is the add), then >> 5
+            trc_ldsw16(RCB_A(a), p - t5 + m);                  // rcb_adapt: p - (t5 + bit), 16 bits kept by the store
+            a = c0 | (m & 128u);                               // child 2*ctx + bit (bit 7 of c0 is clear)
+            p = (pr & m) | (pl & ~m);
         }
         p1 = trc_ldsr16(mcol + 128u);                          // node 1 as the next byte will find it
         if (__ballot(cnt != 0u)) {                             // the stream moves once per byte
