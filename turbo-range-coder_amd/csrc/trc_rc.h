@@ -103,7 +103,11 @@ struct RcEncD {
         range = act ? (rn ? range2 << 32 : range2) : range;
     }
     template <class SO>
-    __device__ __forceinline__ void flush(SO &so) { cw.emit_if(so, pend, pcy, pw); pend = false; }
+    __device__ __forceinline__ void flush(SO &so)
+    {
+        cw.emit_if(so, pend, pcy, pw);
+        pend = pcy = false; pw = 0;                                     // (constants at the start of the next pair: nothing of them is carried around the loops)
+    }
     template <class SO>
     __device__ __forceinline__ void sym(SO &so, u32 c0, u32 f) { sym_rec(true, c0, f); flush(so); }   // one symbol, emitted at once
     template <class SO>
