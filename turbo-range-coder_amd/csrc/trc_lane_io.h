@@ -94,6 +94,22 @@ struct LaneIn {
         a = b1 ? hi : lo;
         b = b1 ? t1 : t0;
     }
+    // Window refill without a stall.  `advance` below loads the next window inside a divergent branch, and the compiler waits
+    // for that load on the spot (it lands in a temporary that must be copied into the loop-carried registers): with 64 lanes
+    // some lane crosses a 16-byte boundary at almost every step, so the wave ate a memory round trip per step.  The
+    // prefetch form: EVERY lane requests the 16 bytes behind its current window at the START of a step (`prefetch`, mostly
+    // L1 hits: the same block ~20 times) and takes them in at the END (`advance_pre`), a whole step of work later.  Valid
+    // while a step consumes at most 8 bytes: after a crossing the position is in the first half of the new window, so the
+    // window behind it is not touched before the next step's prefetch has landed.
+    __device__ __forceinline__ uint4 prefetch() const { return trc_ld16_a2(src + trc_min((rpos & ~15u) + 16u, lim)); }
+    __device__ __forceinline__ void advance_pre(u32 bytes, const uint4 pre)
+    {
+        nxt = pre;
+        const u32 before = rpos;
+        rpos += bytes;
+        const bool cross = ((before ^ rpos) & ~15u) != 0u;
+        cur.x = cross ? nxt.x : cur.x; cur.y = cross ? nxt.y : cur.y; cur.z = cross ? nxt.z : cur.z; cur.w = cross ? nxt.w : cur.w;
+    }
     // consume `bytes` (0, 4 or 8) at once
     __device__ __forceinline__ void advance(u32 bytes)
     {

@@ -233,6 +233,7 @@ __global__ __launch_bounds__(64) void trc_rcb_dec_kernel(
     const u32 mcol = trc_lds_addr(smem) + lane * 2u;           // this lane's model column as an LDS byte address
     const u32 negm = 0u - mcol;
     auto get_byte = [&](bool act) -> u32 {
+        uint4 pre = si.prefetch();                             // the window behind the current one: taken in at the end of the byte
         u32 a = mcol + 128u;                                   // LDS address of the current node (row stride 128 B)
         u32 p = p1;
         u32 cnt = 0;                                           // words taken in this byte
@@ -242,6 +243,7 @@ __global__ __launch_bounds__(64) void trc_rcb_dec_kernel(
                 if (k >= 4) {
                     if (__ballot(cnt == 2u)) {                 // rare: both look-ahead words are gone
                         si.advance(cnt == 2u ? 8u : 0u);
+                        pre = si.prefetch();                   // (the position moved: the prefetch must follow it)
                         u32 n0, n1; si.two_words(n0, n1);
                         w0 = cnt == 2u ? n0 : w0; w1 = cnt == 2u ? n1 : w1;
                         cnt = cnt == 2u ? 0u : cnt;
@@ -274,10 +276,8 @@ __global__ __launch_bounds__(64) void trc_rcb_dec_kernel(
             p = (pr & m) | (pl & ~m);
         }
         p1 = trc_ldsr16(mcol + 128u);                          // node 1 as the next byte will find it
-        if (__ballot(cnt != 0u)) {                             // the stream moves once per byte
-            si.advance(cnt << 2);
-            si.two_words(w0, w1);
-        }
+        si.advance_pre(cnt << 2, pre);                         // the stream moves once per byte
+        si.two_words(w0, w1);
         return ((a + negm) >> 7) & 255u;
     };
 
