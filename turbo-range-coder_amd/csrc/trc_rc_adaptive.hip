@@ -211,32 +211,36 @@ __global__ __launch_bounds__(64) void trc_rca_dec_kernel(
                     const u32 q0 = p0 + d * 4u;
                     u32 w = 0;
                     // every stream advances once per PAIR of its symbols (at most one of the two renormalises)
+                    // (the window behind the current one is requested by every lane at the start of a pair and taken in at its
+                    // end: trc_lane_io.h `prefetch`)
                     if (!NIB && NS == 1) {
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
                             const bool act = coded && q0 + (u32)i < len;
+                            const uint4 pre = s0.prefetch();
                             const u32 sw = s0.peek32();
                             const u32 h = get0(d0, sw, act);
                             const u32 l = get(d0, sw, m.table(1u + (h & 15u)), act);
-                            s0.skip_if(((h | l) & 16u) != 0u);
+                            s0.advance_pre(((h | l) & 16u) >> 2, pre);
                             w |= ((h & 15u) << 4 | (l & 15u)) << (8 * i);
                         }
                     } else if (!NIB) {
 #pragma unroll
                         for (int pr = 0; pr < 2; pr++) {
                             const bool acta = coded && q0 + 2u * (u32)pr < len, actb = coded && q0 + 2u * (u32)pr + 1u < len;
+                            const uint4 pre0 = s0.prefetch(), pre1 = s1.prefetch();
                             const u32 w0 = s0.peek32(), w1 = s1.peek32();
                             const u32 ha = get0(d0, w0, acta);
                             const u32 la = get(d1, w1, m.table(1u + (ha & 15u)), acta);
                             const u32 hb = get0(d0, w0, actb);
                             const u32 lb = get(d1, w1, m.table(1u + (hb & 15u)), actb);
-                            s0.skip_if(((ha | hb) & 16u) != 0u); s1.skip_if(((la | lb) & 16u) != 0u);
+                            s0.advance_pre(((ha | hb) & 16u) >> 2, pre0); s1.advance_pre(((la | lb) & 16u) >> 2, pre1);
                             w |= (((ha & 15u) << 4 | (la & 15u)) | ((hb & 15u) << 4 | (lb & 15u)) << 8) << (16 * pr);
                         }
                     } else if (NS == 1) {
 #pragma unroll
                         for (int pr = 0; pr < 2; pr++) {
-                            const u32 sw = s0.peek32();
+                            const u32 sw = s0.peek32();         // (a nibble pair is cheap and consumes little: the plain refill measures better here)
                             const u32 a = get0(d0, sw, coded && q0 + 2u * (u32)pr < len);
                             const u32 b = get0(d0, sw, coded && q0 + 2u * (u32)pr + 1u < len);
                             s0.skip_if(((a | b) & 16u) != 0u);
