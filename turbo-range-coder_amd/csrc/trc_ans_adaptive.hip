@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64) void trc_ansa_dec_kernel(
     constexpr u32 NST = NIB ? 2u : 4u;
     u32 st[4] = { TRC_ANS_LOW, TRC_ANS_LOW, TRC_ANS_LOW, TRC_ANS_LOW };
     if (coded) for (u32 k = 0; k < NST; k++) st[k] = trc_ld32_a2(payload + off + 4u * k);   // decoder st[i] = encoder st[NST-1-i] (mnfill)
-    LaneIn<2> si; si.prime(payload + off + 4u * NST, coded, trc_sub_sat(cl, 4u * NST));   // words follow the states
+    LaneInWide si; si.prime(payload + off + 4u * NST, coded, trc_sub_sat(cl, 4u * NST));   // words follow the states
 
     // cdf16ansdec: search + state update + model update; the renorm comes separately (its order is the word order)
     auto get_nibble = [&](u32 &s, u8 *tb, bool act) -> u32 {
@@ -245,12 +245,15 @@ __global__ __launch_bounds__(64) void trc_ansa_dec_kernel(
 #pragma unroll
                         for (int j = 0; j < 2; j++) {          // mndec8x2: two bytes, then four renorms in order st0..st3
                             const bool act = coded && q0 + 2u * (u32)j < len;     // the second byte of an odd tail is the dummy
+                            const uint4 pre = si.prefetch();   // (<= 8 stream bytes per group: trc_lane_io.h LaneInWide)
                             const u32 h0 = get_nibble(st[0], m.table(0), act), l0 = get_nibble(st[1], m.table(1u + h0), act);
                             const u32 h1 = get_nibble(st[2], m.table(0), act), l1 = get_nibble(st[3], m.table(1u + h1), act);
                             renorm(st[0], act); renorm(st[1], act); renorm(st[2], act); renorm(st[3], act);
+                            si.end_step(pre);
                             w |= ((h0 << 4 | l0) | (h1 << 4 | l1) << 8) << (16 * j);
                         }
                     } else {
+                        const uint4 pre = si.prefetch();
 #pragma unroll
                         for (int i = 0; i < 4; i++) {          // mndec4: positions 0,2 of a group <- st[0], 1,3 <- st[1]; tail <- st[1]
                             const u32 pos = q0 + (u32)i;
@@ -262,6 +265,7 @@ __global__ __launch_bounds__(64) void trc_ansa_dec_kernel(
                             st[0] = first ? cur : st[0]; st[1] = first ? st[1] : cur;
                             w |= x << (8 * i);
                         }
+                        si.end_step(pre);
                     }
                     v.x = v.y; v.y = v.z; v.z = v.w; v.w = w;
                 }

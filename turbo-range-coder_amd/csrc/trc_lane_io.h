@@ -123,3 +123,40 @@ struct LaneIn {
         if (take && (rpos & 15u) == 0u) { cur = nxt; nxt = trc_ld16_a2(src + trc_min(rpos + 16u, lim)); }
     }
 };
+
+// The same for 16-bit units consumed at several points of a step (the rANS decoders: up to four renormalisations per group
+// of symbols, 8 bytes): a 32-byte window [base, base + 32) in registers, reads anywhere in its first 24 bytes, no refill inside
+// a step.  A step: `pre = prefetch()` (the 16 bytes behind the window, every lane), any number of peek16 / skip_if totalling
+// <= 8 bytes, `end_step(pre)` (the window moves up by 16 bytes where the position has left its first half: selects only).
+struct LaneInWide {
+    const u8 *src;       // this lane's stream (2-byte aligned; the payload buffer carries TRC_PAD bytes of slack)
+    u32 rpos;            // bytes consumed
+    u32 base;            // stream offset of the window (multiple of 16)
+    u32 lim;             // no bytes are fetched from beyond this stream offset (a corrupt stream re-reads its last window)
+    uint4 lo, hi;        // stream bytes [base, +16) and [base + 16, +16)
+
+    __device__ __forceinline__ void prime(const u8 *s, bool alive, u32 limit)
+    {
+        src = s; rpos = 0; base = 0; lim = limit;
+        lo = hi = make_uint4(0, 0, 0, 0);
+        if (alive) { lo = trc_ld16_a2(src); hi = trc_ld16_a2(src + trc_min(16u, lim)); }
+    }
+    __device__ __forceinline__ uint4 prefetch() const { return trc_ld16_a2(src + trc_min(base + 32u, lim)); }
+    __device__ __forceinline__ u32 peek16() const
+    {
+        const u32 o = rpos - base;                                       // 0 .. 22
+        const bool b2 = o & 4u, b3 = o & 8u, b4 = o & 16u;
+        const u32 a0 = b2 ? lo.y : lo.x, a1 = b2 ? lo.w : lo.z, a2 = b2 ? hi.y : hi.x;     // (offsets >= 24 are never reached)
+        const u32 w = b4 ? a2 : (b3 ? a1 : a0);
+        return (o & 2u) ? w >> 16 : w & 0xffffu;
+    }
+    __device__ __forceinline__ void skip_if(bool take) { rpos += take ? 2u : 0u; }
+    __device__ __forceinline__ void end_step(const uint4 pre)
+    {
+        const bool up = rpos - base >= 16u;
+        lo.x = up ? hi.x : lo.x; lo.y = up ? hi.y : lo.y; lo.z = up ? hi.z : lo.z; lo.w = up ? hi.w : lo.w;
+        hi.x = up ? pre.x : hi.x; hi.y = up ? pre.y : hi.y; hi.z = up ? pre.z : hi.z; hi.w = up ? pre.w : hi.w;
+        base += up ? 16u : 0u;
+    }
+};
+
