@@ -156,6 +156,14 @@ __global__ __launch_bounds__(64) void trc_rcv_dec_kernel(
         if (on) m.adapt(T, x);
         return x;
     };
+    // the same against a look-ahead word; bit 4 of the result: renormalised
+    auto getw = [&](RcDec &dq, u32 w, NibTable &T, bool on) -> u32 {
+        u32 c0, c1;
+        const u32 x = trc_nib_search(T, dq.scaled(), c0, c1);
+        const bool rn = dq.consume_w(on, c0, c1, w);
+        if (on) m.adapt(T, x);
+        return x | (rn ? 16u : 0u);
+    };
 
     QuadOut qout; qout.base = out + (u64)wc.c0 * chunk;
     u8 *dst = out + (u64)c * chunk;
@@ -174,10 +182,27 @@ __global__ __launch_bounds__(64) void trc_rcv_dec_kernel(
 #pragma nounroll
                     for (u32 i = 0; i < 4; i++) {
                         const bool act = coded && q0 + i < len;
-                        const u32 a = get(d0, s0, T0, act);
+                        u32 a, b, cc;
+                        if (NS == 1) {
+                            // three steps on one stream: two consecutive ones cannot both renormalise (trc_rc.h), so the byte
+                            // takes at most two words -- both looked at up front, the stream advanced once, its next window
+                            // prefetched (trc_lane_io.h)
+                            const uint4 pre = s0.prefetch();
+                            u32 w0, w1; s0.two_words(w0, w1);
+                            const u32 ra = getw(d0, w0, T0, act);
+                            a = ra & 15u;
+                            const bool two_ = act && a >= 13u, three_ = act && a == 15u;
+                            const u32 rb = getw(d0, w0, T1, two_);
+                            const u32 took = (ra | rb) & 16u;
+                            const u32 rc = getw(d0, took ? w1 : w0, T2, three_);
+                            b = rb & 15u; cc = rc & 15u;
+                            s0.advance_pre((took >> 2) + ((rc & 16u) >> 2), pre);
+                        } else {
+                            a = get(d0, s0, T0, act);
+                            b = get(d1, s1, T1, act && a >= 13u);
+                            cc = get(d0, s0, T2, act && a == 15u);
+                        }
                         const bool two = act && a >= 13u, three = act && a == 15u;
-                        const u32 b = NS == 1 ? get(d0, s0, T1, two) : get(d1, s1, T1, two);
-                        const u32 cc = get(d0, s0, T2, three);
                         const u32 x = three ? ((b << 4) | cc) + 45u : two ? (((a - 13u) << 4) | b) + 13u : a;
                         w |= (x & 255u) << (8 * i);
                     }
