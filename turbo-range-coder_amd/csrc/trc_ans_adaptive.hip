@@ -99,17 +99,20 @@ __global__ __launch_bounds__(64) void trc_ansa_model_kernel(
 }
 
 // ------------------------------------------------------------------------------ encode, pass 2 ---
-__device__ __forceinline__ void ansa_put(u32 &st, u32 rec, StreamOut<true> &so)
+// one step where `act`, nothing where not (no branch: with 64 lanes some lane is always at a different point of its chunk)
+__device__ __forceinline__ void ansa_put(u32 &st, u32 rec, StreamOut<true> &so, bool act = true)
 {
     const u32 f = rec & 0x7fffu, c0 = rec >> 15;
-    const bool emit = st >= (f << 16);
+    const bool emit = act && st >= (f << 16);
     so.put16_if(emit, st);
-    st = emit ? st >> 16 : st;
-    u32 q = (u32)((float)st * __builtin_amdgcn_rcpf((float)f));          // st/f within +-1
-    u32 r = st - __umul24(q, f);                                         // q < 2^16+1, f < 2^15
-    if ((int)r < 0) { q--; r += f; }
-    if (r >= f) { q++; r -= f; }
-    st = (q << TRC_PROB_BITS) + r + c0;
+    const u32 s1 = emit ? st >> 16 : st;
+    u32 q = (u32)((float)s1 * __builtin_amdgcn_rcpf((float)f));          // st/f within +-1 (garbage where !act: f may be 0)
+    u32 r = s1 - __umul24(q, f);                                         // q < 2^16+1, f < 2^15
+    const bool dn = (int)r < 0;
+    q -= dn ? 1u : 0u; r += dn ? f : 0u;
+    const bool up = r >= f;
+    q += up ? 1u : 0u; r -= up ? f : 0u;
+    st = act ? (q << TRC_PROB_BITS) + r + c0 : st;
 }
 
 template <bool NIB>
@@ -152,16 +155,16 @@ __global__ __launch_bounds__(64) void trc_ansa_code_kernel(
             const u32 *rr = (const u32 *)q;
 #pragma unroll
             for (int i = 15; i >= 0; i--) {
-                if ((u32)i < hi && !ovf) {
-                    if (so.wpos + room >= len) ovf = true;
-                    else if (!NIB) ansa_put(st[3 - (i & 3)], rr[i], so);      // record index 16*s + i, 16*s is a multiple of 4
-                    else if (i & 1) ansa_put(st[0], rr[i], so);
-                    else {                                     // even position: state 1 inside the body, state 0 in the tail
-                        const bool one = 16u * s + (u32)i < body;
-                        u32 cur = one ? st[1] : st[0];
-                        ansa_put(cur, rr[i], so);
-                        st[1] = one ? cur : st[1]; st[0] = one ? st[0] : cur;
-                    }
+                const bool can = (u32)i < hi && !ovf;
+                ovf = ovf || (can && so.wpos + room >= len);
+                const bool go = can && !ovf;
+                if (!NIB) ansa_put(st[3 - (i & 3)], rr[i], so, go);           // record index 16*s + i, 16*s is a multiple of 4
+                else if (i & 1) ansa_put(st[0], rr[i], so, go);
+                else {                                         // even position: state 1 inside the body, state 0 in the tail
+                    const bool one = 16u * s + (u32)i < body;
+                    u32 cur = one ? st[1] : st[0];
+                    ansa_put(cur, rr[i], so, go);
+                    st[1] = one ? cur : st[1]; st[0] = one ? st[0] : cur;
                 }
             }
         }
