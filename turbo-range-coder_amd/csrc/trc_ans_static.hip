@@ -241,29 +241,8 @@ __device__ __forceinline__ u32 ans_get(u32 &st, const u8 *lut, const uint2 *dtab
     si.rpos += rn ? 2u : 0u;
     return x;
 }
-// Two steps (state a, then state b) on one 32-bit stream window: a pair consumes at most two words, so the ring is read
-// once per pair (two aligned dwords, one ds_read2_b32) instead of once per symbol (ds_read_u16 under 32-bank rules)
-__device__ __forceinline__ u32 ans_step_win(u32 &st, const u8 *lut, const uint2 *dtab, u32 &win, u32 &cnt)
-{
-    const u32 slot = st & (TRC_PROB_ONE - 1);
-    const u32 x = lut[slot];
-    const uint2 e = dtab[x];                                  // { f, -c0 }
-    st = __umul24(e.x, st >> TRC_PROB_BITS) + e.y + slot;
-    const bool rn = st < TRC_ANS_LOW;
-    st = rn ? __builtin_amdgcn_perm(st, win, 0x05040100u) : st;     // (st << 16) | (win & 0xffff)
-    win = rn ? win >> 16 : win;
-    cnt += rn ? 2u : 0u;
-    return x;
-}
-__device__ __forceinline__ u32 ans_get2(u32 &a, u32 &b, const u8 *lut, const uint2 *dtab, StreamIn &si)
-{
-    u32 win = si.peek32w(), cnt = si.rpos;
-    const u32 x0 = ans_step_win(a, lut, dtab, win, cnt);
-    const u32 x1 = ans_step_win(b, lut, dtab, win, cnt);
-    si.rpos = cnt;
-    return x0 | (x1 << 8);
-}
-// (Also measured and dropped in round 2: the same step with integer LDS addresses and a carry-driven halfword cursor --
+// (Also measured and dropped in round 2: one aligned two-dword ring read per PAIR of symbols plus a register window instead of
+// a 16-bit read per symbol -- 14 % fewer LDS instructions, the same LDS conflict cycles, 79 against 75 us; and the same step with integer LDS addresses and a carry-driven halfword cursor --
 // 12 instead of 14 VALU per symbol in the listing, 78 against 74-75 us in three A/B pairs.  The decoder does not wait for
 // VALU issue slots; see profiles/r02_notes.md.)
 // (A hand-issued form of this step -- both states' LUT bytes and both candidate ring words requested up front, counted
@@ -319,14 +298,9 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
                 u32 w[4];
 #pragma unroll
                 for (int d = 0; d < 4; d++) {
-#ifdef TRC_DEC_WINDOW
-                    const u32 q0 = ans_get2(sb, sa, lut, dtab, si), q1 = ans_get2(sb, sa, lut, dtab, si);
-                    w[d] = q0 | (q1 << 16);
-#else
                     const u32 x0 = ans_get(sb, lut, dtab, si), x1 = ans_get(sa, lut, dtab, si);
                     const u32 x2 = ans_get(sb, lut, dtab, si), x3 = ans_get(sa, lut, dtab, si);
                     w[d] = x0 | (x1 << 8) | (x2 << 16) | (x3 << 24);
-#endif
                 }
                 tout.put((u32)k, make_uint4(w[0], w[1], w[2], w[3]));
             } else if (coded && p0 < len) {                    // last chunk's final partial piece

@@ -321,9 +321,6 @@ struct StreamIn {
                 *(u32 *)(rings + trc_raddr(trc_lane(), 16u * i)) = v[i].x;      *(u32 *)(rings + trc_raddr(trc_lane(), 16u * i + 4u)) = v[i].y;
                 *(u32 *)(rings + trc_raddr(trc_lane(), 16u * i + 8u)) = v[i].z; *(u32 *)(rings + trc_raddr(trc_lane(), 16u * i + 12u)) = v[i].w;
             }
-#ifndef TRC_RING_INTERLEAVED
-            *(u32 *)(rings + trc_raddr(trc_lane(), TRC_SRING)) = v[0].x;
-#endif
             lbytes = TRC_SRING;
         }
     }
@@ -333,20 +330,7 @@ struct StreamIn {
         const u32 j = hd >> 8, o = hd & 0xffu;
         *(u32 *)(rings + trc_raddr(j, o)) = v.x;      *(u32 *)(rings + trc_raddr(j, o + 4u)) = v.y;
         *(u32 *)(rings + trc_raddr(j, o + 8u)) = v.z; *(u32 *)(rings + trc_raddr(j, o + 12u)) = v.w;
-#ifndef TRC_RING_INTERLEAVED
-        if (o == 0) *(u32 *)(rings + trc_raddr(j, TRC_SRING)) = v.x;       // the row's pad dword mirrors ring dword 0 (peek32w)
-#endif
     }
-#ifndef TRC_RING_INTERLEAVED
-    // the 32 stream bits at rpos as ONE LDS instruction: the two aligned dwords around rpos (the second may be the mirror
-    // of dword 0 behind the ring), funnel-shifted by rpos & 2 bytes
-    __device__ __forceinline__ u32 peek32w() const
-    {
-        typedef __attribute__((address_space(3))) u32 lds_u32;
-        const lds_u32 *p = (const lds_u32 *)(uintptr_t)(trc_lds_addr(rings) + trc_lane() * TRC_SRING_STRIDE + (rpos & (TRC_SRING - 4u)));
-        return __builtin_amdgcn_alignbyte(p[1], p[0], rpos);
-    }
-#endif
     // land the round that travels in set `par` (requested two periods ago)
     __device__ __forceinline__ void commit(int par)
     {
