@@ -19,7 +19,14 @@
 #define ANSB_MODEL_BYTES (256u * 64u * 2u)                 // [ctx][lane] u16
 #define ANSB_CODE_LDS    (TRC_TILE_BYTES + TRC_SRING_BYTES + TRC_SEL_BYTES)
 
-__device__ __forceinline__ u32 ansb_adapt(u32 p, u32 bit) { return bit ? p + ((TRC_PROB_ONE - p) >> 5) : p - (p >> 5); }
+// bit 1: p += (2^15 - p) >> 5, bit 0: p -= p >> 5 -- as mask arithmetic (written as ?: the compiler made a divergent if / else of it,
+// eight per byte)
+__device__ __forceinline__ u32 ansb_adapt(u32 p, u32 bit)
+{
+    const u32 m = 0u - bit, nm = ~m;                                   // bit 1: m all ones
+    const u32 s = ((p ^ m) + (m & (TRC_PROB_ONE + 1u))) >> 5;          // (bit ? 2^15 - p : p) >> 5
+    return p + ((s ^ nm) - nm);                                         // bit ? p + s : p - s
+}
 
 // ------------------------------------------------------------------------------ encode, pass 1 ---
 __global__ __launch_bounds__(64) void trc_ansb_model_kernel(
