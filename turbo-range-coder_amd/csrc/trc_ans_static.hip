@@ -259,29 +259,22 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
     uint2 *dtab = (uint2 *)(smem + 32768);            // 256 x 8
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, BLOCK = blockDim.x;
     u8 *wbase = smem + 32768 + 2048 + wv * DEC_WAVE_LDS;
-    // Prologue order: the tables' global loads first, then each lane's own dependent chain (directory entry -> offset -> states
-    // and first 128 stream bytes, three memory round trips), THEN the tables' LDS stores and the barrier: the chain's latency
-    // runs while the table data is on its way instead of after the barrier.  (The rings are the wave's own: no barrier needed.)
-    uint4 tl[3]; u32 td = 0;                                   // <= 3 LUT vectors and 1 table entry per thread (BLOCK >= 704; fewer threads loop below)
-    const bool fast_fill = BLOCK >= 704u;
-    if (fast_fill) {
-#pragma unroll
-        for (u32 j = 0; j < 3; j++) if (tid + j * BLOCK < 2048u) tl[j] = ((const uint4 *)lut_g)[tid + j * BLOCK];
-        if (tid < 256u) td = dtab_g[tid];
-    }
+    for (u32 i = tid; i < 2048; i += BLOCK) ((uint4 *)lut)[i] = ((const uint4 *)lut_g)[i];
+    for (u32 i = tid; i < 256; i += BLOCK) { const u32 d = dtab_g[i]; dtab[i] = make_uint2(d >> 16, 0u - (d & 0xffffu)); }
+    __syncthreads();
 
     WaveChunks wc;
     wc.c0 = (blockIdx.x * (BLOCK / 64) + wv) * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
     wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
-    const bool valid = wc.c0 < nchunks;                        // (a wave without chunks still fills tables and meets the barrier)
-    wc.rows = !valid ? 0u : nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
+    if (wc.c0 >= nchunks) return;
+    wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
 
     const bool alive = lane < wc.rows;
     const u32 c = wc.c0 + lane;
     const u32 len = alive ? wc.len_of(lane) : 0u;
     const u32 cl = alive ? trc_min(clen[c], len) : 0u;        // a directory entry above the chunk length (corrupt input) reads as raw
     const u32 ex = trc_wave_incl_scan(cl) - cl;
-    const u64 off = (valid ? trc_group_base(goff, gsum, wc.c0 >> 6) : 0) + ex;
+    const u64 off = trc_group_base(goff, gsum, wc.c0 >> 6) + ex;
     const bool coded = alive && cl != len;
 
     QuadOut tout; tout.base = out + (u64)wc.c0 * chunk;        // output leaves through an in-register quad transpose
@@ -291,17 +284,6 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
     u32 sa = 0, sb = 0;
     if (coded) { sa = trc_ld32_a2(payload + off); sb = trc_ld32_a2(payload + off + 4); }   // sa = enc state 1, sb = enc state 0
     si.prime(coded);
-
-    if (fast_fill) {
-#pragma unroll
-        for (u32 j = 0; j < 3; j++) if (tid + j * BLOCK < 2048u) ((uint4 *)lut)[tid + j * BLOCK] = tl[j];
-        if (tid < 256u) dtab[tid] = make_uint2(td >> 16, 0u - (td & 0xffffu));
-    } else {
-        for (u32 i = tid; i < 2048; i += BLOCK) ((uint4 *)lut)[i] = ((const uint4 *)lut_g)[i];
-        for (u32 i = tid; i < 256; i += BLOCK) { const u32 d = dtab_g[i]; dtab[i] = make_uint2(d >> 16, 0u - (d & 0xffffu)); }
-    }
-    __syncthreads();
-    if (!valid) return;
 
     const u32 S = chunk / TRC_SEG;
     const u32 body4 = len & ~3u;
