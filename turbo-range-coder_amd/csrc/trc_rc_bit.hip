@@ -34,6 +34,13 @@
 #endif
 #define RCB_WAVE_LDS    RCB_MODEL_BYTES
 
+// (a & m) | (b & ~m) as the one instruction it is (from the C form the compiler builds and / and-or pairs, or compares and selects)
+__device__ __forceinline__ u32 rcb_bfi(u32 m, u32 a, u32 b)
+{
+    u32 r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ u32 rcb_adapt(u32 p, u32 bit) { return (p - (((p - (bit << TRC_PROB_BITS)) >> 5) + bit)) & 0xffffu; }
 
 __global__ __launch_bounds__(64) void trc_rcb_enc_kernel(
@@ -94,7 +101,6 @@ __global__ __launch_bounds__(64) void trc_rcb_enc_kernel(
         u32 pr[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) pr[k] = trc_ldsr16(ad[k]);
-        const u32 nx = ~x;
         u32 P[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -121,17 +127,16 @@ __global__ __launch_bounds__(64) void trc_rcb_enc_kernel(
                 const int k = 2 * j + h;
                 const u32 prob = h ? P[j] >> 16 : P[j] & 0xffffu;
                 const u32 m = (u32)__builtin_amdgcn_sbfe((int)x, 7 - k, 1);        // bit 1: all ones
-                const u32 nm = (u32)__builtin_amdgcn_sbfe((int)nx, 7 - k, 1);      // bit 0: all ones
                 const u32 slo = __builtin_amdgcn_alignbit(rhi, rlo, TRC_PROB_BITS), shi = rhi >> TRC_PROB_BITS;
                 const u64 c64 = (u64)slo * prob;
                 const u32 clo = (u32)c64, chi = __umul24(shi, prob) + (u32)(c64 >> 32);    // shi < 2^17, prob < 2^16
                 u32 k1, k2;
-                llo = __builtin_addc(llo, clo & nm, 0u, &k1);
-                lhi = __builtin_addc(lhi, chi & nm, k1, &k2);
+                llo = __builtin_addc(llo, rcb_bfi(m, 0u, clo), 0u, &k1);           // low += bit ? 0 : cut
+                lhi = __builtin_addc(lhi, rcb_bfi(m, 0u, chi), k1, &k2);
                 cy = cy || (k2 != 0u);
                 u32 b1, b2;
                 const u32 tlo = __builtin_subc(rlo, clo, 0u, &b1), thi = __builtin_subc(rhi, chi, b1, &b2);
-                rlo = (clo & m) | (tlo & nm); rhi = (chi & m) | (thi & nm);
+                rlo = rcb_bfi(m, clo, tlo); rhi = rcb_bfi(m, chi, thi);             // range = bit ? cut : range - cut
             }
         }
         const bool two = (rnj[0] && (rnj[1] || rnj[2] || rnj[3])) || (rnj[1] && (rnj[2] || rnj[3])) || (rnj[2] && rnj[3]);
