@@ -185,13 +185,15 @@ __global__ __launch_bounds__(64) void trc_ansb_dec_kernel(
 
     u32 st[4] = { TRC_ANS_LOW, TRC_ANS_LOW, TRC_ANS_LOW, TRC_ANS_LOW };
     if (coded) for (u32 k = 0; k < 4; k++) st[k] = trc_ld32_a2(payload + off + 4u * k);   // decoder st[i] = encoder st[3-i]
-    LaneIn<2> si; si.prime(payload + off + 16u, coded, trc_sub_sat(cl, 16u));
+    LaneInWide si; si.prime(payload + off + 16u, coded, trc_sub_sat(cl, 16u));   // <= 8 stream bytes per four bits (trc_lane_io.h)
 
     auto get_byte = [&](bool act) -> u32 {
         u32 ctx = 1;
         u32 p = mb[64];
+        uint4 pre = si.prefetch();
 #pragma unroll
         for (int j = 0; j < 8; j++) {
+            if (j == 4) { si.end_step(pre); pre = si.prefetch(); }
             // both children are requested before this bit is known (below the last level the index wraps, values unused)
             const u32 lc = (2u * ctx) & 255u;
             const u32 pl = mb[lc * 64], pr = mb[(lc + 1u) * 64];
@@ -210,6 +212,7 @@ __global__ __launch_bounds__(64) void trc_ansb_dec_kernel(
             ctx = ctx * 2 + (one ? 1u : 0u);
             p = one ? pr : pl;
         }
+        si.end_step(pre);
         return ctx & 255u;
     };
 
