@@ -70,6 +70,14 @@ __device__ __forceinline__ u32 trc_lds_addr(const void *p) { return (u32)(uintpt
 __device__ __forceinline__ u32 trc_ldsr16(u32 a) { return *(const trc_lds_u16 *)(uintptr_t)a; }
 __device__ __forceinline__ void trc_ldsw16(u32 a, u32 v) { *(trc_lds_u16 *)(uintptr_t)a = (u16)v; }
 
+// (a & m) | (b & ~m) as the one instruction it is.  From the C form the compiler builds and / and-or pairs, compares and selects
+// or -- for a group of selects on one condition -- a divergent if / else; in the one-wave-per-SIMD kernels every one of those is slower.
+__device__ __forceinline__ u32 trc_bfi(u32 m, u32 a, u32 b)
+{
+    u32 r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ u32 trc_min(u32 a, u32 b) { return a < b ? a : b; }
 __device__ __forceinline__ u32 trc_sub_sat(u32 a, u32 b) { return a > b ? a - b : 0u; }
 

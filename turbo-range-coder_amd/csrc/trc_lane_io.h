@@ -145,10 +145,11 @@ struct LaneInWide {
     __device__ __forceinline__ u32 peek16() const
     {
         const u32 o = rpos - base;                                       // 0 .. 22
-        const bool b2 = o & 4u, b3 = o & 8u, b4 = o & 16u;
-        const u32 a0 = b2 ? lo.y : lo.x, a1 = b2 ? lo.w : lo.z, a2 = b2 ? hi.y : hi.x;     // (offsets >= 24 are never reached)
-        const u32 w = b4 ? a2 : (b3 ? a1 : a0);
-        return (o & 2u) ? w >> 16 : w & 0xffffu;
+        // bit selects under sign masks of the offset's bits (as ?: the compiler made a divergent if / else of this)
+        const u32 m2 = (u32)__builtin_amdgcn_sbfe((int)o, 2, 1), m3 = (u32)__builtin_amdgcn_sbfe((int)o, 3, 1), m4 = (u32)__builtin_amdgcn_sbfe((int)o, 4, 1);
+        const u32 a0 = trc_bfi(m2, lo.y, lo.x), a1 = trc_bfi(m2, lo.w, lo.z), a2 = trc_bfi(m2, hi.y, hi.x);     // (offsets >= 24 are never reached)
+        const u32 w = trc_bfi(m4, a2, trc_bfi(m3, a1, a0));
+        return (w >> ((o & 2u) << 3)) & 0xffffu;
     }
     __device__ __forceinline__ void skip_if(bool take) { rpos += take ? 2u : 0u; }
     __device__ __forceinline__ void end_step(const uint4 pre)
