@@ -205,12 +205,12 @@ __global__ __launch_bounds__(64) void trc_ansb_dec_kernel(
                 si.skip_if(rn);
             }
             const u32 r = s & (TRC_PROB_ONE - 1), rcx = __umul24(s >> TRC_PROB_BITS, p);   // s >> 15 < 2^17, p < 2^15: the product fits 32 bits
-            const bool one = r < p;                            // ecbd
-            const u32 ns = one ? rcx + r : s - rcx - p;
+            const u32 m = (u32)((int)(r - p) >> 31);           // ecbd: bit = r < p, as a mask (r, p < 2^15); everything below selects under it
+            const u32 ns = trc_bfi(m, rcx + r, s - rcx - p);
             st[j & 3] = act ? ns : s;
-            mb[ctx * 64] = (u16)ansb_adapt(p, one ? 1u : 0u);
-            ctx = ctx * 2 + (one ? 1u : 0u);
-            p = one ? pr : pl;
+            mb[ctx * 64] = (u16)ansb_adapt(p, m & 1u);
+            ctx = ctx * 2 - m;
+            p = trc_bfi(m, pr, pl);
         }
         si.end_step(pre);
         return ctx & 255u;
