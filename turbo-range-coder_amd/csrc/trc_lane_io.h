@@ -77,22 +77,21 @@ struct LaneIn {
         cur = nxt = make_uint4(0, 0, 0, 0);
         if (alive) { cur = trc_ld16_a2(src); nxt = trc_ld16_a2(src + 16); }
     }
+    // (bit selects under sign masks of the position's bits, not compares and v_cndmask: in these one-wave-per-SIMD kernels the
+    // all-VALU form is the faster one, and a group of ?: on one condition can come out as a divergent branch)
     __device__ __forceinline__ u32 word() const
     {
-        const bool b0 = rpos & 4u, b1 = rpos & 8u;
-        const u32 lo = b0 ? cur.y : cur.x, hi = b0 ? cur.w : cur.z;
-        return b1 ? hi : lo;
+        const u32 m4 = (u32)__builtin_amdgcn_sbfe((int)rpos, 2, 1), m8 = (u32)__builtin_amdgcn_sbfe((int)rpos, 3, 1);
+        return trc_bfi(m8, trc_bfi(m4, cur.w, cur.z), trc_bfi(m4, cur.y, cur.x));
     }
     __device__ __forceinline__ u32 peek32() const { return word(); }
     __device__ __forceinline__ u32 peek16() const { const u32 w = word(); return (rpos & 2u) ? w >> 16 : w & 0xffffu; }
     // the words at rpos (a) and rpos + 4 (b), for callers that keep their own look-ahead (UNIT == 4: rpos is a multiple of 4)
     __device__ __forceinline__ void two_words(u32 &a, u32 &b) const
     {
-        const bool b0 = rpos & 4u, b1 = rpos & 8u;
-        const u32 lo = b0 ? cur.y : cur.x, hi = b0 ? cur.w : cur.z;
-        const u32 t0 = b0 ? cur.z : cur.y, t1 = b0 ? nxt.x : cur.w;
-        a = b1 ? hi : lo;
-        b = b1 ? t1 : t0;
+        const u32 m4 = (u32)__builtin_amdgcn_sbfe((int)rpos, 2, 1), m8 = (u32)__builtin_amdgcn_sbfe((int)rpos, 3, 1);
+        a = trc_bfi(m8, trc_bfi(m4, cur.w, cur.z), trc_bfi(m4, cur.y, cur.x));
+        b = trc_bfi(m8, trc_bfi(m4, nxt.x, cur.w), trc_bfi(m4, cur.z, cur.y));
     }
     // Window refill without a stall.  `advance` below loads the next window inside a divergent branch, and the compiler waits
     // for that load on the spot (it lands in a temporary that must be copied into the loop-carried registers): with 64 lanes
@@ -107,8 +106,8 @@ struct LaneIn {
         nxt = pre;
         const u32 before = rpos;
         rpos += bytes;
-        const bool cross = ((before ^ rpos) & ~15u) != 0u;
-        cur.x = cross ? nxt.x : cur.x; cur.y = cross ? nxt.y : cur.y; cur.z = cross ? nxt.z : cur.z; cur.w = cross ? nxt.w : cur.w;
+        const u32 mc = (u32)__builtin_amdgcn_sbfe((int)(before ^ rpos), 4, 1);        // crossed a 16-byte boundary (<= 8 bytes per step: bit 4 flips)
+        cur.x = trc_bfi(mc, nxt.x, cur.x); cur.y = trc_bfi(mc, nxt.y, cur.y); cur.z = trc_bfi(mc, nxt.z, cur.z); cur.w = trc_bfi(mc, nxt.w, cur.w);
     }
     // consume `bytes` (0, 4 or 8) at once
     __device__ __forceinline__ void advance(u32 bytes)
