@@ -10,6 +10,8 @@
 //              requested when the current one is used up, i.e. 16 bytes (>= 4 renormalisations) ahead.
 // No LDS at all, so four model-carrying waves fit a CU (one per SIMD).  At <= 1 scattered access per ~40
 // coded nibbles the TA cost is noise (profiles/r01_notes.md).
+// Late round 2 (profiles/r02_notes.md): LaneOutDirect (the range encoders: a plain 4-byte store per released word), the
+// prefetch form of the input window (LaneIn::prefetch / advance_pre) and LaneInWide (rANS decoders) -- see each below.
 #pragma once
 #include "trc_dev.h"
 

@@ -10,14 +10,15 @@
 //
 // One lane = one chunk = one range-coder state.  The lane's 256 x u16 model lives in LDS in a [context][lane] layout
 // (2 lanes per bank, independent of the context each lane is at), 32 KiB per wave, and it is the ONLY thing in LDS:
-// chunk bytes move through in-register quad transposes (trc_io.h QuadIn/QuadOut), the coded stream through a 16-byte
-// register window per lane (trc_lane_io.h), so five waves share a CU.  What bounds the coder is the latency of the
-// model accesses, eight per byte:
+// chunk bytes move through in-register quad transposes (trc_io.h QuadIn/QuadOut), the coded stream through per-lane
+// registers (trc_lane_io.h: released words are stored directly; the decoder keeps a 32-byte window whose next half every
+// lane prefetches at the start of a byte), so five waves share a CU: one wave per SIMD, where a kernel's time is its
+// instruction count, scalar mask logic and branches included (profiles/r02_notes.md).  The two sides:
 //   encoder  the eight nodes a byte visits are known from the byte itself ((0x100|x) >> (8-k)) and are all different,
-//            so their probabilities are read in one batch, the eight coding steps run on registers (predicated renorm,
-//            no branches), and the eight updated probabilities are written back in one batch;
+//            so their probabilities are read in one batch, adapted with packed 16-bit arithmetic and written back before
+//            the eight coding steps run on registers (state on 32-bit halves, mask selects, one emit per byte);
 //   decoder  the path depends on the decoded bits; both children of the current node are requested before the bit is
-//            resolved, so the next probability is already on its way while the current step computes.
+//            resolved, the bit is the borrow of code - cut and everything that depends on it a select under its mask.
 #include "trc_rc.h"
 #include "trc_nibmodel.h"
 #include "trc_lane_io.h"
