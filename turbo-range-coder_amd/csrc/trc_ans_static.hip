@@ -259,20 +259,34 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
     uint2 *dtab = (uint2 *)(smem + 32768);            // 256 x 8
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, BLOCK = blockDim.x;
     u8 *wbase = smem + 32768 + 2048 + wv * DEC_WAVE_LDS;
-    for (u32 i = tid; i < 2048; i += BLOCK) ((uint4 *)lut)[i] = ((const uint4 *)lut_g)[i];
-    for (u32 i = tid; i < 256; i += BLOCK) { const u32 d = dtab_g[i]; dtab[i] = make_uint2(d >> 16, 0u - (d & 0xffffu)); }
-    __syncthreads();
-
     WaveChunks wc;
     wc.c0 = (blockIdx.x * (BLOCK / 64) + wv) * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
     wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
-    if (wc.c0 >= nchunks) return;
-    wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
-
+    const bool valid = wc.c0 < nchunks;
+    wc.rows = !valid ? 0u : nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
     const bool alive = lane < wc.rows;
     const u32 c = wc.c0 + lane;
     const u32 len = alive ? wc.len_of(lane) : 0u;
+    // the table fill as one batch of loads (a plain copy loop waits for each of its three loads before it issues the next:
+    // 75.9 -> 73.6 us for 100 MB)
+    if (BLOCK >= 704u) {
+        uint4 t0 = make_uint4(0, 0, 0, 0), t1 = t0, t2 = t0; u32 td = 0;
+        t0 = ((const uint4 *)lut_g)[tid];
+        t1 = ((const uint4 *)lut_g)[tid + BLOCK];
+        if (tid + 2u * BLOCK < 2048u) t2 = ((const uint4 *)lut_g)[tid + 2u * BLOCK];
+        if (tid < 256u) td = dtab_g[tid];
+        ((uint4 *)lut)[tid] = t0; ((uint4 *)lut)[tid + BLOCK] = t1;
+        if (tid + 2u * BLOCK < 2048u) ((uint4 *)lut)[tid + 2u * BLOCK] = t2;
+        if (tid < 256u) dtab[tid] = make_uint2(td >> 16, 0u - (td & 0xffffu));
+    } else {
+        for (u32 i = tid; i < 2048; i += BLOCK) ((uint4 *)lut)[i] = ((const uint4 *)lut_g)[i];
+        for (u32 i = tid; i < 256; i += BLOCK) { const u32 d = dtab_g[i]; dtab[i] = make_uint2(d >> 16, 0u - (d & 0xffffu)); }
+    }
+    __syncthreads();
+    if (!valid) return;
+
     const u32 cl = alive ? trc_min(clen[c], len) : 0u;        // a directory entry above the chunk length (corrupt input) reads as raw
+    // (requesting it before the table fill, so that its round trip runs beside the fill's, measured the same: 75.0 vs 74.8 us)
     const u32 ex = trc_wave_incl_scan(cl) - cl;
     const u64 off = trc_group_base(goff, gsum, wc.c0 >> 6) + ex;
     const bool coded = alive && cl != len;

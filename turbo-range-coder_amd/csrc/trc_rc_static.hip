@@ -140,8 +140,18 @@ __global__ __launch_bounds__(896) void trc_rcs_dec_kernel(
     u32 *tab = (u32 *)(smem + 32768);                          // 256 x {f<<16 | c0}
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, BLOCK = blockDim.x;
     u8 *wbase = smem + 32768 + 1024 + wv * RCS_WAVE_LDS(NS);
-    for (u32 i = tid; i < 2048; i += BLOCK) ((uint4 *)lut)[i] = ((const uint4 *)lut_g)[i];
-    for (u32 i = tid; i < 256; i += BLOCK) tab[i] = tab_g[i];
+    if (BLOCK >= 704u) {                                        // one batch of loads (a copy loop waits for each load before the next: trc_ans_static.hip)
+        uint4 t0 = ((const uint4 *)lut_g)[tid], t1 = ((const uint4 *)lut_g)[tid + BLOCK], t2 = make_uint4(0, 0, 0, 0);
+        u32 td = 0;
+        if (tid + 2u * BLOCK < 2048u) t2 = ((const uint4 *)lut_g)[tid + 2u * BLOCK];
+        if (tid < 256u) td = tab_g[tid];
+        ((uint4 *)lut)[tid] = t0; ((uint4 *)lut)[tid + BLOCK] = t1;
+        if (tid + 2u * BLOCK < 2048u) ((uint4 *)lut)[tid + 2u * BLOCK] = t2;
+        if (tid < 256u) tab[tid] = td;
+    } else {
+        for (u32 i = tid; i < 2048; i += BLOCK) ((uint4 *)lut)[i] = ((const uint4 *)lut_g)[i];
+        for (u32 i = tid; i < 256; i += BLOCK) tab[i] = tab_g[i];
+    }
     __syncthreads();
 
     WaveChunks wc;
