@@ -30,6 +30,9 @@ Extra objects on the JSON line:
   flags         what the timed region leans on: TABLES_READY (coder tables derived once per CDF, untimed, as the
                 reference harness builds its CDF untimed) and DIR_READY (the decode of a step reuses the directory sums
                 its encode left in the workspace); value_cold = the same steps with both off
+  clock_warmup  the untimed preamble (the same step for ~0.4 s) that precedes the W warm-up steps: a fresh process finds the GPU
+                at idle clocks and 25 steps are over before it has ramped up; value_cold_clocks / ms_per_step_cold_clocks =
+                the same W + K protocol measured BEFORE the preamble (--clock-warmup-ms 0: no preamble, value is that)
   payload_sha256  SHA-256 of the payload area the last timed step produced on rank 0 (the committed reference hash for
                 the default configurations is in tests/golden/bench_configs.json)
   cpu_baseline  the reference (oracle/_ref) or, where absent, the oracle port, 1 thread, on a bounded
@@ -179,6 +182,9 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cold", action="store_true", help="skip the value_cold pass (flags off)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the exchange code even with 1 rank (self-test)")
+    ap.add_argument("--clock-warmup-ms", type=float, default=400.0,
+                    help="untimed preamble: the same step repeated for about this long before the W warm-up steps, so that the K "
+                         "timed steps run at the GPU's steady-state clocks (0 = none; the JSON also carries the cold-clock line)")
     ap.add_argument("--inflight", type=int, default=1,
                     help="N = 1 only: steps kept in flight on as many streams / contexts (default 1: kernels run alone, so their event "
                          "timings are their own; 2-3 hide the payload gather and the launch gaps behind the next step's coder: "
@@ -296,13 +302,50 @@ def main():
             step(k, k == G - 1)
         torch.cuda.synchronize(dev)
         pipe.reset()
-    for k in range(args.warmup):
-        step(k, k == args.warmup - 1)
-    torch.cuda.synchronize(dev)
-    if pipe is not None:
-        pipe.reset()
+    def run_untimed(nsteps):
+        for k in range(nsteps):
+            step(k, k == nsteps - 1)
+        torch.cuda.synchronize(dev)
+        if pipe is not None:
+            pipe.reset()
+
+    def wall_of(nsteps):
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        for k in range(nsteps):
+            step(k, k == nsteps - 1)
+        torch.cuda.synchronize(dev)
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        d = time.perf_counter() - t
+        if use_dist:
+            tt = torch.tensor([d], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            d = float(tt.item())
+        if pipe is not None:
+            pipe.reset()
+        return d
+
+    # ---- the GPU's clocks.  A fresh process finds the GPU at idle clocks, and W + K = 25 steps (5 ms) are over before it has
+    # ramped up: the same K steps take 0.19 ms each on a cold GPU and 0.17 ms after 0.2 s of work (profiles/r02_notes.md).  The
+    # line's `value` is the steady state: W warm-up steps and K timed steps AFTER an untimed preamble of the same step;
+    # `value_cold_clocks` is the same protocol without the preamble, measured first.
+    run_untimed(args.warmup)
     if not args.no_verify:
         assert torch.equal(d_out[:n], d_in[:n]), "round trip failed"
+    cold_clocks = None
+    pre_steps = 0
+    if args.clock_warmup_ms > 0:
+        dtc = wall_of(args.steps)
+        cold_clocks = (n * args.steps * world / dtc / 1e6, dtc / args.steps * 1e3)
+        est = dtc / args.steps
+        pre_steps = int(min(max(args.clock_warmup_ms / 1e3 / est, G), 20000))
+        pre_steps = ((pre_steps + G - 1) // G) * G
+        run_untimed(pre_steps)
+        run_untimed(args.warmup)
 
     trc.timing_enable(not os.environ.get('TRC_BENCH_NO_KTIMING'))   # (probe: event pairs on the coder launches off)
     if use_dist:
@@ -400,6 +443,10 @@ def main():
             "flags": ["TABLES_READY", "DIR_READY"] if (codec in trc.STATIC and DIRR) else (["DIR_READY"] if DIRR else (["TABLES_READY"] if codec in trc.STATIC else [])),
             "value_cold": round(cold[0], 1) if cold else None,
             "ms_per_step_cold": round(cold[1], 4) if cold else None,
+            "clock_warmup": {"ms": args.clock_warmup_ms, "steps": pre_steps,
+                             "note": "untimed preamble of the same step before the W warm-up steps: the K timed steps run at steady-state clocks"},
+            "value_cold_clocks": round(cold_clocks[0], 1) if cold_clocks else None,
+            "ms_per_step_cold_clocks": round(cold_clocks[1], 4) if cold_clocks else None,
             "payload_sha256": sha, "clen_sha256": clen_sha,
             "enc_MBps": round(n / (enc_avg * 1e-3) / 1e6, 1) if enc_avg else None,
             "dec_MBps": round(n / (dec_avg * 1e-3) / 1e6, 1) if dec_avg else None,
