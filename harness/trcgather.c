@@ -81,6 +81,19 @@ static int run_rank(int rank, int world, size_t n, uint32_t chunk, int steps, co
     trc_batch b; memset(&b, 0, sizeof b);
     b.d_clen = d_clen; b.nchunks = mych; b.d_payload = d_payload; b.d_total = d_total; b.d_clen_all = d_all_clen; b.d_payload_all = d_all_payload;
     double best = 1e30;
+    /* the GPU leaves its idle clocks only after some 0.2 s of work: the same pass, untimed and unsynchronised, until then */
+    {
+        double w0 = now();
+        int done = 0;
+        while (done < 1 || (now() - w0 < 0.4 && done < 4000)) {
+            for (int k = 0; k < (done ? 50 : 1); k++, done++) {
+                if (mylen) TK(trc_encode_dev(TRC_ANS4S, d_in, mylen, chunk, d_cdf, 256, d_clen, d_payload, d_total, d_work, wb, s));
+                TK(trc_exchange_dev(comm, 1, &b, sizes, d_meta, s));
+            }
+            CK(hipStreamSynchronize(s));
+            if (world > 1) break;                               /* (ranks must issue the same number of exchanges: one pass only) */
+        }
+    }
     for (int k = 0; k < steps + 1; k++) {                       /* first pass untimed (connections, allocations) */
         CK(hipStreamSynchronize(s));
         double t0 = now();
