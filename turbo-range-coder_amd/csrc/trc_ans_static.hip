@@ -43,8 +43,8 @@
 // The renorm half of a step is one hand-written block (6 instructions, 5 VALU): compare -> VCC; ring address of the next
 // unit from the halfword cursor (and, shift-add: also the two wait states a VALU write of VCC needs before a VALU reads
 // it as a mask on gfx950); speculative 16-bit store; st = VCC ? st >> 16 : st as ONE v_cndmask with an SDWA source
-// select (WORD_1 of st); cursor -= VCC (v_subbrev).  The division half (mul_hi, SDWA shift, mul24, add3) is left to the
-// compiler, which schedules it across the two chains.
+// select (WORD_1 of st); cursor -= VCC (v_subbrev).  The division half (mul_hi, SDWA shift, mul24, add3) follows in the same
+// block (left to the compiler it came with an s_nop per symbol behind the asm block: 1-1.5 % of the kernel).
 #ifndef TRC_ENC_PRED_WRITE
 #define TRC_ENC_PRED_WRITE 0          // 1: store only in lanes that emit (EXEC = VCC around the ds_write): ablation
 #endif
@@ -70,13 +70,21 @@ __device__ __forceinline__ void ans_put(u32 &st, const trc_v4u e, u32 rbase, u32
                  "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc"
                  : "+v"(st), "+v"(wn), "=&v"(t) : "v"(e.z), "v"(rbase) : "vcc", "memory");
 #else
+    // the whole step in one block, division included (mul_hi, SDWA shift by the entry's shift byte, mul24, add3): the compiler puts
+    // a wait state behind an asm block whose result the next instruction reads (it cannot see which instruction wrote it),
+    // which was an s_nop per symbol between the renorm block and the division -- 1-1.5 % of the kernel at every chunk size
     asm volatile("v_cmp_ge_u32_e32 vcc, %0, %3\n\t"
                  "v_and_b32_e32 %2, 63, %1\n\t"
                  "v_lshl_add_u32 %2, %2, 1, %4\n\t"
                  "ds_write_b16 %2, %0\n\t"
                  "v_cndmask_b32_sdwa %0, %0, %0, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
-                 "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc"
-                 : "+v"(st), "+v"(wn), "=&v"(t) : "v"(e.z), "v"(rbase) : "vcc", "memory");
+                 "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+                 "v_mul_hi_u32 %2, %0, %5\n\t"
+                 "v_lshrrev_b32_sdwa %2, %6, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+                 "v_mul_u32_u24_e32 %2, %2, %6\n\t"
+                 "v_add3_u32 %0, %0, %7, %2"
+                 : "+v"(st), "+v"(wn), "=&v"(t) : "v"(e.z), "v"(rbase), "v"(e.x), "v"(e.y), "v"(e.w) : "vcc", "memory");
+    return;
 #endif
     const u32 q = __umulhi(st, e.x) >> (e.y >> 24);
     st = st + e.w + __umul24(q, e.y);                         // mul24 ignores the shift byte
