@@ -293,6 +293,8 @@ struct StreamIn {
     u8 *sel;
     const u8 *gbase;     // payload base (kernel argument: keeps the loads in the global address space)
     u64 soff;            // this lane's stream start, bytes from gbase (2-byte aligned)
+    u64 wbase;           // (set by prime) soff of the wave's first lane: wave-uniform
+    u32 srel;            // (set by prime) soff - wbase: the lanes' streams follow one another, all within 64 chunks
     u32 lim;             // no segment is fetched from beyond this stream offset (a valid stream never consumes from
                          // there; a corrupt one re-reads its last segment instead of running off the payload buffer)
     u32 rpos;            // bytes consumed
@@ -311,6 +313,11 @@ struct StreamIn {
     __device__ __forceinline__ void prime(bool alive)
     {
         rpos = 0; lbytes = 0; infl = 0; mineA = mineB = false; hokA = hokB = false;
+        {
+            const u32 blo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)soff), bhi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(soff >> 32));
+            wbase = ((u64)bhi << 32) | blo;
+            srel = (u32)(soff - wbase);
+        }
         hvA = hvB = make_uint4(0, 0, 0, 0); hdA = hdB = 0;
         if (alive) {
             uint4 v[8];
@@ -357,11 +364,11 @@ struct StreamIn {
         const u32 j = sel[q];
         const u32 nx = lbytes + TRC_SEG * infl;                 // stream offset of this lane's next segment
         const u32 nx_j = (u32)__shfl((int)nx, (int)j, 64);
-        const u32 src_j = (u32)__shfl((int)trc_min(nx, lim), (int)j, 64);     // where the bytes come from (ring slot: from nx_j)
-        const u32 lo = (u32)__shfl((int)(u32)soff, (int)j, 64);
-        const u32 hi = (u32)__shfl((int)(u32)(soff >> 32), (int)j, 64);
+        // where the bytes come from (the ring slot follows from nx_j), relative to the wave's first stream: one shuffle
+        // instead of three (source offset, stream start low / high)
+        const u32 a_j = (u32)__shfl((int)(srel + trc_min(nx, lim)), (int)j, 64);
         if (q < cnt && q < 16u) {
-            const u8 *s = gbase + ((((u64)hi) << 32) | lo) + src_j + part;
+            const u8 *s = gbase + wbase + a_j + part;
             const uint4 v = trc_ld16_a2(s);
             const u32 dd = (j << 8) | ((nx_j & (TRC_SRING - 1)) + part);
             if (par == 0) { hvA = v; hdA = dd; hokA = true; } else { hvB = v; hdB = dd; hokB = true; }
