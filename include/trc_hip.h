@@ -192,6 +192,7 @@ int trc_container_check(const void *buf, size_t buflen, int codec, size_t outlen
  * number of encode (decode) CALLS measured: total_ms / launches = coder-kernel time of one call (at most 4096
  * kernel launches per direction between two enable() calls).  Thread-safe. */
 int trc_timing_enable(int on);
+int trc_timing_pause(int paused);   /* suspend (1) / resume (0) the event pairs without resetting what was collected: time a SAMPLE of the calls */
 int trc_timing_read(int decode, double *total_ms, int *launches);
 
 /* name of the dominant kernel the last encode/decode of `codec` launched (for rocprof lookups) */

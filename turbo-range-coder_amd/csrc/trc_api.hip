@@ -148,13 +148,21 @@ static struct TmState {
     int calls[2] = { 0, 0 }, pairs[2] = { 0, 0 };
     hipEvent_t ev[2][TRC_TM_MAX][2];
     bool made[2][TRC_TM_MAX] = {};
+    bool paused = false;
 } g_tm;
 static thread_local int tm_dir = -1;                            // direction of the call in progress on this thread, -1 = not timing
 extern "C" int trc_timing_enable(int on)
 {
     std::lock_guard<std::mutex> lk(g_tm.mu);
-    g_tm.on = on != 0;
+    g_tm.on = on != 0; g_tm.paused = false;
     g_tm.calls[0] = g_tm.calls[1] = g_tm.pairs[0] = g_tm.pairs[1] = 0;
+    return TRC_OK;
+}
+// suspend / resume without touching what has been collected (a caller that times a sample of its calls)
+extern "C" int trc_timing_pause(int paused)
+{
+    std::lock_guard<std::mutex> lk(g_tm.mu);
+    g_tm.paused = paused != 0;
     return TRC_OK;
 }
 bool trc_tm_next(hipEvent_t *start, hipEvent_t *stop)
@@ -174,7 +182,7 @@ bool trc_tm_next(hipEvent_t *start, hipEvent_t *stop)
 static inline void tm_begin(int dec)
 {
     std::lock_guard<std::mutex> lk(g_tm.mu);
-    tm_dir = g_tm.on ? dec : -1;
+    tm_dir = (g_tm.on && !g_tm.paused) ? dec : -1;
 }
 static inline void tm_end(int dec)
 {

@@ -76,6 +76,7 @@ def lib():
         l.trc_decode_dev.restype = C.c_int
         l.trc_decode_dev.argtypes = [C.c_int, _vp, _vp, _sz, C.c_uint32, _vp, C.c_uint, _vp, _vp, _sz, _vp]
         l.trc_timing_enable.restype = C.c_int; l.trc_timing_enable.argtypes = [C.c_int]
+        l.trc_timing_pause.restype = C.c_int; l.trc_timing_pause.argtypes = [C.c_int]
         l.trc_timing_read.restype = C.c_int
         l.trc_timing_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         l.trc_kernel_name.restype = C.c_char_p; l.trc_kernel_name.argtypes = [C.c_int, C.c_int]
@@ -94,6 +95,11 @@ def _chk(rc):
 
 def timing_enable(on=True):
     _chk(lib().trc_timing_enable(1 if on else 0))
+
+
+def timing_pause(paused=True):
+    """suspend / resume the event pairs without resetting what has been collected"""
+    _chk(lib().trc_timing_pause(1 if paused else 0))
 
 
 def timing_read(decode):
