@@ -122,6 +122,45 @@ __device__ __forceinline__ void trc_wave_copy(u8 *dst, const u8 *src, u32 len)
     if (lane < len - done) dst[done + lane] = src[done + lane];
 }
 
+// The chunks a wave's lanes hold RAW (rawmask: stored length == chunk length), copied to their places in `out`: four at a time,
+// one per 16-lane group (the copy of one 512-byte chunk is a memory round trip with half a wave's lanes busy; a wave of mixed
+// data has a dozen of them, and one after the other they were a quarter of the decoder's time on `mix100m`).
+// off / len: this lane's payload offset and chunk length; out_wave = out + first chunk of the wave * chunk.
+__device__ __forceinline__ void trc_wave_copy_raw(u64 rawmask, u64 off, u32 len, u8 *out_wave, u32 chunk, const u8 *payload)
+{
+    const u32 lane = trc_lane(), grp = lane >> 4, gl = lane & 15u;
+    if (((uintptr_t)out_wave | chunk) & 15u) {                  // (unaligned output: the general copy, one chunk at a time)
+        while (rawmask) {
+            const int k = __ffsll((long long)rawmask) - 1;
+            rawmask &= rawmask - 1;
+            const u32 olo = (u32)__shfl((int)(u32)off, k, 64), ohi = (u32)__shfl((int)(u32)(off >> 32), k, 64);
+            const u32 l = (u32)__shfl((int)len, k, 64);
+            trc_wave_copy(out_wave + (u64)(u32)k * chunk, payload + (((u64)ohi << 32) | olo), l);
+        }
+        return;
+    }
+    while (rawmask) {
+        int mine = -1;                                          // the chunk (lane index) this 16-lane group copies in this trip
+#pragma unroll
+        for (u32 g = 0; g < 4; g++) {
+            const int k = rawmask ? __ffsll((long long)rawmask) - 1 : -1;
+            if (rawmask) rawmask &= rawmask - 1;
+            if (g == grp) mine = k;
+        }
+        const int src_lane = mine < 0 ? 0 : mine;
+        const u32 olo = (u32)__shfl((int)(u32)off, src_lane, 64), ohi = (u32)__shfl((int)(u32)(off >> 32), src_lane, 64);
+        const u32 l = (u32)__shfl((int)len, src_lane, 64);
+        if (mine >= 0) {
+            u8 *d = out_wave + (u64)(u32)mine * chunk;
+            const u8 *sp = payload + (((u64)ohi << 32) | olo);
+            const u32 nvec = l >> 4;
+            for (u32 i = gl; i < nvec; i += 16) *(uint4 *)(d + (size_t)i * 16) = trc_ld16_a2(sp + (size_t)i * 16);
+            const u32 done = nvec << 4;
+            if (gl < l - done) d[done + gl] = sp[done + gl];
+        }
+    }
+}
+
 // Payload offset of group g (64 chunks): goff[g] when the caller ran the scan kernel, otherwise the sum
 // of the per-group byte counts below g, computed by the calling wave (all 64 lanes must call).
 // (A variant with atomically accumulated per-64-group super-sums was measured and dropped: the atomics

@@ -270,14 +270,7 @@ __global__ __launch_bounds__(64) void trc_rca_dec_kernel(
         qout.put(0, pc0); qout.put(1, pc1); qout.put(2, pc2); qout.put(3, pc3);
         qout.flush(wc, s * TRC_SEG);
     }
-    u64 rawmask = __ballot(alive && cl == len && len != 0);
-    while (rawmask) {
-        const int k = __ffsll((long long)rawmask) - 1;
-        rawmask &= rawmask - 1;
-        const u32 olo = (u32)__shfl((int)(u32)off, k, 64), ohi = (u32)__shfl((int)(u32)(off >> 32), k, 64);
-        const u32 l = (u32)__shfl((int)len, k, 64);
-        trc_wave_copy(out + (u64)(wc.c0 + (u32)k) * chunk, payload + (((u64)ohi << 32) | olo), l);
-    }
+    trc_wave_copy_raw(__ballot(alive && cl == len && len != 0), off, len, out + (u64)wc.c0 * chunk, chunk, payload);
 }
 
 template <int NS, bool NIB>
