@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json metric: encode+decode MB/s, order-0 static-CDF rANS, 100 MB bytes.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without WORLD_SIZE: starts its own N ranks, see launch_command)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 A "step" = one encode pass + one decode pass of the hot path over this rank's 100 MB shard, inputs
@@ -167,6 +167,35 @@ def cpu_baseline(codec, d, cdf, cdfnum, sample):
     return out
 
 
+def launch_command(ngpus, argv, env=None):
+    """`python bench.py --gpus N` started by hand (no WORLD_SIZE in the environment) starts its own N ranks: the command and
+    the environment additions of that launch -- one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1
+    (the container hostname may not resolve), a free port unless MASTER_PORT is given."""
+    import socket
+    env = os.environ if env is None else env
+    port = env.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + [a for a in argv if a != "--dry-launch"]
+    add = {"HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),     # dmabuf IPC: RCCL needs it on this stack
+           "OMP_NUM_THREADS": env.get("OMP_NUM_THREADS", "8")}
+    return cmd, add
+
+
+def self_launch(args):
+    import subprocess
+    cmd, add = launch_command(args.gpus, sys.argv[1:])
+    if args.dry_launch:
+        print(json.dumps({"launch": cmd, "env": add}))
+        return 0
+    env = dict(os.environ); env.update(add)
+    # the ranks inherit stdout: rank 0 prints the one JSON line; torch.distributed.run ends non-zero if any rank dies
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,7 +222,13 @@ def main():
                     help="N = 1 only: steps kept in flight on as many streams / contexts (default 1: kernels run alone, so their event "
                          "timings are their own; 2-3 hide the payload gather and the launch gaps behind the next step's coder: "
                          "+9 %% at chunk 512, +31 %% at chunk 1024, profiles/r02_notes.md -- with longer per-kernel times)")
+    ap.add_argument("--dry-launch", action="store_true", help="with --gpus N > 1 and no WORLD_SIZE: print the launch (command, environment) as JSON and exit")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:       # started by hand: start the N ranks ourselves
+        sys.exit(self_launch(args))
+    if args.dry_launch:
+        print(json.dumps({"launch": None, "env": {}}))
+        return
 
     import hashlib
     import torch
@@ -204,9 +239,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    if world != args.gpus and not (world == 1 and args.gpus <= 1):
+        sys.exit("bench.py --gpus %d inside a job of WORLD_SIZE=%d: the two must agree" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU: libturborc_hip has no CPU path"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
