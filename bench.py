@@ -167,6 +167,39 @@ def cpu_baseline(codec, d, cdf, cdfnum, sample):
     return out
 
 
+def beyond_cache_leg(torch, trc, T, codec, chunk, dev, steps=5, warmup=2, n=1000 * 1000 * 1000):
+    """The default workload (100 MB in, 64.5 MB of payload) sits inside the 256 MiB Infinity Cache.  This leg repeats the
+    step on BASELINE config 5's per-GPU shard -- 10^9 Zipf(1.1) bytes generated on the device, beyond any cache -- and
+    reports it next to the headline: value, kernel times and the roofline fraction of its dominant kernel."""
+    d_in = torch.zeros(n + 512, dtype=torch.uint8, device=dev)
+    T.table_bytes_device(torch, dev, n, T.zipf_weights(1.1, 256), 1000, out=d_in)
+    dc = trc.DeviceCoder(codec, n, chunk, dev)
+    d_out = torch.zeros(n + 512, dtype=torch.uint8, device=dev)
+    if codec in trc.STATIC:
+        dc.cdfini(d_in, n, 256)
+    for _ in range(warmup):
+        dc.encode(d_in, n); dc.decode(d_out, n, dir_ready=True)
+    torch.cuda.synchronize(dev)
+    assert torch.equal(d_out[:n], d_in[:n]), "round trip failed (beyond-cache leg)"
+    trc.timing_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        dc.encode(d_in, n); dc.decode(d_out, n, dir_ready=True)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    enc_ms, enc_cnt = trc.timing_read(False)
+    dec_ms, dec_cnt = trc.timing_read(True)
+    trc.timing_enable(False)
+    total_c = int(dc.total[0].item())
+    e, d = enc_ms / max(enc_cnt, 1), dec_ms / max(dec_cnt, 1)
+    dom = max(e, d)
+    ach = (n + total_c) / (dom * 1e-3) / 1e9
+    return {"workload": "zipf1000m: 10^9 Zipf(1.1) bytes generated on the device (seed 1000), chunk %d" % chunk,
+            "value": round(n * steps / dt / 1e6, 1), "unit": "MB/s", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
+            "compressed_bytes": total_c, "enc_kernel_ms": round(e, 4), "dec_kernel_ms": round(d, 4),
+            "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4)}
+
+
 def launch_command(ngpus, argv, env=None):
     """`python bench.py --gpus N` started by hand (no WORLD_SIZE in the environment) starts its own N ranks: the command and
     the environment additions of that launch -- one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1
@@ -222,6 +255,7 @@ def main():
                     help="N = 1 only: steps kept in flight on as many streams / contexts (default 1: kernels run alone, so their event "
                          "timings are their own; 2-3 hide the payload gather and the launch gaps behind the next step's coder: "
                          "+9 %% at chunk 512, +31 %% at chunk 1024, profiles/r02_notes.md -- with longer per-kernel times)")
+    ap.add_argument("--no-beyond", action="store_true", help="default workload, N = 1: skip the beyond-cache leg (the same step on 1 GB generated on the device)")
     ap.add_argument("--dry-launch", action="store_true", help="with --gpus N > 1 and no WORLD_SIZE: print the launch (command, environment) as JSON and exit")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:       # started by hand: start the N ranks ourselves
@@ -463,12 +497,18 @@ def main():
         dom_ms = max(enc_avg, dec_avg)
         alg_bytes = n + total_c
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic = None
+        # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes of this same command
+        # (scripts/gpu_profile_round.sh -> scripts/pmc_traffic.py -> profiles/pmc_traffic.json): counters cannot be read
+        # from inside the timed process, so the line names where the figure was taken (`traffic_source`)
+        traffic = traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
                 if n == 100 * 1000 * 1000 and args.workload == "default":   # the PMC passes were taken on the default workload
-                    traffic = json.load(open(tpath)).get("%s_%s_chunk%d" % (args.codec, dom, chunk))
+                    tj = json.load(open(tpath))
+                    traffic = tj.get("%s_%s_chunk%d" % (args.codec, dom, chunk))
+                    if traffic is not None:
+                        traffic_source = "profiles/pmc_traffic.json (%s)" % tj.get("source", "rocprofv3 --pmc passes of `python bench.py`, TCC_EA0_RDREQ/WRREQ by request size")
             except Exception:
                 traffic = None
         default_metric = args.codec == "anscdf4s" and args.workload == "default" and n == 100 * 1000 * 1000
@@ -494,7 +534,7 @@ def main():
             "dec_MBps": round(n / (dec_avg * 1e-3) / 1e6, 1) if dec_avg else None,
             "roofline": {"bound": "hbm", "kernel": trc.lib().trc_kernel_name(codec, dom == "dec").decode(),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "alg_bytes_per_launch": alg_bytes,
                          "enc_kernel_ms": round(enc_avg, 4), "dec_kernel_ms": round(dec_avg, 4), "launches_timed": enc_cnt,
                          "timed": "HIP event pairs on the coder-kernel launches of every %s timed step (two-pass encoders: both passes summed); directory and gather kernels are in ms_per_step only" % ("" if te == 1 else {2: "2nd", 3: "3rd"}.get(te, "%dth" % te))},
@@ -506,6 +546,12 @@ def main():
             for e in json.load(open(gold)):
                 if e["codec"] == args.codec and e["chunk"] == chunk and e["n"] == n:
                     res["payload_matches_reference_sha256"] = bool(e["payload_sha256"] == sha and e["clen_sha256"] == clen_sha)
+        if world == 1 and default_metric and not args.no_beyond and inflight == 1:
+            del d_out
+            torch.cuda.empty_cache()
+            res["beyond_cache"] = beyond_cache_leg(torch, trc, T, codec, chunk, dev)
+            res["roofline"]["frac_beyond_l3"] = res["beyond_cache"]["frac"]
+            res["roofline"]["note_l3"] = "frac is measured on the 100 MB workload, which (with its 64.5 MB payload) fits the 256 MiB Infinity Cache; frac_beyond_l3 is the same kernel on 1 GB"
         if world == 1 and not args.no_cpu:
             if d is None:                                      # device-only workload: time the CPU on the first bytes of the same stream
                 d = T.table_bytes_range(0, min(n, 100 * 1000 * 1000), T.zipf_weights(1.1, 256), 1000 + rank)

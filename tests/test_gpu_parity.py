@@ -204,6 +204,39 @@ def test_host_pointer_layer(torch_cuda, codec):
         trc.lib().trc_set_chunk(1024)
 
 
+def test_host_pointer_layer_is_thread_safe(torch_cuda):
+    """host-pointer calls from several threads at once.  Calls on one device serialise on the device
+    context's lock and use that context's own copy-thread pools (round 2 had process-wide pools behind per-device locks);
+    inputs above 1 MB per slice go through the pools' threaded path.  Eight threads, three coders, sizes straddling the
+    pool threshold: every container must equal the one the same call produces alone, and decode back."""
+    import concurrent.futures as cf
+    chunk = 1024
+    assert trc.lib().trc_set_chunk(chunk) == 0
+    try:
+        jobs = []
+        for t in range(8):
+            codec = (trc.ANS4S, trc.RCS2, trc.RCA)[t % 3]
+            n = (6000001, 900001, 2500003, 300000)[t % 4] + 4096 * t
+            d = gen("text" if t % 2 else "zipf", n, 100 + t)
+            _, cdf, cdfnum = T.orc_cdfini(d)
+            jobs.append((codec, d, cdf, cdfnum))
+        alone = [trc.host_encode(c, d, cdf, m) for c, d, cdf, m in jobs]
+
+        def both(j):
+            c, d, cdf, m = jobs[j]
+            comp = trc.host_encode(c, d, cdf, m)
+            back = trc.host_decode(c, comp, d.size, cdf, m)
+            return comp, back
+        for _ in range(3):
+            with cf.ThreadPoolExecutor(8) as ex:
+                res = list(ex.map(both, range(len(jobs))))
+            for j, (comp, back) in enumerate(res):
+                assert np.array_equal(comp, alone[j]), "thread %d: container differs from the single-threaded call" % j
+                assert np.array_equal(back, jobs[j][1]), "thread %d: round trip" % j
+    finally:
+        trc.lib().trc_set_chunk(1024)
+
+
 @pytest.mark.parametrize("codec", trc.AVAILABLE, ids=lambda c: trc.CODEC_NAMES[c])
 def test_baseline_size_properties(torch_cuda, codec):
     """100 MB (BASELINE.json configs): round trip on device, directory consistency, sampled chunks == oracle"""

@@ -154,6 +154,22 @@ def test_host_layer_slice_plan(torch_cuda, tmp_path):
             assert np.array_equal(np.fromfile(back, dtype=np.uint8), np.fromfile(src, dtype=np.uint8)), (cid, tag)
             outs.append(np.fromfile(packed, dtype=np.uint8))
         assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]), cid
+    # slice targets below two groups of 64 chunks (TRC_HOST_SLICE < 2 * chunk * 64): the ramps are then as long as whole slices
+    # and the plan must not take them unless they fit (round 2: 257..383 chunks made the plan's remainder wrap around)
+    for nchunks in (257, 300, 383, 384, 450):
+        src2 = tmp_path / ("in%d.bin" % nchunks)
+        gen("text", nchunks * 1024 - 17, 35).tofile(src2)
+        outs = []
+        for tag, env in (("one", {}), ("tiny", {"TRC_HOST_SLICE": "65536"}), ("tinyflat", {"TRC_HOST_SLICE": "65536", "TRC_HOST_NO_RAMP": "1"})):
+            packed, back = tmp_path / ("q%d%s" % (nchunks, tag)), tmp_path / ("r%d%s" % (nchunks, tag))
+            e = dict(os.environ, **env)
+            r = subprocess.run([exe, "c", "65", str(src2), str(packed)], capture_output=True, text=True, timeout=60, env=e)
+            assert r.returncode == 0, (nchunks, tag, r.stdout + r.stderr)
+            r = subprocess.run([exe, "d", str(packed), str(back)], capture_output=True, text=True, timeout=60, env=e)
+            assert r.returncode == 0, (nchunks, tag, r.stdout + r.stderr)
+            assert np.array_equal(np.fromfile(back, dtype=np.uint8), np.fromfile(src2, dtype=np.uint8)), (nchunks, tag)
+            outs.append(np.fromfile(packed, dtype=np.uint8))
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]), nchunks
 
 
 def test_c_harness_links_and_roundtrips(torch_cuda):

@@ -383,20 +383,22 @@ namespace {
 // ---- copy threads: memcpy(dst, src, len) split over the pool, caller blocks until done --------------------------
 class CopyPool {
 public:
-    // never destroyed: its threads are detached and wait on the condition variable for the life of the process
-    // (destroying a condition variable with waiters blocks in glibc: a process would hang at exit).
-    // Two pools: 0 fills the staging buffers on the way in, 1 empties them on the way out -- both directions at once.
-    static CopyPool &get(int which) { static CopyPool *p[2] = { new CopyPool, new CopyPool }; return *p[which]; }
-    // start a copy on the pool's threads and return; wait() blocks until it is done (one copy in flight per pool)
+    // A pool belongs to ONE HostCtx (one device): two per context -- one fills the staging buffers on the way in, one empties
+    // them on the way out, both directions at once -- created with the context and used only under the context's lock, so
+    // calls on different devices never meet in a pool (round 2 had two process-wide pools behind per-device locks: two
+    // threads could both pass wait() and the second overwrite the first's job).  Never destroyed: the threads are detached
+    // and wait on the condition variable for the life of the process (destroying a condition variable with waiters blocks
+    // in glibc: a process would hang at exit).
+    // start a copy on the pool's threads and return; wait() blocks until it is done (one copy in flight per pool).
+    // Waiting for the previous job and installing the new one happen under ONE lock, so start() is safe on its own too.
     void start(void *dst, const void *src, size_t len)
     {
-        wait();
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [&] { return pending_ == 0; });
         if (len == 0) return;
-        if (nthr_ == 0) { memcpy(dst, src, len); return; }
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            dst_ = (uint8_t *)dst; src_ = (const uint8_t *)src; len_ = len; next_ = 0; pending_ = nthr_; gen_++;
-        }
+        if (nthr_ == 0) { lk.unlock(); memcpy(dst, src, len); return; }
+        dst_ = (uint8_t *)dst; src_ = (const uint8_t *)src; len_ = len; next_ = 0; pending_ = nthr_; gen_++;
+        lk.unlock();
         cv_.notify_all();
     }
     void wait()
@@ -412,8 +414,6 @@ public:
         work();
         wait();
     }
-private:
-    static constexpr size_t PIECE = 1u << 19;
     CopyPool()
     {
         const char *e = getenv("TRC_COPY_THREADS");
@@ -422,6 +422,9 @@ private:
         if (nthr_ > 15) nthr_ = 15;
         for (int i = 0; i < nthr_; i++) std::thread([this] { loop(); }).detach();
     }
+    CopyPool(const CopyPool &) = delete;
+private:
+    static constexpr size_t PIECE = 1u << 19;
     void work()
     {
         for (;;) {
@@ -460,6 +463,23 @@ struct HostCtx {
     uint8_t *pin_in[TRC_NSLOT] = {}, *pin_out[TRC_NSLOT] = {}; size_t cap_pin = 0;
     uint64_t *pin_tot = nullptr;                       // pinned: per-slice totals
     hipEvent_t ev_in[TRC_NSLOT] = {}, ev_k[TRC_NSLOT] = {}, ev_out[TRC_NSLOT] = {};
+    CopyPool *pool_in = nullptr, *pool_out = nullptr;  // this context's copy threads (staging in / unstaging out)
+};
+// Every failure of a host-pointer call leaves through this guard: copy threads may still be writing into the caller's
+// `out`, DMAs may still target the staging buffers -- nothing of the call may be in flight when it returns (the caller may
+// free `out`, the next call may reallocate the pinned buffers).
+struct HostDrain {
+    HostCtx &c; bool ok = false;
+    explicit HostDrain(HostCtx &ctx) : c(ctx) {}
+    ~HostDrain()
+    {
+        if (ok) return;
+        if (c.pool_in) c.pool_in->wait();
+        if (c.pool_out) c.pool_out->wait();
+        if (c.s_in) (void)hipStreamSynchronize(c.s_in);
+        if (c.s_k) (void)hipStreamSynchronize(c.s_k);
+        if (c.s_out) (void)hipStreamSynchronize(c.s_out);
+    }
 };
 #define TRC_MAX_DEV 64
 HostCtx g_ctxs[TRC_MAX_DEV];
@@ -488,6 +508,7 @@ int ctx_init(HostCtx &c, int dev)
         HIPCHK(hipEventCreateWithFlags(&c.ev_k[i], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c.ev_out[i], hipEventDisableTiming));
     }
+    c.pool_in = new CopyPool; c.pool_out = new CopyPool;
     c.init = true;
     return TRC_OK;
 }
@@ -547,12 +568,12 @@ size_t slice_plan(uint32_t chunk, size_t nchunks, std::vector<size_t> &first)
     size_t c = 0;
     std::vector<size_t> tail;
     size_t left = nchunks;
-    if (ramp && nchunks > 4 * per) {                                        // up: per/8, per/4, per/2; the same coming down
-        for (int sh = 3; sh >= 1; sh--) { first.push_back(c); c += part(sh); }
+    size_t ramp_chunks = 0;
+    for (int sh = 3; sh >= 1; sh--) ramp_chunks += part(sh);                // part() never goes below one group: with small slice targets the
+    if (ramp && nchunks > 4 * per && nchunks > 2 * ramp_chunks + per) {     // ramps are longer than 7/8 of a slice each -- count what they really take
+        for (int sh = 3; sh >= 1; sh--) { first.push_back(c); c += part(sh); }   // up: per/8, per/4, per/2; the same coming down
         for (int sh = 3; sh >= 1; sh--) tail.push_back(part(sh));
-        left = nchunks - c;
-        size_t t = 0; for (size_t x : tail) t += x;
-        left -= t;
+        left = nchunks - 2 * ramp_chunks;
     }
     for (size_t done = 0; done < left; done += per) first.push_back(c + done);
     c += left;
@@ -577,6 +598,7 @@ static size_t host_encode(int codec, const unsigned char *in, size_t inlen, unsi
     std::lock_guard<std::mutex> lk(c.mu);
     int dev = 0; HCHK(hipGetDevice(&dev));
     if (ctx_init(c, dev)) return 0;
+    HostDrain guard(c);
     uint32_t chunk = chunk_override ? chunk_override : trc_get_chunk();
     if (!chunk_ok(chunk)) { fail(TRC_E_ARG, "chunk %u: must be a multiple of 64 in [%u,%u]", chunk, TRC_CHUNK_MIN, TRC_CHUNK_MAX); return 0; }
     if (codec == TRC_ANSB && chunk > TRC_ANSB_CHUNK_MAX) chunk = TRC_ANSB_CHUNK_MAX;
@@ -615,7 +637,7 @@ static size_t host_encode(int codec, const unsigned char *in, size_t inlen, unsi
         const int k = (int)(i % TRC_NSLOT);
         const size_t o = slice_off(i), l = slice_len(i);
         if (i >= TRC_NSLOT && hipEventSynchronize(c.ev_in[k]) != hipSuccess) return false;   // slot free: its last H2D is done
-        CopyPool::get(0).copy(c.pin_in[k], in + o, l);
+        c.pool_in->copy(c.pin_in[k], in + o, l);
         if (hipMemcpyAsync(c.d_in + o, c.pin_in[k], l, hipMemcpyHostToDevice, c.s_in) != hipSuccess) return false;
         return hipEventRecord(c.ev_in[k], c.s_in) == hipSuccess;
     };
@@ -626,7 +648,7 @@ static size_t host_encode(int codec, const unsigned char *in, size_t inlen, unsi
         if (hipEventSynchronize(c.ev_out[k]) != hipSuccess) return false;
         const size_t nc = sc[p.i + 1] - sc[p.i];
         memcpy(out + hdrsz + 4 * sc[p.i], c.pin_out[k], 4 * nc);
-        CopyPool::get(1).start(out + hdrsz + dir + p.pos, c.pin_out[k] + 4 * per, p.tot);
+        c.pool_out->start(out + hdrsz + dir + p.pos, c.pin_out[k] + 4 * per, p.tot);
         p.live = false;
         return true;
     };
@@ -657,8 +679,9 @@ static size_t host_encode(int codec, const unsigned char *in, size_t inlen, unsi
         dpos += (tot + 1) & ~(size_t)1;
     }
     if (!fetch(pend)) { fail(TRC_E_HIP, "host encode: fetch failed"); return 0; }
-    CopyPool::get(1).wait();
+    c.pool_out->wait();
     HCHK(hipStreamSynchronize(c.s_in));
+    guard.ok = true;                                                        // everything of this call has landed
     if (raw) { memcpy(out, in, inlen); return inlen; }                      // reference convention: == inlen => raw
     trc_container_hdr h;
     memset(&h, 0, sizeof h);
@@ -678,6 +701,7 @@ static size_t host_decode(int codec, const unsigned char *in, size_t outlen, uns
     std::lock_guard<std::mutex> lk(c.mu);
     int dev = 0; HCHK(hipGetDevice(&dev));
     if (ctx_init(c, dev)) return 0;
+    HostDrain guard(c);
     trc_container_hdr h;
     memcpy(&h, in, sizeof h);
     if (h.magic != TRC_MAGIC || h.version != 1 || h.codec != codec || h.n != outlen ||
@@ -687,8 +711,11 @@ static size_t host_decode(int codec, const unsigned char *in, size_t outlen, uns
     }
     const size_t hdrsz = sizeof h, nchunks = h.nchunks, dir = 4 * nchunks;
     const uint32_t chunk = h.chunk;
-    // the prototype carries no input length: what is read from `in` is bounded by the caller's own outlen (header
-    // fields were checked against it above) and the directory must add up to the payload the header states
+    // The prototype carries no input length, so this is a SELF-CONSISTENCY test of the container, not a bound on the caller's
+    // buffer: the length passed below is the one the header itself states.  It rejects truncated or inconsistent
+    // directories; a forged header can still make this function read up to outlen + 4 * nchunks + 32 bytes from `in`.
+    // Callers holding untrusted input must call trc_container_check(buf, REAL_LENGTH, ...) themselves first, as
+    // harness/trcfile.c does.
     if (trc_container_check(in, hdrsz + dir + (size_t)h.payload, codec, outlen)) return 0;
     if (is_static(codec)) {
         if (cdfnum <= 0) cdfnum = host_cdfnum(cdf);
@@ -728,7 +755,7 @@ static size_t host_decode(int codec, const unsigned char *in, size_t outlen, uns
         const size_t c0 = sc[i], nc = sc[i + 1] - c0, pl = pstart[i + 1] - pstart[i];
         if (i >= TRC_NSLOT && hipEventSynchronize(c.ev_in[k]) != hipSuccess) return false;
         memcpy(c.pin_in[k], in + hdrsz + 4 * c0, 4 * nc);
-        CopyPool::get(0).copy(c.pin_in[k] + 4 * per, in + hdrsz + dir + pstart[i], pl);
+        c.pool_in->copy(c.pin_in[k] + 4 * per, in + hdrsz + dir + pstart[i], pl);
         // (payload offsets may be odd only for corrupt directories; the device layer wants 2-byte alignment: keep the slice's own offset even)
         if (hipMemcpyAsync(d_clen + c0, c.pin_in[k], 4 * nc, hipMemcpyHostToDevice, c.s_in) != hipSuccess) return false;
         if (hipMemcpyAsync(d_payload + ((pstart[i] + 1) & ~(size_t)1) + 2 * i, c.pin_in[k] + 4 * per, pl, hipMemcpyHostToDevice, c.s_in) != hipSuccess) return false;
@@ -739,7 +766,7 @@ static size_t host_decode(int codec, const unsigned char *in, size_t outlen, uns
         if (!p.live) return true;
         const int k = (int)(p.i % TRC_NSLOT);
         if (hipEventSynchronize(c.ev_out[k]) != hipSuccess) return false;
-        CopyPool::get(1).start(out + slice_off(p.i), c.pin_out[k], slice_len(p.i));
+        c.pool_out->start(out + slice_off(p.i), c.pin_out[k], slice_len(p.i));
         p.live = false;
         return true;
     };
@@ -762,8 +789,9 @@ static size_t host_decode(int codec, const unsigned char *in, size_t outlen, uns
         pend = { i, true };
     }
     if (!fetch(pend)) { fail(TRC_E_HIP, "host decode: fetch failed"); return 0; }
-    CopyPool::get(1).wait();
+    c.pool_out->wait();
     HCHK(hipStreamSynchronize(c.s_in));
+    guard.ok = true;
     return outlen;
 }
 
