@@ -204,6 +204,27 @@ def test_host_pointer_layer(torch_cuda, codec):
         trc.lib().trc_set_chunk(1024)
 
 
+def test_static_rans_buckets_with_many_symbols(torch_cuda):
+    """the static rANS decoder reads ONE table entry per symbol, over buckets of 8 slots; buckets that hold three or more
+    symbols -- runs of low-frequency symbols -- take a second route (flag -> 1 KiB LUT row -> symbol table).  Real data
+    seldom lands there, so this input is built to: a dominant symbol plus PRESENT rare symbols that sit next to each other
+    in the alphabet (frequencies 1-3 of 32768), in every lane of a wave and at every position of a chunk."""
+    rng = np.random.default_rng(77)
+    for n, chunk, nrare in ((200000, 512, 40), (70001, 1024, 200), (4099, 256, 255)):
+        d = np.full(n, 65, dtype=np.uint8)
+        rare = np.arange(256 - nrare, 256, dtype=np.uint8) if nrare < 255 else np.array([x for x in range(256) if x != 65], dtype=np.uint8)
+        pos = rng.choice(n, size=min(n // 6, 12 * rare.size), replace=False)
+        d[pos] = rng.choice(rare, size=pos.size)
+        _, cdf, cdfnum = T.orc_cdfini(d)
+        f = np.diff(cdf[:cdfnum + 1].astype(np.int64))
+        lut = np.searchsorted(cdf[1:cdfnum + 1].astype(np.int64), np.arange(32768), side="right").reshape(4096, 8)
+        many = (lut[:, 7] - lut[:, 0]) >= 2
+        present = np.zeros(256, bool); present[np.unique(d)] = True
+        assert many.any() and present[lut[many].ravel()].any(), "the input must put present symbols into buckets of 3+ symbols"
+        assert f.min() >= 1
+        device_roundtrip(torch_cuda, trc.ANS4S, d, chunk, cdf, cdfnum)
+
+
 def test_host_pointer_layer_is_thread_safe(torch_cuda):
     """host-pointer calls from several threads at once.  Calls on one device serialise on the device
     context's lock and use that context's own copy-thread pools (round 2 had process-wide pools behind per-device locks);

@@ -95,7 +95,54 @@ __device__ __forceinline__ u32 trc_quad_xor1(u32 v) { return (u32)__builtin_amdg
 __device__ __forceinline__ u32 trc_quad_xor2(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false); }
 // 4x4 transpose of uint4 blocks inside every quad of lanes: afterwards m[j] of lane i is what m[i] of lane
 // (quad base + j) held (an involution, used in both directions).
+// Round 3: the DPP lane swap folded into the select (v_cndmask_b32_dpp: D = VCC ? src1 : quad_perm(src0)) -- one VALU per
+// dword and stage, 32 per 64 bytes, where the C form below costs 64 (select the word to send, v_mov_dpp, two selects).
+// VCC holds the lane-parity mask of the half-stage; four half-stages, each one asm block over the four columns.  A DPP
+// source must have been written at least two instructions earlier and the compiler cannot see DPP inside an asm block:
+// every block starts with s_mov vcc + s_nop.
+#ifndef TRC_QUAD_DPP
+#define TRC_QUAD_DPP 1
+#endif
+#define TRC_QT_HALF(PERM, MASK, D0, D1, D2, D3, D4, D5, D6, D7, S0, T0, S1, T1, S2, T2, S3, T3, S4, T4, S5, T5, S6, T6, S7, T7)      \
+    asm volatile("s_mov_b64 vcc, %[mk]\n\ts_nop 0\n\t"                                                                              \
+        "v_cndmask_b32_dpp %[d0], %[s0], %[t0], vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                                        \
+        "v_cndmask_b32_dpp %[d1], %[s1], %[t1], vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                                        \
+        "v_cndmask_b32_dpp %[d2], %[s2], %[t2], vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                                        \
+        "v_cndmask_b32_dpp %[d3], %[s3], %[t3], vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                                        \
+        "v_cndmask_b32_dpp %[d4], %[s4], %[t4], vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                                        \
+        "v_cndmask_b32_dpp %[d5], %[s5], %[t5], vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                                        \
+        "v_cndmask_b32_dpp %[d6], %[s6], %[t6], vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                                        \
+        "v_cndmask_b32_dpp %[d7], %[s7], %[t7], vcc " PERM " row_mask:0xf bank_mask:0xf"                                             \
+        : [d0] "=&v"(D0), [d1] "=&v"(D1), [d2] "=&v"(D2), [d3] "=&v"(D3), [d4] "=&v"(D4), [d5] "=&v"(D5), [d6] "=&v"(D6), [d7] "=&v"(D7) \
+        : [mk] "s"(MASK), [s0] "v"(S0), [t0] "v"(T0), [s1] "v"(S1), [t1] "v"(T1), [s2] "v"(S2), [t2] "v"(T2), [s3] "v"(S3), [t3] "v"(T3), \
+          [s4] "v"(S4), [t4] "v"(T4), [s5] "v"(S5), [t5] "v"(T5), [s6] "v"(S6), [t6] "v"(T6), [s7] "v"(S7), [t7] "v"(T7) : "vcc")
+__device__ __forceinline__ void trc_quad_transpose_dpp(u32 (&m)[4][4])
+{
+    const u64 even = 0x5555555555555555ull, odd = 0xAAAAAAAAAAAAAAAAull, lo2 = 0x3333333333333333ull, hi2 = 0xCCCCCCCCCCCCCCCCull;
+    u32 a[4][4];
+    // stage 1, lane ^ 1: even lanes keep m[k] and take the partner's m[k] as m[k+1]; odd lanes take the partner's m[k+1] as m[k]
+    //   new m[k]   = even ? m[k]   : dpp(m[k+1])        (k = 0, 2)
+    //   new m[k+1] = odd  ? m[k+1] : dpp(m[k])
+    TRC_QT_HALF("quad_perm:[1,0,3,2]", even, a[0][0], a[0][1], a[0][2], a[0][3], a[2][0], a[2][1], a[2][2], a[2][3],
+                m[1][0], m[0][0], m[1][1], m[0][1], m[1][2], m[0][2], m[1][3], m[0][3], m[3][0], m[2][0], m[3][1], m[2][1], m[3][2], m[2][2], m[3][3], m[2][3]);
+    TRC_QT_HALF("quad_perm:[1,0,3,2]", odd, a[1][0], a[1][1], a[1][2], a[1][3], a[3][0], a[3][1], a[3][2], a[3][3],
+                m[0][0], m[1][0], m[0][1], m[1][1], m[0][2], m[1][2], m[0][3], m[1][3], m[2][0], m[3][0], m[2][1], m[3][1], m[2][2], m[3][2], m[2][3], m[3][3]);
+    // stage 2, lane ^ 2 on (k, k+2), k = 0, 1
+    TRC_QT_HALF("quad_perm:[2,3,0,1]", lo2, m[0][0], m[0][1], m[0][2], m[0][3], m[1][0], m[1][1], m[1][2], m[1][3],
+                a[2][0], a[0][0], a[2][1], a[0][1], a[2][2], a[0][2], a[2][3], a[0][3], a[3][0], a[1][0], a[3][1], a[1][1], a[3][2], a[1][2], a[3][3], a[1][3]);
+    TRC_QT_HALF("quad_perm:[2,3,0,1]", hi2, m[2][0], m[2][1], m[2][2], m[2][3], m[3][0], m[3][1], m[3][2], m[3][3],
+                a[0][0], a[2][0], a[0][1], a[2][1], a[0][2], a[2][2], a[0][3], a[2][3], a[1][0], a[3][0], a[1][1], a[3][1], a[1][2], a[3][2], a[1][3], a[3][3]);
+}
+__device__ __forceinline__ void trc_quad_transpose_c(u32 (&m)[4][4]);
 __device__ __forceinline__ void trc_quad_transpose(u32 (&m)[4][4])
+{
+#if TRC_QUAD_DPP
+    trc_quad_transpose_dpp(m);
+#else
+    trc_quad_transpose_c(m);
+#endif
+}
+__device__ __forceinline__ void trc_quad_transpose_c(u32 (&m)[4][4])
 {
     const u32 lane = trc_lane();
     const bool b0 = lane & 1u, b1 = lane & 2u;
@@ -288,7 +335,17 @@ struct StreamOut {
 // with ~32 symbols of work.  A lane asks for its next segment as soon as its ring has room
 // (avail + in-flight <= 64), i.e. long before it runs dry; if a lane nevertheless gets low
 // (adversarial data: every symbol renormalising) the caller falls back to sync_refill().
-struct StreamIn {
+// IL = false: lane-major rows of 132 bytes (trc_raddr).  IL = true (round 3, static rANS decoder): dword d of every lane's ring
+// in row d (row = 64 lanes x 4 B = 256 B): a wave's accesses to its rings then never conflict, whatever the lanes' cursors
+// are (bank = lane), against ~3.4 cycles per 32-lane group for the drifted cursors of the lane-major form.  Row 32 (lane-major:
+// the row's 4 pad bytes) mirrors the ring's first dword, so a reader may take the dword behind its cursor and the next one
+// from one address without wrapping.  Both forms take 8448 bytes per wave.
+template <bool IL>
+struct StreamInT {
+    static __device__ __forceinline__ u32 ra(u32 lane, u32 off)
+    {
+        return IL ? ((off >> 2) << 8) + (lane << 2) + (off & 3u) : trc_raddr(lane, off);
+    }
     u8 *rings;           // this wave's ring array (LDS)
     u8 *sel;
     const u8 *gbase;     // payload base (kernel argument: keeps the loads in the global address space)
@@ -304,8 +361,8 @@ struct StreamIn {
     // helper side: this lane moves one 16-byte piece of some lane's segment, per register set
     uint4 hvA, hvB; u32 hdA, hdB; bool hokA, hokB;
 
-    __device__ __forceinline__ u32 peek16() const { return *(const u16 *)(rings + trc_raddr(trc_lane(), rpos & (TRC_SRING - 1))); }
-    __device__ __forceinline__ u32 peek32() const { return *(const u32 *)(rings + trc_raddr(trc_lane(), rpos & (TRC_SRING - 1))); }
+    __device__ __forceinline__ u32 peek16() const { return *(const u16 *)(rings + ra(trc_lane(), rpos & (TRC_SRING - 1))); }
+    __device__ __forceinline__ u32 peek32() const { return *(const u32 *)(rings + ra(trc_lane(), rpos & (TRC_SRING - 1))); }
     __device__ __forceinline__ u32 avail() const { return lbytes - rpos; }
     __device__ __forceinline__ void skip_if(bool take) { rpos += take ? 4u : 0u; }
 
@@ -325,9 +382,12 @@ struct StreamIn {
             for (int i = 0; i < 8; i++) v[i] = trc_ld16_a2(gbase + soff + 16 * i);
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                *(u32 *)(rings + trc_raddr(trc_lane(), 16u * i)) = v[i].x;      *(u32 *)(rings + trc_raddr(trc_lane(), 16u * i + 4u)) = v[i].y;
-                *(u32 *)(rings + trc_raddr(trc_lane(), 16u * i + 8u)) = v[i].z; *(u32 *)(rings + trc_raddr(trc_lane(), 16u * i + 12u)) = v[i].w;
+                *(u32 *)(rings + ra(trc_lane(), 16u * i)) = v[i].x;      *(u32 *)(rings + ra(trc_lane(), 16u * i + 4u)) = v[i].y;
+                *(u32 *)(rings + ra(trc_lane(), 16u * i + 8u)) = v[i].z; *(u32 *)(rings + ra(trc_lane(), 16u * i + 12u)) = v[i].w;
             }
+#ifndef TRC_RING_INTERLEAVED
+            *(u32 *)(rings + ra(trc_lane(), TRC_SRING)) = v[0].x;          // guard (see put_piece)
+#endif
             lbytes = TRC_SRING;
         }
     }
@@ -335,8 +395,11 @@ struct StreamIn {
     __device__ __forceinline__ void put_piece(u32 hd, uint4 v)
     {
         const u32 j = hd >> 8, o = hd & 0xffu;
-        *(u32 *)(rings + trc_raddr(j, o)) = v.x;      *(u32 *)(rings + trc_raddr(j, o + 4u)) = v.y;
-        *(u32 *)(rings + trc_raddr(j, o + 8u)) = v.z; *(u32 *)(rings + trc_raddr(j, o + 12u)) = v.w;
+        *(u32 *)(rings + ra(j, o)) = v.x;      *(u32 *)(rings + ra(j, o + 4u)) = v.y;
+        *(u32 *)(rings + ra(j, o + 8u)) = v.z; *(u32 *)(rings + ra(j, o + 12u)) = v.w;
+#ifndef TRC_RING_INTERLEAVED
+        if (o == 0u) *(u32 *)(rings + ra(j, TRC_SRING)) = v.x;          // guard: mirrors the ring's first bytes, so a reader may take
+#endif                                                                  // what lies at ring offset p and just behind it from one address
     }
     // land the round that travels in set `par` (requested two periods ago)
     __device__ __forceinline__ void commit(int par)
@@ -395,3 +458,4 @@ struct StreamIn {
         refill(alive, par);
     }
 };
+typedef StreamInT<false> StreamIn;
