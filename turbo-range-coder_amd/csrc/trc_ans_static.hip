@@ -10,7 +10,7 @@
 // inside one (that would change the bitstream).
 //
 // MI355X mapping: symbol tables in LDS (encoder: 256 x 16 B {reciprocal, 2^15-f | shift<<24,
-// f<<16, c0}; decoder: 32 KiB bucket table, one read per symbol, + 3 KiB for the rare buckets); all HBM traffic in 64-byte
+// f<<16, c0}; decoder: 32 KiB slot->symbol LUT + 256 x 8 B {f, -c0}); all HBM traffic in 64-byte
 // quad segments through the LDS tiles/rings of trc_io.h.  No MFMA: integer work, bounded by VALU
 // issue (4 cycles per wave64 op) and LDS, not by HBM (DESIGN.md has the arithmetic).
 #include <stdlib.h>
@@ -19,6 +19,12 @@
 
 #define ENC_WAVE_LDS (TRC_SRING_BYTES + TRC_SEL_BYTES)       // input arrives through an in-register quad transpose
 #define DEC_WAVE_LDS (TRC_SRING_BYTES + TRC_SEL_BYTES)       // 8.3 KiB: 12 waves + 34 KiB of tables fit one CU
+#ifndef TRC_DEC_LATE_FLUSH
+#define TRC_DEC_LATE_FLUSH 1    // decoder: a segment's output stores behind the next period's commit (0: before it, as in round 2)
+#endif
+#ifndef TRC_ENC_EARLY_COMMIT
+#define TRC_ENC_EARLY_COMMIT 1  // encoder: the next input segment lands before the current segment's last drain (0: after it, as in round 2)
+#endif
 #ifndef TRC_ENC_REP_DEFAULT
 #define TRC_ENC_REP_DEFAULT 1
 #endif
@@ -157,12 +163,21 @@ __global__ __launch_bounds__(BLOCK) void trc_ans4s_enc_kernel(
 
     // both halves of a 128-byte line are requested together (QuadIn, paired mode)
     if ((S - 1u) & 1u) { tin.issue_slot<1>(wc, S - 1u); tin.issue_slot<0>(wc, S - 2u); } else tin.issue_slot<0>(wc, S - 1u);
-    for (u32 s = S - 1u;; s--) {
-        if (s & 1u) tin.commit_slot<1>(); else tin.commit_slot<0>();
-        if (!(s & 1u) && s >= 1u) {                             // the next line down: in flight during this segment (and the next)
-            tin.issue_slot<1>(wc, s - 1u);
-            if (s >= 2u) tin.issue_slot<0>(wc, s - 2u);
+    // land segment sn (its registers become `p`) and request the line below it.  The compiler guards the landing with
+    // s_waitcnt vmcnt(0), and on gfx950 stores count in vmcnt: done at the top of a segment (round 2) it sat out the latency
+    // of the drain stores issued just before; it now runs BEFORE the last drain of the segment above (TRC_ENC_EARLY_COMMIT).
+    auto take = [&](u32 sn) {
+        if (sn & 1u) tin.commit_slot<1>(); else tin.commit_slot<0>();
+        if (!(sn & 1u) && sn >= 1u) {                           // the next line down: in flight during this segment (and the next)
+            tin.issue_slot<1>(wc, sn - 1u);
+            if (sn >= 2u) tin.issue_slot<0>(wc, sn - 2u);
         }
+    };
+    take(S - 1u);
+    for (u32 s = S - 1u;; s--) {
+#if !TRC_ENC_EARLY_COMMIT
+        if (s != S - 1u) take(s);
+#endif
         bool act = alive && s <= top && !ovf;
         const bool ragged = act && s == top && toplen != TRC_SEG;
         if (ragged) {                                           // last chunk only: byte by byte
@@ -201,6 +216,9 @@ __global__ __launch_bounds__(BLOCK) void trc_ans4s_enc_kernel(
                 so.wpos = (~wn) << 1;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the ring writes above are not in the compiler's books
+#if TRC_ENC_EARLY_COMMIT
+            if (k == 0 && s > 0) take(s - 1u);                  // (this segment's last piece has been read)
+#endif
             so.drain(false, alive);                             // <= 32 new bytes per lane since the last drain
             ovf = ovf || (alive && so.wpos + 8u >= len);        // already incompressible: stop coding this chunk
             act = act && !ovf;
@@ -224,64 +242,47 @@ __global__ __launch_bounds__(BLOCK) void trc_ans4s_enc_kernel(
 
 // ------------------------------------------------------------------------------------- decode ---
 // cdf16sansdec + ecdnorm (cdf_.h:99-107, anscdf_.h:51-73) for a byte alphabet:
-//     x = symbol of slot (st & 0x7fff);  st = f * (st >> 15) + slot - c0;  if (st < 2^15) st = st << 16 | next word
+//     x = lut[slot = st & 0x7fff];  st = f * (st >> 15) + slot - c0;  if (st < 2^15) st = st << 16 | next word
+// with a 32 KiB slot -> symbol LUT and a 256-entry {f, -c0} table in LDS.
 //
-// Round 3.  Rounds 1-2 looked the symbol up in a 32 KiB slot -> symbol LUT and then its {f, -c0} in a 256-entry table: two
-// DEPENDENT random LDS reads per symbol.  PMC showed the kernel bound by neither pipe -- three rewrites that removed 17 % of
-// the VALU instructions, half of the transposes and 28 % of the LDS conflict cycles changed its time by nothing
-// (profiles/r03_notes.md): at 100 MB / chunk 512 every one of the 390 000 state chains is resident from the first cycle and
-// the kernel lasts as long as ONE chain of 256 steps, i.e. 256 x the latency of a step.  So the step was made shorter:
-//   * ONE table read per symbol: a 4096-entry table over buckets of 8 slots (trc_dir.hip: `bkt`) holds both frequencies, the
-//     lower symbol's offset and the boundary of the at most two symbols a bucket normally straddles; the few buckets with
-//     three or more symbols (runs of frequency-1 symbols, i.e. bytes the data does not contain) are flagged and take the old
-//     two-read route through a 1 KiB LUT of their own, behind a wave-uniform test that real data hardly ever passes;
-//   * symbols are decoded in PAIRS (one per state); the two ring units a pair can consume are requested up front -- from the
-//     INTERLEAVED ring (StreamInT<true>: dword d of every lane in row d, conflict-free whatever the cursors are; row 32
-//     mirrors row 0): the dword behind the cursor and the next one from one address, funnel-shifted by the cursor's parity --
-//     so the second symbol's word does not wait for the first symbol's renormalisation;
-//   * the renormalisation of a pair is one hand-scheduled block of 9 VALU: compares into VCC / an SGPR pair, candidates
-//     `state << 16 | unit` as byte permutes of the state and the 32-bit window, selects, the halfword cursor advanced by the
-//     carries (v_addc); the two symbols' instructions interleaved so that the two wait states a VALU-written mask needs on
-//     gfx950 are filled with work.
+// Round 3 (profiles/r03_notes.md has the counters of every step):
+//   * symbols are decoded in PAIRS (one per state) on integer LDS addresses: the LUT sits at LDS offset 0, so its read needs no
+//     address arithmetic (through generic pointers the compiler added the zero segment base with a v_add per read); the table
+//     read folds its base into the offset field;
+//   * the two ring units a pair can consume are requested up front from the INTERLEAVED ring (StreamInT<true>: dword d of
+//     every lane in row d, conflict-free whatever the cursors are; row 32 mirrors row 0): the dword behind the cursor and the
+//     next one from one address, funnel-shifted by the cursor's parity -- the second symbol's word no longer waits for the
+//     first symbol's renormalisation compare, cursor arithmetic and LDS round trip;
+//   * the renormalisation of a pair is one hand-scheduled block of 9 VALU (the compiler's form of the same selects: 14):
+//     compares into VCC / an SGPR pair, candidates `state << 16 | unit` as byte permutes of the state and the 32-bit window,
+//     selects, the halfword cursor advanced by the carries (v_addc); the two symbols' instructions interleaved so that the two
+//     wait states a VALU-written mask needs on gfx950 are filled with work;
+//   * the output segment of 64 symbols leaves (QuadOut::flush) AFTER the next period's commit instead of before it: the
+//     compiler guards the commit's use of the refill registers with s_waitcnt vmcnt(0), and on gfx950 stores count in vmcnt --
+//     every segment the wave sat out the full latency of the stores it had just issued.
+// A variant with ONE table read per symbol (a 4096-entry table over buckets of 8 slots holding both symbols a bucket can
+// straddle, flagged buckets taking the two-read route) is bit-exact and 43 % SLOWER (96 against 67 us: 16 more VALU per pair
+// make the kernel issue-bound): commit 341b467, numbers in profiles/r03_notes.md.
 typedef u32 trc_v2u __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) trc_v2u trc_lds_u64;
 typedef __attribute__((address_space(3))) u32 trc_lds_u32;
 typedef StreamInT<true> AnsStreamIn;
-#define DEC_LDS_BKT   0u          // uint2[4096]
+#define DEC_LDS_LUT   0u          // u8[32768]
 #define DEC_LDS_DTAB  32768u      // uint2[256]  { f, -c0 }
-#define DEC_LDS_LUT2  34816u      // u8[128][8]
-#define DEC_LDS_WAVES 35840u
+#define DEC_LDS_WAVES 34816u
 
-// everything the step needs about slot `sl`: symbol, frequency, sl - cdf[symbol]
-struct AnsSym { u32 x, f, d, flag; };
-__device__ __forceinline__ AnsSym ans_sym(u32 sl)
-{
-    const u32 r = sl & 7u;
-    const trc_v2u e = *(const trc_lds_u64 *)(uintptr_t)(DEC_LDS_BKT + (sl & 0x7ff8u));
-    const u32 dt = (e.y >> 16) & 15u;
-    const bool lo = r < dt;
-    AnsSym y;
-    y.f = lo ? (e.x & 0xffffu) : (e.x >> 16);
-    y.d = lo ? r + (e.y & 0x7fffu) : r - dt;
-    y.x = (e.y >> 23) - (lo ? 1u : 0u);
-    y.flag = e.y & 0x8000u;
-    if (__builtin_expect(__ballot(y.flag) != 0, 0)) {            // some lane's bucket holds 3+ symbols
-        const u32 x2 = *(const trc_lds_u8 *)(uintptr_t)(DEC_LDS_LUT2 + ((y.flag ? e.x & 127u : 0u) << 3) + r);
-        const trc_v2u g = *(const trc_lds_u64 *)(uintptr_t)(DEC_LDS_DTAB + (x2 << 3));
-        if (y.flag) { y.x = x2; y.f = g.x; y.d = sl + g.y; }
-    }
-    return y;
-}
 // one symbol, any position (the ragged tail of the last chunk)
 __device__ __forceinline__ u32 ans_get(u32 &st, AnsStreamIn &si)
 {
-    const AnsSym y = ans_sym(st & (TRC_PROB_ONE - 1));
-    st = __umul24(y.f, st >> TRC_PROB_BITS) + y.d;
+    const u32 slot = st & (TRC_PROB_ONE - 1);
+    const u32 x = *(const trc_lds_u8 *)(uintptr_t)(DEC_LDS_LUT + slot);
+    const trc_v2u e = *(const trc_lds_u64 *)(uintptr_t)(DEC_LDS_DTAB + (x << 3));
+    st = __umul24(e.x, st >> TRC_PROB_BITS) + e.y + slot;
     const u32 w = si.peek16();
     const bool rn = st < TRC_ANS_LOW;
     st = rn ? (st << 16) | w : st;
     si.rpos += rn ? 2u : 0u;
-    return y.x;
+    return x;
 }
 // a pair of symbols, s0 first; hc = halfword cursor into the lane's ring (lbase = LDS address of its dword 0)
 __device__ __forceinline__ void ans_get_pair(u32 &s0, u32 &s1, u32 lbase, u32 &hc, u32 &x0, u32 &x1, u32 sel_lo, u32 sel_hi)
@@ -290,25 +291,13 @@ __device__ __forceinline__ void ans_get_pair(u32 &s0, u32 &s1, u32 lbase, u32 &h
     asm("v_bfe_u32 %0, %1, 1, 5\n\tv_lshl_add_u32 %0, %0, 8, %2" : "=&v"(a) : "v"(hc), "v"(lbase));
     const u32 dw0 = *(const trc_lds_u32 *)(uintptr_t)a;
     const u32 dw1 = *(const trc_lds_u32 *)(uintptr_t)(a + 256u);
-    const u32 sl0 = s0 & (TRC_PROB_ONE - 1), sl1 = s1 & (TRC_PROB_ONE - 1), r0 = sl0 & 7u, r1 = sl1 & 7u;
-    const trc_v2u e0 = *(const trc_lds_u64 *)(uintptr_t)(DEC_LDS_BKT + (sl0 & 0x7ff8u));
-    const trc_v2u e1 = *(const trc_lds_u64 *)(uintptr_t)(DEC_LDS_BKT + (sl1 & 0x7ff8u));
-    const u32 dt0 = (e0.y >> 16) & 15u, dt1 = (e1.y >> 16) & 15u;
-    const bool lo0 = r0 < dt0, lo1 = r1 < dt1;
-    u32 f0 = lo0 ? (e0.x & 0xffffu) : (e0.x >> 16), f1 = lo1 ? (e1.x & 0xffffu) : (e1.x >> 16);
-    u32 d0 = lo0 ? r0 + (e0.y & 0x7fffu) : r0 - dt0, d1 = lo1 ? r1 + (e1.y & 0x7fffu) : r1 - dt1;
-    x0 = (e0.y >> 23) - (lo0 ? 1u : 0u); x1 = (e1.y >> 23) - (lo1 ? 1u : 0u);
-    const u32 fl0 = e0.y & 0x8000u, fl1 = e1.y & 0x8000u;
-    if (__builtin_expect(__ballot(fl0 | fl1) != 0, 0)) {          // a bucket with 3+ symbols somewhere in the wave: LUT row -> {f, -c0}
-        const u32 y0 = *(const trc_lds_u8 *)(uintptr_t)(DEC_LDS_LUT2 + ((fl0 ? e0.x & 127u : 0u) << 3) + r0);
-        const u32 y1 = *(const trc_lds_u8 *)(uintptr_t)(DEC_LDS_LUT2 + ((fl1 ? e1.x & 127u : 0u) << 3) + r1);
-        const trc_v2u g0 = *(const trc_lds_u64 *)(uintptr_t)(DEC_LDS_DTAB + (y0 << 3));
-        const trc_v2u g1 = *(const trc_lds_u64 *)(uintptr_t)(DEC_LDS_DTAB + (y1 << 3));
-        if (fl0) { x0 = y0; f0 = g0.x; d0 = sl0 + g0.y; }
-        if (fl1) { x1 = y1; f1 = g1.x; d1 = sl1 + g1.y; }
-    }
-    u32 t0 = __umul24(f0, s0 >> TRC_PROB_BITS) + d0;
-    u32 t1 = __umul24(f1, s1 >> TRC_PROB_BITS) + d1;
+    const u32 sl0 = s0 & (TRC_PROB_ONE - 1), sl1 = s1 & (TRC_PROB_ONE - 1);
+    x0 = *(const trc_lds_u8 *)(uintptr_t)(DEC_LDS_LUT + sl0);
+    x1 = *(const trc_lds_u8 *)(uintptr_t)(DEC_LDS_LUT + sl1);
+    const trc_v2u e0 = *(const trc_lds_u64 *)(uintptr_t)(DEC_LDS_DTAB + (x0 << 3));
+    const trc_v2u e1 = *(const trc_lds_u64 *)(uintptr_t)(DEC_LDS_DTAB + (x1 << 3));
+    u32 t0 = __umul24(e0.x, s0 >> TRC_PROB_BITS) + e0.y + sl0;
+    u32 t1 = __umul24(e1.x, s1 >> TRC_PROB_BITS) + e1.y + sl1;
     const u32 w32 = __builtin_amdgcn_alignbit(dw1, dw0, hc << 4);                        // units hc, hc + 1 (the shift uses 5 bits: 16 x parity)
     u32 c0, c1, sl;
     u64 m1, cy;
@@ -329,7 +318,7 @@ __device__ __forceinline__ void ans_get_pair(u32 &s0, u32 &s1, u32 lbase, u32 &h
 __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
     const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
     u64 n, u32 chunk, u32 nchunks,
-    const u8 *__restrict__ bkt_g, const u8 *__restrict__ lut2_g, const u32 *__restrict__ dtab_g, u8 *__restrict__ out)
+    const u8 *__restrict__ lut_g, const u32 *__restrict__ dtab_g, u8 *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, BLOCK = blockDim.x;
@@ -342,24 +331,21 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
     const bool alive = lane < wc.rows;
     const u32 c = wc.c0 + lane;
     const u32 len = alive ? wc.len_of(lane) : 0u;
-    // the table fill as one batch of loads (a plain copy loop waits for each of its loads before it issues the next:
+    // the table fill as one batch of loads (a plain copy loop waits for each of its three loads before it issues the next:
     // 75.9 -> 73.6 us for 100 MB in round 2)
     {
         uint2 *dtab = (uint2 *)(smem + DEC_LDS_DTAB);
         if (BLOCK >= 704u) {
-            uint4 t0 = make_uint4(0, 0, 0, 0), t1 = t0, t2 = t0, t3 = t0; u32 td = 0;
-            t0 = ((const uint4 *)bkt_g)[tid];
-            t1 = ((const uint4 *)bkt_g)[tid + BLOCK];
-            if (tid + 2u * BLOCK < 2048u) t2 = ((const uint4 *)bkt_g)[tid + 2u * BLOCK];
-            if (tid < 64u) t3 = ((const uint4 *)lut2_g)[tid];
+            uint4 t0 = make_uint4(0, 0, 0, 0), t1 = t0, t2 = t0; u32 td = 0;
+            t0 = ((const uint4 *)lut_g)[tid];
+            t1 = ((const uint4 *)lut_g)[tid + BLOCK];
+            if (tid + 2u * BLOCK < 2048u) t2 = ((const uint4 *)lut_g)[tid + 2u * BLOCK];
             if (tid < 256u) td = dtab_g[tid];
             ((uint4 *)smem)[tid] = t0; ((uint4 *)smem)[tid + BLOCK] = t1;
             if (tid + 2u * BLOCK < 2048u) ((uint4 *)smem)[tid + 2u * BLOCK] = t2;
-            if (tid < 64u) ((uint4 *)(smem + DEC_LDS_LUT2))[tid] = t3;
             if (tid < 256u) dtab[tid] = make_uint2(td >> 16, 0u - (td & 0xffffu));
         } else {
-            for (u32 i = tid; i < 2048; i += BLOCK) ((uint4 *)smem)[i] = ((const uint4 *)bkt_g)[i];
-            for (u32 i = tid; i < 64; i += BLOCK) ((uint4 *)(smem + DEC_LDS_LUT2))[i] = ((const uint4 *)lut2_g)[i];
+            for (u32 i = tid; i < 2048; i += BLOCK) ((uint4 *)smem)[i] = ((const uint4 *)lut_g)[i];
             for (u32 i = tid; i < 256; i += BLOCK) { const u32 d = dtab_g[i]; dtab[i] = make_uint2(d >> 16, 0u - (d & 0xffffu)); }
         }
     }
@@ -377,7 +363,11 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
     si.gbase = payload; si.soff = off + 8; si.lim = trc_sub_sat(cl, 8u);   // words follow the two states
     u32 sa = 0, sb = 0;
     if (coded) { sa = trc_ld32_a2(payload + off); sb = trc_ld32_a2(payload + off + 4); }   // sa = enc state 1, sb = enc state 0
+#ifdef TRC_DEC_ABL_NOPRIME                                      // timing ablations (results wrong by construction; scripts/gpu_ablate.sh)
+    si.prime(false); si.lbytes = coded ? TRC_SRING : 0u;
+#else
     si.prime(coded);
+#endif
 
     const u32 S = chunk / TRC_SEG;
     const u32 body4 = len & ~3u;
@@ -390,12 +380,24 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
         for (int k = 0; k < 4; k++) {
             const u32 p0 = s * TRC_SEG + (u32)k * 16u;          // chunk offset of this 16-byte piece
             // period boundary: land the round requested 16 symbols ago, request the next one
+#ifdef TRC_DEC_ABL_NOPERIOD
+            si.lbytes = si.rpos + TRC_SRING;
+#else
             si.period(coded && p0 < len, k & 1);
+#endif
+#if TRC_DEC_LATE_FLUSH && !defined(TRC_DEC_ABL_NOFLUSH)
+            if (k == 0 && s > 0) tout.flush(wc, (s - 1u) * TRC_SEG);   // the segment before: behind this period's commit (header comment)
+#endif
             if (coded && p0 + 16u <= len) {
                 u32 w[4];
                 u32 hc = si.rpos >> 1;
+#ifdef TRC_DEC_ABL_NOSYMS
+                w[0] = sa; w[1] = sb; w[2] = hc; w[3] = p0; hc += 5;
+                for (int d = 0; d < 0; d++) {
+#else
 #pragma unroll
                 for (int d = 0; d < 4; d++) {
+#endif
                     u32 x0, x1, x2, x3;
                     ans_get_pair(sb, sa, rbase, hc, x0, x1, sel_lo, sel_hi);
                     ans_get_pair(sb, sa, rbase, hc, x2, x3, sel_lo, sel_hi);
@@ -408,8 +410,13 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
                     dst[pos] = (u8)((pos >= body4 || !(pos & 1u)) ? ans_get(sb, si) : ans_get(sa, si));
             }
         }
+#if !TRC_DEC_LATE_FLUSH
         tout.flush(wc, s * TRC_SEG);
+#endif
     }
+#if TRC_DEC_LATE_FLUSH
+    tout.flush(wc, (S - 1u) * TRC_SEG);
+#endif
     // chunks stored raw (clen == len): the whole wave copies them, one after the other
     trc_wave_copy_raw(__ballot(alive && cl == len && len != 0), off, len, out + (u64)wc.c0 * chunk, chunk, payload);
 }
@@ -453,16 +460,16 @@ void trc_launch_ans4s_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const T
 void trc_launch_ans4s_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                           const TrcWork &w, uint8_t *d_out, hipStream_t s)
 {
-    const u8 *bkt = w.tables + TRC_TAB_BKT, *lut2 = w.tables + TRC_TAB_LUT2;
+    const u8 *lut = w.tables + TRC_TAB_LUT;
     const u32 *dtab = (const u32 *)(w.tables + TRC_TAB_DEC);
     const u32 nwaves = w.ngroups;
     TRC_RAISE_LDS_ONCE(trc_ans4s_dec_kernel, DEC_LDS_WAVES + 14 * DEC_WAVE_LDS);
     // the 34 KiB of tables are per workgroup, so waves share a workgroup -- but no more than it takes to
     // give every one of the 256 CUs a workgroup (1526 waves: 6 per workgroup -> 255 workgroups); up to 14 fit
     u32 wpb = (nwaves + 255u) / 256u;
-    wpb = wpb < 1u ? 1u : wpb > 14u ? 14u : wpb;               // 35 KiB + 14 x 8.3 KiB = 151 KiB of the CU's 160
+    wpb = wpb < 1u ? 1u : wpb > 14u ? 14u : wpb;               // 34 KiB + 14 x 8.3 KiB = 150 KiB of the CU's 160
     if (const char *e = getenv("TRC_DEC_WPB")) { const u32 v = (u32)atoi(e); if (v >= 1 && v <= 14) wpb = v; }   // tuning aid
     const size_t sm = DEC_LDS_WAVES + wpb * DEC_WAVE_LDS;
     TRC_LAUNCH_TIMED(trc_ans4s_dec_kernel, dim3((nwaves + wpb - 1) / wpb), dim3(64 * wpb), sm, s,
-                       d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, bkt, lut2, dtab, d_out);
+                       d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, lut, dtab, d_out);
 }

@@ -9,15 +9,6 @@
 //            (m = floor(2^(31+l)/f) + 1, l = ceil(log2 f): exact round-up reciprocal; f = 1 special-cased)
 //   dec[x] = f<<16 | c0
 //   lut[s] = largest x with cdf[x] <= s            (replaces the reference's per-symbol CDF search)
-//   bkt[b] = static rANS decoder, ONE lookup per symbol (round 3): everything the step needs for the 8 slots 8b .. 8b+7.
-//            A bucket lies inside one symbol or straddles ONE boundary in all but a few buckets (text: 4069 of 4096), so
-//            .x = fL | fH << 16                                   frequencies of the lower / upper symbol
-//            .y = (8b - cdf[xL]) | flag << 15 | dt << 16 | (xL + 1) << 23      dt = boundary's offset in the bucket (8: none)
-//            slot s, r = s & 7:  r < dt -> symbol xL, s - cdf[xL] = r + (8b - cdf[xL]);  else xL + 1, s - cdf[xL + 1] = r - dt.
-//            flag: the bucket holds 3 or more symbols (runs of frequency-1 symbols: bytes that do not occur in the data, so a
-//            decoder never lands there unless a present symbol sits among them): .x = row in lut2, the step falls back to
-//            lut2[row][r] -> dec[] (two reads, as round 2 did for every symbol).  Row = (xL + 1) >> 1: two flagged buckets
-//            are at least two symbols apart, at most 127 rows.
 __global__ __launch_bounds__(256) void trc_static_prep_kernel(const u16 *__restrict__ cdf, u32 cdfnum,
                                                               u8 *__restrict__ tables)
 {
@@ -29,25 +20,6 @@ __global__ __launch_bounds__(256) void trc_static_prep_kernel(const u16 *__restr
     u32 x = 0, hi = 256;
     while (x + 1 < hi) { u32 mid = (x + hi) >> 1; if (c[mid] > slot) hi = mid; else x = mid; }
     tables[TRC_TAB_LUT + slot] = (u8)x;
-    {
-        __shared__ u32 xs[256];
-        xs[tid] = x;
-        __syncthreads();
-        const u32 xl = xs[tid & ~7u], xh = xs[tid | 7u], base = slot & ~7u;
-        const bool many = xh - xl >= 2u;
-        if (many) tables[TRC_TAB_LUT2 + ((xl + 1u) >> 1) * 8u + (tid & 7u)] = (u8)x;
-        if ((tid & 7u) == 0u) {
-            const u32 cl = c[xl], t = c[xl + 1];
-            uint2 e;
-            if (many) { e.x = (xl + 1u) >> 1; e.y = 0x8000u | (8u << 16) | ((xl + 1u) << 23); }
-            else {
-                const bool two = xh != xl;
-                e.x = (t - cl) | ((two ? c[xl + 2] - t : 0u) << 16);
-                e.y = (base - cl) | ((two ? t - base : 8u) << 16) | ((xl + 1u) << 23);
-            }
-            ((uint2 *)(tables + TRC_TAB_BKT))[slot >> 3] = e;
-        }
-    }
     if (blockIdx.x == 0) {
         const u32 c0 = c[tid], f = c[tid + 1] - c0;
         uint4 e; u32 d;

@@ -302,26 +302,34 @@ struct StreamOut {
     // Move finished segments to HBM.  Called by the whole wave at uniform points.
     // final = false: lanes holding >= 64 pending bytes;  final = true: every lane with pending bytes
     // (the partial segment is written as a whole 64 B; the surplus lands in the region's slack).
+    // Round 3: the up to 16 lanes drained in a round PUSH the LDS address of their oldest segment and its place in the scratch
+    // array (relative to the wave's first region) to the leader of helper quad `rank` with two ds_permute_b32 (lanes not
+    // picked push to lane 1, which leads no quad), and the quad takes them from its leader by DPP -- one cross-lane round
+    // trip per round where round 2 made two (rank -> lane table written to and read back from LDS, then a shuffle).
     __device__ __forceinline__ void drain(bool final, bool alive)
     {
         const u32 lane = trc_lane();
+        const u32 rw = trc_lds_addr(rings);
         bool ready = alive && (final ? pending() > 0 : pending() >= TRC_SEG);
         u64 mask = __ballot(ready);
         while (mask) {
             const u32 rank = trc_mbcnt(mask);
             const bool pick = ready && rank < 16u;
-            if (pick) sel[rank] = (u8)lane;
             const u32 cnt = (u32)__popcll(mask);
+            const u32 ro = DOWN ? ((0u - TRC_SEG * (nfl + 1u)) & (TRC_SRING - 1)) : ((TRC_SEG * nfl) & (TRC_SRING - 1));
+            const u32 from = rw + trc_raddr(lane, ro);
+            const u32 to = lane * stride + (DOWN ? stride - TRC_SEG * (nfl + 1u) : TRC_SEG * nfl);   // (63 regions of at most 64 KiB + slack: 32 bits)
+            const int dst = (int)((pick ? rank << 2 : 1u) << 2);
+            const u32 from_l = (u32)__builtin_amdgcn_ds_permute(dst, (int)from), to_l = (u32)__builtin_amdgcn_ds_permute(dst, (int)to);
+            const u32 from_q = (u32)__builtin_amdgcn_update_dpp(0, (int)from_l, 0x00, 0xf, 0xf, false);   // quad_perm [0,0,0,0]
+            const u32 to_q = (u32)__builtin_amdgcn_update_dpp(0, (int)to_l, 0x00, 0xf, 0xf, false);
             const u32 q = lane >> 2, part = (lane & 3u) << 4;
-            const u32 j = sel[q];
-            const u32 nfl_j = (u32)__shfl((int)nfl, (int)j, 64);
             if (q < cnt && q < 16u) {
-                const u32 ro = DOWN ? ((0u - TRC_SEG * (nfl_j + 1u)) & (TRC_SRING - 1)) : ((TRC_SEG * nfl_j) & (TRC_SRING - 1));
-                const u32 s0 = *(const u32 *)(rings + trc_raddr(j, ro + part)), s1 = *(const u32 *)(rings + trc_raddr(j, ro + part + 4u));
-                const u32 s2 = *(const u32 *)(rings + trc_raddr(j, ro + part + 8u)), s3 = *(const u32 *)(rings + trc_raddr(j, ro + part + 12u));
-                u8 *reg = scratch + (size_t)(c0 + j) * stride;
-                u8 *d = DOWN ? reg + stride - (size_t)TRC_SEG * (nfl_j + 1u) + part : reg + (size_t)TRC_SEG * nfl_j + part;
-                *(uint4 *)d = make_uint4(s0, s1, s2, s3);
+                typedef __attribute__((address_space(3))) u32 lds_u32;
+                const u32 a = from_q + part;
+                const u32 s0 = *(const lds_u32 *)(uintptr_t)a, s1 = *(const lds_u32 *)(uintptr_t)(a + 4u);
+                const u32 s2 = *(const lds_u32 *)(uintptr_t)(a + 8u), s3 = *(const lds_u32 *)(uintptr_t)(a + 12u);
+                *(uint4 *)(scratch + (size_t)c0 * stride + to_q + part) = make_uint4(s0, s1, s2, s3);
             }
             if (pick) { nfl++; ready = final ? (wpos > TRC_SEG * nfl) : pending() >= TRC_SEG; }
             mask = __ballot(ready);
@@ -357,6 +365,7 @@ struct StreamInT {
     u32 rpos;            // bytes consumed
     u32 lbytes;          // bytes committed to the ring
     u32 infl;            // segments requested for this lane and not yet committed (0..2)
+    u32 rw;              // (set by prime) LDS byte address of this wave's ring array
     bool mineA, mineB;   // ... and in which register set they travel
     // helper side: this lane moves one 16-byte piece of some lane's segment, per register set
     uint4 hvA, hvB; u32 hdA, hdB; bool hokA, hokB;
@@ -370,6 +379,7 @@ struct StreamInT {
     __device__ __forceinline__ void prime(bool alive)
     {
         rpos = 0; lbytes = 0; infl = 0; mineA = mineB = false; hokA = hokB = false;
+        rw = trc_lds_addr(rings);
         {
             const u32 blo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)soff), bhi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(soff >> 32));
             wbase = ((u64)bhi << 32) | blo;
@@ -385,21 +395,33 @@ struct StreamInT {
                 *(u32 *)(rings + ra(trc_lane(), 16u * i)) = v[i].x;      *(u32 *)(rings + ra(trc_lane(), 16u * i + 4u)) = v[i].y;
                 *(u32 *)(rings + ra(trc_lane(), 16u * i + 8u)) = v[i].z; *(u32 *)(rings + ra(trc_lane(), 16u * i + 12u)) = v[i].w;
             }
-#ifndef TRC_RING_INTERLEAVED
             *(u32 *)(rings + ra(trc_lane(), TRC_SRING)) = v[0].x;          // guard (see put_piece)
-#endif
-            lbytes = TRC_SRING;
+            lbytes = TRC_SRING;   // (starting odd lanes with half a ring, to spread the lanes' refill requests over the periods, measured
+                                  // 1-2 % slower at chunk 512 and 2 % faster at 1024: not kept, profiles/r03_notes.md)
         }
     }
-    // hd = lane<<8 | ring offset of the 16-byte piece
+    // Round 3: a refill round costs ONE cross-lane round trip and the landing of a piece one address operation.
+    //   * the up to 16 lanes picked in a round PUSH what their helpers need -- the source offset of the segment and the LDS
+    //     address of its ring slot -- to the leader of helper quad `rank` with two ds_permute_b32 (lanes not picked push to
+    //     lane 1, which leads no quad); the leader's values reach its quad by DPP.  Round 2 wrote the picked lanes' numbers to
+    //     an LDS table, read it back and fetched the two values with two shuffles: two dependent LDS round trips per period;
+    //   * the helper keeps the piece's final LDS address (bit 0: the piece opens the ring, its first dword is mirrored behind
+    //     the ring); landing it is four stores at constant offsets -- rows of the interleaved ring are 256 bytes apart -- where
+    //     round 2 rebuilt four addresses from (lane, offset) with some twenty VALU instructions.
+    static constexpr u32 PIECE_STEP = IL ? 1024u : 16u;        // LDS distance of consecutive 16-byte pieces of a segment
+    static constexpr u32 GUARD_OFF = IL ? 8192u : TRC_SRING;   // from a ring's first dword to its mirror
+    typedef __attribute__((address_space(3))) u32 lds_u32;
     __device__ __forceinline__ void put_piece(u32 hd, uint4 v)
     {
-        const u32 j = hd >> 8, o = hd & 0xffu;
-        *(u32 *)(rings + ra(j, o)) = v.x;      *(u32 *)(rings + ra(j, o + 4u)) = v.y;
-        *(u32 *)(rings + ra(j, o + 8u)) = v.z; *(u32 *)(rings + ra(j, o + 12u)) = v.w;
-#ifndef TRC_RING_INTERLEAVED
-        if (o == 0u) *(u32 *)(rings + ra(j, TRC_SRING)) = v.x;          // guard: mirrors the ring's first bytes, so a reader may take
-#endif                                                                  // what lies at ring offset p and just behind it from one address
+        const u32 a = hd & ~3u;
+        if (IL) {
+            *(lds_u32 *)(uintptr_t)a = v.x;          *(lds_u32 *)(uintptr_t)(a + 256u) = v.y;
+            *(lds_u32 *)(uintptr_t)(a + 512u) = v.z; *(lds_u32 *)(uintptr_t)(a + 768u) = v.w;
+        } else {
+            *(lds_u32 *)(uintptr_t)a = v.x;        *(lds_u32 *)(uintptr_t)(a + 4u) = v.y;
+            *(lds_u32 *)(uintptr_t)(a + 8u) = v.z; *(lds_u32 *)(uintptr_t)(a + 12u) = v.w;
+        }
+        if (hd & 1u) *(lds_u32 *)(uintptr_t)(a + GUARD_OFF) = v.x;   // guard: a reader may take what lies at ring offset p and just behind it from one address
     }
     // land the round that travels in set `par` (requested two periods ago)
     __device__ __forceinline__ void commit(int par)
@@ -421,19 +443,19 @@ struct StreamInT {
         if (!mask) return;
         const u32 rank = trc_mbcnt(mask);
         const bool pick = needy && rank < 16u;
-        if (pick) sel[rank] = (u8)lane;
         const u32 cnt = (u32)__popcll(mask);
-        const u32 q = lane >> 2, part = (lane & 3u) << 4;
-        const u32 j = sel[q];
         const u32 nx = lbytes + TRC_SEG * infl;                 // stream offset of this lane's next segment
-        const u32 nx_j = (u32)__shfl((int)nx, (int)j, 64);
-        // where the bytes come from (the ring slot follows from nx_j), relative to the wave's first stream: one shuffle
-        // instead of three (source offset, stream start low / high)
-        const u32 a_j = (u32)__shfl((int)(srel + trc_min(nx, lim)), (int)j, 64);
+        const u32 ro = nx & (TRC_SRING - 1);                    // its ring offset: 0 or 64
+        const u32 src = srel + trc_min(nx, lim);                // where the bytes come from, relative to the wave's first stream
+        const u32 slot = (rw + ra(lane, ro)) | (ro == 0u ? 1u : 0u);
+        const int dst = (int)((pick ? rank << 2 : 1u) << 2);    // byte index of the receiving lane
+        const u32 src_l = (u32)__builtin_amdgcn_ds_permute(dst, (int)src), slot_l = (u32)__builtin_amdgcn_ds_permute(dst, (int)slot);
+        const u32 src_q = (u32)__builtin_amdgcn_update_dpp(0, (int)src_l, 0x00, 0xf, 0xf, false);     // quad_perm [0,0,0,0]: the leader's value
+        const u32 slot_q = (u32)__builtin_amdgcn_update_dpp(0, (int)slot_l, 0x00, 0xf, 0xf, false);
+        const u32 q = lane >> 2, part = lane & 3u;
         if (q < cnt && q < 16u) {
-            const u8 *s = gbase + wbase + a_j + part;
-            const uint4 v = trc_ld16_a2(s);
-            const u32 dd = (j << 8) | ((nx_j & (TRC_SRING - 1)) + part);
+            const uint4 v = trc_ld16_a2(gbase + wbase + src_q + (part << 4));
+            const u32 dd = ((slot_q & ~1u) + part * PIECE_STEP) | (part == 0u ? slot_q & 1u : 0u);
             if (par == 0) { hvA = v; hdA = dd; hokA = true; } else { hvB = v; hdB = dd; hokB = true; }
         }
         if (pick) { infl++; if (par == 0) mineA = true; else mineB = true; }

@@ -48,9 +48,7 @@ struct TrcWork {
 #define TRC_TAB_DEC   4096       // u32[256]     decoder symbol table
 #define TRC_TAB_LUT   8192       // u8[32768]    slot -> symbol
 #define TRC_TAB_CDF   40960      // u16[260]     sanitised CDF copy
-#define TRC_TAB_BKT   45056      // uint2[4096]  static rANS decoder: one entry per bucket of 8 slots (trc_dir.hip)
-#define TRC_TAB_LUT2  77824      // u8[128][8]   ... slot -> symbol rows of the buckets that hold 3 or more symbols
-#define TRC_TAB_BYTES 78848
+#define TRC_TAB_BYTES 45056
 
 // static-table prep (ANS4S / RCS1 / RCS2)
 void trc_launch_static_prep(const uint16_t *d_cdf, unsigned cdfnum, uint8_t *tables, hipStream_t s);
