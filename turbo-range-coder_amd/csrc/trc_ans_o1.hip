@@ -8,26 +8,26 @@
 //
 // 136 KiB per chunk rules LDS out (one chunk per CU would leave 256 lanes busy on the whole chip).  The models live
 // in HBM instead -- 288 GB per GPU hold two million of them -- one contiguous block per chunk, each lane working on
-// its own: a table is two 16-byte global loads, the update runs on registers (K table in LDS, trc_nibmodel.h), two
-// 16-byte stores.  The symbol bounds come out of the register copy by select trees, so a nibble costs one memory
-// round trip.  The encoder knows both tables of a byte in advance (context and hi nibble are input bytes) and
-// requests them together; the decoder learns the lo table only from the hi nibble it has just decoded.  Nothing in
-// LDS but the K table, so occupancy is limited by registers only and the round trips overlap across waves.
+// its own: a table is two 16-byte global accesses per lane, the update runs on registers (K table in LDS,
+// trc_nibmodel.h), the symbol bounds come out of the register copy by select trees.
+//
+// Round 3.  PMC arithmetic says these kernels are bound by the texture-address unit: every table access is 64 scattered
+// 16-byte lane accesses, four wave-instructions per nibble (load x 2, store x 2).  So the accesses themselves were cut:
+//   * each lane keeps the hi table and the lo table it used last IN REGISTERS, with their identities, and goes to memory
+//     only when the next nibble needs a different table (write the old one back, fetch the new one) -- loads and stores
+//     run under the lanes' own predicates, so a wave-instruction costs the unit only the lanes that miss.  In run-heavy
+//     data (what an order-1 coder is for: BWT output) most bytes repeat their predecessor and both tables hit;
+//   * FIRST TOUCH: a table that has not been written in this call is not read either -- it IS the initial table
+//     (cdf[j] = j << 11).  256 "context seen" bits per lane live in LDS; the 16 "lo table seen" bits of a context ride in
+//     entry 0 of its hi table, which the model keeps at 0 (K[x][0] = 0) and which is masked out while the table is in
+//     registers.  The 136 KiB-per-chunk fill kernel of rounds 1-2 (3.3 GB per call at 100 MB / chunk 4096, twice per
+//     step) is gone, and so is the first read of every table.
 #include "trc_io.h"
 #include "trc_lane_io.h"
 #include "trc_nibmodel.h"
 #include "trc_launch.h"
 
 #define O1_MODEL_BYTES TRC_O1_MODEL_BYTES                    // 139264 per chunk
-
-__global__ __launch_bounds__(256) void trc_o1_fill_kernel(uint4 *__restrict__ model, u64 nvec)
-{
-    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (i >= nvec) return;
-    const u32 k = (u32)(i & 1u) * 4u;                       // which half of a 32-byte table: entries 8k' .. (cdf[j] = j << 11)
-    model[i] = make_uint4(trc_pk((2 * k) << 11, (2 * k + 1) << 11), trc_pk((2 * k + 2) << 11, (2 * k + 3) << 11),
-                          trc_pk((2 * k + 4) << 11, (2 * k + 5) << 11), trc_pk((2 * k + 6) << 11, (2 * k + 7) << 11));
-}
 
 __device__ __forceinline__ NibTable o1_load(const u8 *tb)
 {
@@ -75,11 +75,64 @@ __device__ __forceinline__ void o1_init_k(u8 *kb)
     __syncthreads();
 }
 
+// The per-lane table cache (header comment).  Tables are named by their index in the chunk's model block: hi table of
+// context c = 17 c, lo table (c, h) = 17 c + 1 + h.
+#define O1_SEEN_BYTES (64u * 32u)                            // 256 context bits per lane
+struct O1Cache {
+    NibTable H, L;
+    u32 hid, lid;        // what H / L hold (~0u: nothing yet)
+    u32 hmask;           // lo tables of H's context written so far (entry 0 of the hi table in memory)
+    u8 *mine;            // this lane's model block
+    u32 seen;            // LDS byte address of this lane's context bits
+    __device__ __forceinline__ static NibTable fresh()
+    {
+        NibTable T;
+#pragma unroll
+        for (u32 k = 0; k < 8; k++) T.d[k] = trc_pk((2 * k) << 11, (2 * k + 1) << 11);
+        return T;
+    }
+    // every lane of the wave must call (one wave per workgroup: the barrier orders the zeroing before the first read)
+    __device__ __forceinline__ void init(u8 *model_block, u8 *seen_lds)
+    {
+        typedef __attribute__((address_space(3))) u32 lds_u32;
+        mine = model_block; hid = lid = ~0u; hmask = 0; H = fresh(); L = fresh();
+        seen = trc_lds_addr(seen_lds) + trc_lane() * 32u;
+#pragma unroll
+        for (u32 k = 0; k < 8; k++) *(lds_u32 *)(uintptr_t)(seen + 4u * k) = 0u;
+        __syncthreads();
+    }
+    // make H the hi table of context cx (only lanes with `on`)
+    __device__ __forceinline__ void need_hi(bool on, u32 cx)
+    {
+        typedef __attribute__((address_space(3))) u32 lds_u32;
+        const u32 id = cx * 17u;
+        if (on && id != hid) {
+            if (hid != ~0u) { NibTable W = H; W.d[0] |= hmask; o1_store(mine + (size_t)hid * 32u, W); }
+            const u32 a = seen + ((cx >> 5) << 2), bits = *(const lds_u32 *)(uintptr_t)a, bit = 1u << (cx & 31u);
+            if (bits & bit) { H = o1_load(mine + (size_t)id * 32u); hmask = H.d[0] & 0xffffu; H.d[0] &= 0xffff0000u; }
+            else { H = fresh(); hmask = 0; *(lds_u32 *)(uintptr_t)a = bits | bit; }
+            hid = id;
+        }
+    }
+    // make L the lo table (cx, h); H must be the hi table of cx
+    __device__ __forceinline__ void need_lo(bool on, u32 cx, u32 h)
+    {
+        const u32 id = cx * 17u + 1u + h;
+        if (on && id != lid) {
+            if (lid != ~0u) o1_store(mine + (size_t)lid * 32u, L);
+            if ((hmask >> h) & 1u) L = o1_load(mine + (size_t)id * 32u);
+            else { L = fresh(); hmask |= 1u << h; }
+            lid = id;
+        }
+    }
+};
+
 // ------------------------------------------------------------------------------ encode, pass 1 ---
 __global__ __launch_bounds__(64) void trc_o1_model_kernel(
     const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ model, u8 *__restrict__ recs)
 {
     __shared__ __attribute__((aligned(16))) u8 kb[TRC_NIBK_BYTES];
+    __shared__ __attribute__((aligned(16))) u8 seen[O1_SEEN_BYTES];
     const u32 lane = threadIdx.x;
     o1_init_k(kb);
 
@@ -92,7 +145,8 @@ __global__ __launch_bounds__(64) void trc_o1_model_kernel(
     const bool alive = lane < wc.rows;
     const u32 len = alive ? wc.len_of(lane) : 0u;
     const u32 plen = len + (len & 1u);                         // bytes coded, dummy included
-    u8 *mine = model + (u64)(wc.c0 + (alive ? lane : 0u)) * O1_MODEL_BYTES;   // dead lanes alias lane 0's model but never touch it
+    O1Cache tc;
+    tc.init(model + (u64)(wc.c0 + (alive ? lane : 0u)) * O1_MODEL_BYTES, seen);   // dead lanes alias lane 0's model but never touch it
 
     QuadIn qin; qin.base = in + (u64)wc.c0 * chunk;
     QuadOut qout; qout.base = recs + (u64)wc.c0 * wr.chunk;
@@ -119,13 +173,12 @@ __global__ __launch_bounds__(64) void trc_o1_model_kernel(
                     u32 x = (w[2 * h + (i >> 2)] >> (8 * (i & 3))) & 255u;
                     if (pos >= len) x = 0;                     // the coded dummy of an odd tail (and unused padding)
                     r[2 * i] = r[2 * i + 1] = 0;
-                    if (alive && pos < plen) {
-                        u8 *th = mine + (cx * 17u) * 32u, *tl = th + (1u + (x >> 4)) * 32u;
-                        NibTable H = o1_load(th), L = o1_load(tl);        // both tables of the byte are known up front
+                    const bool on = alive && pos < plen;
+                    tc.need_hi(on, cx); tc.need_lo(on, cx, x >> 4);
+                    if (on) {
                         u32 a0, a1, b0, b1;
-                        o1_bounds(H, x >> 4, a0, a1); o1_bounds(L, x & 15u, b0, b1);
-                        o1_adapt(H, kb, x >> 4); o1_adapt(L, kb, x & 15u);
-                        o1_store(th, H); o1_store(tl, L);
+                        o1_bounds(tc.H, x >> 4, a0, a1); o1_bounds(tc.L, x & 15u, b0, b1);
+                        o1_adapt(tc.H, kb, x >> 4); o1_adapt(tc.L, kb, x & 15u);
                         r[2 * i] = (a0 << TRC_PROB_BITS) | (a1 - a0);
                         r[2 * i + 1] = (b0 << TRC_PROB_BITS) | (b1 - b0);
                         cx = x;
@@ -145,6 +198,7 @@ __global__ __launch_bounds__(64) void trc_o1_dec_kernel(
     u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ model, u8 *__restrict__ out)
 {
     __shared__ __attribute__((aligned(16))) u8 kb[TRC_NIBK_BYTES];
+    __shared__ __attribute__((aligned(16))) u8 seen[O1_SEEN_BYTES];
     const u32 lane = threadIdx.x;
     o1_init_k(kb);
 
@@ -159,22 +213,30 @@ __global__ __launch_bounds__(64) void trc_o1_dec_kernel(
     const u32 ex = trc_wave_incl_scan(cl) - cl;
     const u64 off = trc_group_base(goff, gsum, wc.c0 >> 6) + ex;
     const bool coded = alive && cl != len;
-    u8 *mine = model + (u64)(wc.c0 + (alive ? lane : 0u)) * O1_MODEL_BYTES;
+    O1Cache tc;
+    tc.init(model + (u64)(wc.c0 + (alive ? lane : 0u)) * O1_MODEL_BYTES, seen);
 
     u32 st[4] = { TRC_ANS_LOW, TRC_ANS_LOW, TRC_ANS_LOW, TRC_ANS_LOW };
     if (coded) for (u32 k = 0; k < 4; k++) st[k] = trc_ld32_a2(payload + off + 4u * k);   // decoder st[i] = encoder st[3-i] (mnfill)
     LaneIn<2> si; si.prime(payload + off + 16u, coded, trc_sub_sat(cl, 16u));
     u32 cx = 0;
 
-    // cdf16ansdec on a table in HBM (only lanes with act touch memory)
-    auto get_nibble = [&](u32 &s, u8 *tb) -> u32 {
+    // cdf16ansdec on a cached table (only lanes with act touch memory, and only for a table they do not hold)
+    auto get_nibble = [&](u32 &s, NibTable &T) -> u32 {
         const u32 slot = s & (TRC_PROB_ONE - 1);
-        NibTable T = o1_load(tb);
         u32 c0, c1;
         const u32 x = trc_nib_find(T, slot, c0, c1);
         s = __umul24(c1 - c0, s >> TRC_PROB_BITS) + slot - c0;
-        o1_adapt(T, kb, x); o1_store(tb, T);
+        o1_adapt(T, kb, x);
         return x;
+    };
+    auto get_byte = [&](bool act, u32 &sh, u32 &sl) -> u32 {    // context cx -> byte, which becomes the context
+        tc.need_hi(act, cx);
+        u32 h = 0, l = 0;
+        if (act) h = get_nibble(sh, tc.H);
+        tc.need_lo(act, cx, h);
+        if (act) { l = get_nibble(sl, tc.L); cx = h << 4 | l; }
+        return h << 4 | l;
     };
     auto renorm = [&](u32 &s, bool act) {
         const u32 w = si.peek16();
@@ -200,14 +262,10 @@ __global__ __launch_bounds__(64) void trc_o1_dec_kernel(
 #pragma unroll
                     for (int j = 0; j < 2; j++) {              // mndec8x2x: two bytes, then four renorms in order st0..st3
                         const bool act = coded && q0 + 2u * (u32)j < len;     // the second byte of an odd tail is the dummy
-                        if (act) {
-                            u8 *th = mine + (cx * 17u) * 32u;
-                            const u32 h0 = get_nibble(st[0], th), l0 = get_nibble(st[1], th + (1u + h0) * 32u);
-                            cx = h0 << 4 | l0;
-                            th = mine + (cx * 17u) * 32u;
-                            const u32 h1 = get_nibble(st[2], th), l1 = get_nibble(st[3], th + (1u + h1) * 32u);
-                            w |= (cx | (h1 << 4 | l1) << 8) << (16 * j);
-                            cx = h1 << 4 | l1;
+                        {
+                            const u32 x0 = get_byte(act, st[0], st[1]);
+                            const u32 x1 = get_byte(act, st[2], st[3]);
+                            w |= (x0 | x1 << 8) << (16 * j);
                         }
                         renorm(st[0], act); renorm(st[1], act); renorm(st[2], act); renorm(st[3], act);
                     }
@@ -227,20 +285,13 @@ __global__ __launch_bounds__(64) void trc_o1_dec_kernel(
 }
 
 // ------------------------------------------------------------------------------------- launch ---
-static void o1_fill(const TrcWork &w, hipStream_t s)
-{
-    const u64 nvec = (u64)w.nchunks * (O1_MODEL_BYTES / 16u);
-    TRC_LAUNCH_TIMED(trc_o1_fill_kernel, dim3((u32)((nvec + 255) / 256)), dim3(256), 0, s, (uint4 *)w.model, nvec);
-}
 void trc_launch_anso1_model(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, hipStream_t s)
 {
-    o1_fill(w, s);
     TRC_LAUNCH_TIMED(trc_o1_model_kernel, dim3(w.ngroups), dim3(64), 0, s, d_in, (u64)n, chunk, w.nchunks, w.model, w.scratch2);
 }
 void trc_launch_anso1_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                           const TrcWork &w, uint8_t *d_out, hipStream_t s)
 {
-    o1_fill(w, s);
     TRC_LAUNCH_TIMED(trc_o1_dec_kernel, dim3(w.ngroups), dim3(64), 0, s,
                        d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, w.model, d_out);
 }
