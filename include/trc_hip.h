@@ -66,9 +66,10 @@ enum trc_codec {
 #define TRC_MAGIC        0x31435254u   /* "TRC1" */
 #define TRC_CHUNK_MIN    256u
 #define TRC_CHUNK_MAX    65536u        /* chunk must be a multiple of 64 in [MIN, MAX] */
-#define TRC_CHUNK_DEFAULT 1024u        /* the parallel unit is the chunk: at 100 MB per GPU 4096 leaves 1.5 waves per CU (static rANS
-                                          147 GB/s), 1024 six (385 GB/s), 512 twelve (514 GB/s); payload ratio on text 63.50 / 63.94 /
-                                          64.52 %.  Gigabyte inputs fill the chip at 4096 too: pick by input size. */
+#define TRC_CHUNK_AUTO_MIN 512u        /* the parallel unit is the chunk: at 100 MB per GPU 4096 leaves 1.5 waves per CU (static rANS
+                                          163 GB/s), 1024 six (449 GB/s), 512 twelve (590 GB/s); payload ratio on text 63.50 / 63.94 /
+                                          64.52 %.  Gigabyte inputs fill the chip at 4096 too, so host-pointer calls pick the size from
+                                          the input length (trc_auto_chunk) unless the caller fixes it. */
 #define TRC_ANSB_CHUNK_MAX 8192u       /* TRC_ANSB only: one 8192-byte block of the reference per chunk */
 #define TRC_PAD          256u          /* readable slack the device entry points need after every buffer */
 
@@ -92,9 +93,13 @@ const char *trc_last_error(void);
 /* number of visible HIP devices (0 if the runtime cannot initialise -- no CPU fallback exists) */
 int trc_device_count(void);
 
-/* process-wide chunk size used by the host-pointer (reference-signature) calls; also TRC_CHUNK env */
+/* chunk size of the host-pointer (reference-signature) calls, process-wide.  0 = automatic (the default): every call
+ * takes trc_auto_chunk(its input length) -- the largest of 4096 / 2048 / 1024 / 512 that still fills the chip (one
+ * residency round of 196 608 chunks: >= 805 / 403 / 201 MB), 512 below.  trc_set_chunk(c) or TRC_CHUNK=c in the
+ * environment fix it; trc_set_chunk(0) returns to automatic.  Decoders take the size from the container. */
 int      trc_set_chunk(uint32_t chunk);
 uint32_t trc_get_chunk(void);
+uint32_t trc_auto_chunk(size_t n);
 
 /* ---- device-resident layer --------------------------------------------------------------------
  * All d_* pointers are device pointers on the current HIP device, 16-byte aligned, with TRC_PAD

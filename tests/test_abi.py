@@ -58,6 +58,14 @@ def test_config_calls_work_without_gpu(lib):
     assert lib.trc_set_chunk(100) != 0          # rejected: not a multiple of 64 in range
     lib.trc_last_error.restype = ctypes.c_char_p
     assert b"chunk" in lib.trc_last_error()
+    # the chunk size of a host-pointer call follows its input length unless the caller fixes it
+    lib.trc_auto_chunk.restype = ctypes.c_uint32
+    lib.trc_auto_chunk.argtypes = [ctypes.c_size_t]
+    assert [lib.trc_auto_chunk(n) for n in (1, 100 * 10**6, 201326591, 201326592, 402653184, 805306368, 8 * 10**9)] == [512, 512, 512, 1024, 2048, 4096, 4096]
+    if "TRC_CHUNK" not in os.environ:
+        assert lib.trc_get_chunk() == 0                                   # automatic by default
+    assert lib.trc_set_chunk(2048) == 0 and lib.trc_get_chunk() == 2048
+    assert lib.trc_set_chunk(0) == 0 and lib.trc_get_chunk() == 0         # back to automatic
 
 
 def test_no_cpu_coding_path(lib):

@@ -201,7 +201,7 @@ def test_host_pointer_layer(torch_cuda, codec):
         _, cdf, cdfnum = T.orc_cdfini(d)
         assert trc.host_encode(codec, d, cdf, cdfnum).size == 40
     finally:
-        trc.lib().trc_set_chunk(1024)
+        trc.lib().trc_set_chunk(0)
 
 
 def test_static_rans_buckets_with_many_symbols(torch_cuda):
@@ -255,7 +255,7 @@ def test_host_pointer_layer_is_thread_safe(torch_cuda):
                 assert np.array_equal(comp, alone[j]), "thread %d: container differs from the single-threaded call" % j
                 assert np.array_equal(back, jobs[j][1]), "thread %d: round trip" % j
     finally:
-        trc.lib().trc_set_chunk(1024)
+        trc.lib().trc_set_chunk(0)
 
 
 @pytest.mark.parametrize("codec", trc.AVAILABLE, ids=lambda c: trc.CODEC_NAMES[c])
@@ -504,4 +504,4 @@ def test_every_alias_entry_point_is_called(torch_cuda, codec):
                 assert np.array_equal(clen, exp_clen) and np.array_equal(payload, exp_payload), en
                 assert np.array_equal(trc.host_decode(codec, comp, n, cdf, cdfnum, name=dn), d), dn
     finally:
-        trc.lib().trc_set_chunk(1024)
+        trc.lib().trc_set_chunk(0)

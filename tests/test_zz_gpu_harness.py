@@ -162,7 +162,7 @@ def test_host_layer_slice_plan(torch_cuda, tmp_path):
         outs = []
         for tag, env in (("one", {}), ("tiny", {"TRC_HOST_SLICE": "65536"}), ("tinyflat", {"TRC_HOST_SLICE": "65536", "TRC_HOST_NO_RAMP": "1"})):
             packed, back = tmp_path / ("q%d%s" % (nchunks, tag)), tmp_path / ("r%d%s" % (nchunks, tag))
-            e = dict(os.environ, **env)
+            e = dict(os.environ, TRC_CHUNK="1024", **env)
             r = subprocess.run([exe, "c", "65", str(src2), str(packed)], capture_output=True, text=True, timeout=60, env=e)
             assert r.returncode == 0, (nchunks, tag, r.stdout + r.stderr)
             r = subprocess.run([exe, "d", str(packed), str(back)], capture_output=True, text=True, timeout=60, env=e)

@@ -48,20 +48,31 @@ extern "C" int trc_device_count(void)
 }
 
 // ------------------------------------------------------------------------------------ config ---
-static uint32_t g_chunk = 0;
+// The chunk is the parallel unit: a call fills the chip when it has ~196 000 chunks (256 CUs x 12 waves x 64 lanes), and
+// every chunk costs 8 bytes of coder state and 4 bytes of directory.  Unless the caller fixes the size (trc_set_chunk,
+// TRC_CHUNK), a host-pointer call picks it from its input length: the largest of 4096 / 2048 / 1024 / 512 that still
+// gives one full residency round (>= 805 / 403 / 201 MB), 512 below that.
+static uint32_t g_chunk = 0;                                  // 0: not read yet;  ~0u: automatic
 static bool chunk_ok(uint32_t c) { return c >= TRC_CHUNK_MIN && c <= TRC_CHUNK_MAX && (c % 64u) == 0; }
+extern "C" uint32_t trc_auto_chunk(size_t n)
+{
+    for (uint32_t c = 4096u; c > TRC_CHUNK_AUTO_MIN; c >>= 1)
+        if (n / c >= 196608u) return c;
+    return TRC_CHUNK_AUTO_MIN;
+}
 extern "C" uint32_t trc_get_chunk(void)
 {
     if (!g_chunk) {
         const char *e = getenv("TRC_CHUNK");
         uint32_t c = e ? (uint32_t)strtoul(e, 0, 10) : 0;
-        g_chunk = chunk_ok(c) ? c : TRC_CHUNK_DEFAULT;
+        g_chunk = chunk_ok(c) ? c : ~0u;
     }
-    return g_chunk;
+    return g_chunk == ~0u ? 0u : g_chunk;
 }
 extern "C" int trc_set_chunk(uint32_t chunk)
 {
-    if (!chunk_ok(chunk)) return fail(TRC_E_ARG, "chunk %u: must be a multiple of 64 in [%u,%u]", chunk, TRC_CHUNK_MIN, TRC_CHUNK_MAX);
+    if (chunk == 0) { g_chunk = ~0u; return TRC_OK; }         // back to automatic
+    if (!chunk_ok(chunk)) return fail(TRC_E_ARG, "chunk %u: must be 0 (automatic) or a multiple of 64 in [%u,%u]", chunk, TRC_CHUNK_MIN, TRC_CHUNK_MAX);
     g_chunk = chunk;
     return TRC_OK;
 }
@@ -600,6 +611,7 @@ static size_t host_encode(int codec, const unsigned char *in, size_t inlen, unsi
     if (ctx_init(c, dev)) return 0;
     HostDrain guard(c);
     uint32_t chunk = chunk_override ? chunk_override : trc_get_chunk();
+    if (!chunk) chunk = trc_auto_chunk(inlen);
     if (!chunk_ok(chunk)) { fail(TRC_E_ARG, "chunk %u: must be a multiple of 64 in [%u,%u]", chunk, TRC_CHUNK_MIN, TRC_CHUNK_MAX); return 0; }
     if (codec == TRC_ANSB && chunk > TRC_ANSB_CHUNK_MAX) chunk = TRC_ANSB_CHUNK_MAX;
     if (codec == TRC_ANSO1 && chunk < 4096u && !chunk_override) chunk = 4096u;    // 256 x 17 tables per chunk: nothing to learn from in fewer bytes (and 136 KiB of workspace each)
