@@ -89,8 +89,8 @@ CODEC_INFO = {
 
 
 # chunk size with the best throughput at 100 MB per GPU where it is not 512 (one residency round of the waves:
-# rccdfs2 keeps two rings per lane, 9 waves per CU; the order-1 coder needs room for its context statistics)
-BEST_CHUNK = {"rccdfs2": 896, "anscdf1": 4096}
+# rccdfs2 runs one lane per stream: chunk 1024 gives it the lanes chunk 512 gives the one-stream coder; the order-1 coder needs room for its context statistics)
+BEST_CHUNK = {"rccdfs2": 1024, "anscdf1": 4096}
 
 
 def make_input(n, rank, kind="text"):

@@ -169,12 +169,15 @@ struct QuadIn {
     uint4 r[4];          // segment in flight: r[j] = piece (lane&3) of the chunk of lane (lane&~3)+j
     uint4 r2[4];         // second segment in flight (paired mode: the other 64-byte half of the same 128-byte line)
     uint4 p[4];          // current segment: p[k] = piece k of this lane's chunk
-    __device__ __forceinline__ void issue(const WaveChunks &w, u32 segoff)
+    // pair = true: lanes 2i and 2i + 1 both take chunk i of the wave (one lane per stream of a two-stream coder): the quad's
+    // four rows are two chunks, each requested twice (the second request hits the first one's line)
+    __device__ __forceinline__ void issue(const WaveChunks &w, u32 segoff, bool pair = false)
     {
         const u32 lane = trc_lane(), part = (lane & 3u) << 4;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             u32 row = (lane & ~3u) + (u32)j;
+            if (pair) row >>= 1;
             row = row < w.rows ? row : w.rows - 1;
             const u32 so = segoff < w.len_of(row) ? segoff : 0u;     // never read past the input's pad
             r[j] = trc_ld16_nt(base + (size_t)row * w.chunk + so + part);     // read once: do not keep it in the caches
@@ -229,7 +232,9 @@ struct QuadOut {
     u8 *base;            // global address of chunk c0 in the output
     uint4 p[4];
     __device__ __forceinline__ void put(u32 k, uint4 v) { p[k] = v; }
-    __device__ __forceinline__ void flush(const WaveChunks &w, u32 segoff)
+    // pair = true: lanes 2i and 2i + 1 hold the SAME 64 bytes of chunk i (one lane per stream, bytes merged across the pair):
+    // after the transpose the quad's rows 0, 2 are its two chunks, rows 1, 3 their duplicates and are not stored
+    __device__ __forceinline__ void flush(const WaveChunks &w, u32 segoff, bool pair = false)
     {
         const u32 lane = trc_lane();
         u32 m[4][4];                                           // m[k][c]: dword c of piece k
@@ -239,7 +244,8 @@ struct QuadOut {
         const u32 part = (lane & 3u) << 4;
 #pragma unroll
         for (int j = 0; j < 4; j++) {                          // m[j] = piece (lane&3) of the chunk of lane (lane&~3)+j
-            const u32 row = (lane & ~3u) + (u32)j;
+            if (pair && (j & 1)) continue;
+            const u32 vrow = (lane & ~3u) + (u32)j, row = pair ? vrow >> 1 : vrow;
             if (row < w.rows && segoff + part + 16u <= w.len_of(row))
                 trc_st16_nt(base + (size_t)row * w.chunk + segoff + part, make_uint4(m[j][0], m[j][1], m[j][2], m[j][3]));
         }
@@ -249,13 +255,23 @@ struct QuadOut {
 // --------------------------------------------------------------------------------- StreamOut ---
 // DOWN = true : units are appended downward from the END of the chunk's scratch region (rANS)
 // DOWN = false: upward from the START of the region (range coders)
-template <bool DOWN>
+// PAIR = true (round 3, the two-stream range coder with one LANE PER STREAM): lanes 2i and 2i + 1 work on chunk c0 + i;
+// the even lane's stream goes to the chunk's region in `scratch`, the odd lane's to its region in `scratch_b`.
+template <bool DOWN, bool PAIR = false>
 struct StreamOut {
     u8 *rings;           // this wave's ring array (LDS)
     u8 *sel;             // this wave's rank->lane table (LDS)
     u8 *scratch;         // global scratch, region of chunk c is [c*stride, (c+1)*stride)
     u32 stride;
     u32 c0;
+    u8 *scratch_b;       // PAIR only: the second stream's regions
+    u32 stride_b;
+    __device__ __forceinline__ u32 my_row() const { return PAIR ? trc_lane() >> 1 : trc_lane(); }
+    __device__ __forceinline__ u32 my_stride() const { return (PAIR && (trc_lane() & 1u)) ? stride_b : stride; }
+    __device__ __forceinline__ u8 *my_region() const
+    {
+        return (PAIR && (trc_lane() & 1u)) ? scratch_b + (size_t)(c0 + my_row()) * stride_b : scratch + (size_t)(c0 + my_row()) * stride;
+    }
     u32 wpos;            // bytes appended by this lane so far
     u32 nfl;             // 64-byte segments already moved to the region
 
@@ -283,19 +299,19 @@ struct StreamOut {
     __device__ __forceinline__ void self_drain()
     {
         const u32 ro = DOWN ? ((0u - TRC_SEG * (nfl + 1u)) & (TRC_SRING - 1)) : ((TRC_SEG * nfl) & (TRC_SRING - 1));
-        u8 *reg = scratch + (size_t)(c0 + trc_lane()) * stride;
-        u8 *d = DOWN ? reg + stride - (size_t)TRC_SEG * (nfl + 1u) : reg + (size_t)TRC_SEG * nfl;
+        u8 *reg = my_region();
+        u8 *d = DOWN ? reg + my_stride() - (size_t)TRC_SEG * (nfl + 1u) : reg + (size_t)TRC_SEG * nfl;
         for (u32 i = 0; i < 16; i++) ((u32 *)d)[i] = *(const u32 *)(rings + trc_raddr(trc_lane(), ro + 4u * i));
         nfl++;
     }
     __device__ __forceinline__ void put32_slow(u32 v)
     {
-        if (pending() + 4u > TRC_SRING - 4u && (size_t)TRC_SEG * (nfl + 2u) <= stride) self_drain();
+        if (pending() + 4u > TRC_SRING - 4u && (size_t)TRC_SEG * (nfl + 2u) <= my_stride()) self_drain();
         put32(v);
     }
     __device__ __forceinline__ void put16_slow(u32 v)
     {
-        if (pending() + 2u > TRC_SRING - 4u && (size_t)TRC_SEG * (nfl + 2u) <= stride) self_drain();
+        if (pending() + 2u > TRC_SRING - 4u && (size_t)TRC_SEG * (nfl + 2u) <= my_stride()) self_drain();
         put16(v);
     }
 
@@ -318,7 +334,9 @@ struct StreamOut {
             const u32 cnt = (u32)__popcll(mask);
             const u32 ro = DOWN ? ((0u - TRC_SEG * (nfl + 1u)) & (TRC_SRING - 1)) : ((TRC_SEG * nfl) & (TRC_SRING - 1));
             const u32 from = rw + trc_raddr(lane, ro);
-            const u32 to = lane * stride + (DOWN ? stride - TRC_SEG * (nfl + 1u) : TRC_SEG * nfl);   // (63 regions of at most 64 KiB + slack: 32 bits)
+            // place in the scratch array relative to the wave's first region (63 regions of at most 64 KiB + slack: 32 bits; offsets
+            // are multiples of 64, so bit 0 can name the array: PAIR, odd lane = second stream)
+            const u32 to = (my_row() * my_stride() + (DOWN ? my_stride() - TRC_SEG * (nfl + 1u) : TRC_SEG * nfl)) | (PAIR ? lane & 1u : 0u);
             const int dst = (int)((pick ? rank << 2 : 1u) << 2);
             const u32 from_l = (u32)__builtin_amdgcn_ds_permute(dst, (int)from), to_l = (u32)__builtin_amdgcn_ds_permute(dst, (int)to);
             const u32 from_q = (u32)__builtin_amdgcn_update_dpp(0, (int)from_l, 0x00, 0xf, 0xf, false);   // quad_perm [0,0,0,0]
@@ -329,7 +347,8 @@ struct StreamOut {
                 const u32 a = from_q + part;
                 const u32 s0 = *(const lds_u32 *)(uintptr_t)a, s1 = *(const lds_u32 *)(uintptr_t)(a + 4u);
                 const u32 s2 = *(const lds_u32 *)(uintptr_t)(a + 8u), s3 = *(const lds_u32 *)(uintptr_t)(a + 12u);
-                *(uint4 *)(scratch + (size_t)c0 * stride + to_q + part) = make_uint4(s0, s1, s2, s3);
+                u8 *base = (PAIR && (to_q & 1u)) ? scratch_b + (size_t)c0 * stride_b : scratch + (size_t)c0 * stride;
+                *(uint4 *)(base + (to_q & ~1u) + part) = make_uint4(s0, s1, s2, s3);
             }
             if (pick) { nfl++; ready = final ? (wpos > TRC_SEG * nfl) : pending() >= TRC_SEG; }
             mask = __ballot(ready);

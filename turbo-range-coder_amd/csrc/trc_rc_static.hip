@@ -12,6 +12,7 @@
 // One lane = one chunk (RCS2: both of its coders).  Both overflow tests are monotone in the number
 // of words written, so evaluating them at 16-symbol periods and once after the last symbol decides
 // exactly like the reference's per-symbol test; the early exit only bounds the scratch writes.
+#include <stdlib.h>
 #include "trc_rc.h"
 #include "trc_launch.h"
 
@@ -250,7 +251,220 @@ __global__ __launch_bounds__(896) void trc_rcs_dec_kernel(
     trc_wave_copy_raw(__ballot(alive && cl == len && len != 0), off, len, out + (u64)wc.c0 * chunk, chunk, payload);
 }
 
+// -------------------------------------------------------------------- RCS2, one LANE per stream ---
+// Round 3.  The two streams of rccdfs2enc are independent byte ranges (rccdf.c:125-143: even-index bytes + an odd tail on
+// stream 0, odd-index bytes on stream 1): lanes 2i and 2i + 1 take chunk i of the wave, one stream each -- twice the lanes
+// for the same bytes, one ring per lane instead of two (16 waves per CU fit where the one-lane form held 9), and a lane's
+// step is the one-stream coder's.  The streams meet only in the overflow tests (word counts exchanged by DPP once per
+// period) and at the end (lengths); the decoder merges the two lanes' bytes by DPP before the output transpose.
+// A workgroup is two waves = one group of 64 chunks, so that gsum keeps its meaning.
+__global__ __launch_bounds__(128) void trc_rcs2p_enc_kernel(
+    const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks, const u32 *__restrict__ tab_g,
+    u8 *__restrict__ scrA, u32 strideA, u8 *__restrict__ scrB, u32 strideB,
+    u32 *__restrict__ clen, u32 *__restrict__ gsum)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    u32 *tab = (u32 *)smem;                                    // 256 x {f<<16 | c0}
+    u32 *wsum = (u32 *)(smem + 1024);                          // the two waves' byte counts
+    const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    u8 *wbase = smem + 1024 + 64 + wv * RCS_WAVE_LDS(1);
+    for (u32 i = tid; i < 256; i += 128) tab[i] = tab_g[i];
+    __syncthreads();
+
+    WaveChunks wc;
+    wc.c0 = blockIdx.x * 64u + wv * 32u; wc.chunk = chunk; wc.nchunks = nchunks;
+    wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
+    wc.rows = wc.c0 >= nchunks ? 0u : nchunks - wc.c0 < 32u ? nchunks - wc.c0 : 32u;
+    u32 gs = 0;
+    if (wc.rows) {
+        const u32 ci = lane >> 1, b = lane & 1u;
+        const bool alive = ci < wc.rows;
+        const u32 c = wc.c0 + ci;
+        const u32 len = alive ? wc.len_of(ci) : 0u;
+        const int lim = trc_rc_limit(len);
+
+        QuadIn tin; tin.base = in + (u64)wc.c0 * chunk;
+        StreamOut<false, true> so;
+        so.rings = wbase; so.sel = wbase + TRC_SRING_BYTES;
+        so.scratch = scrA; so.stride = strideA; so.scratch_b = scrB; so.stride_b = strideB; so.c0 = wc.c0;
+        so.wpos = b ? 0u : 4u; so.nfl = 0;
+        RcEncD e; e.start();
+        const u32 off1 = len >= 4u ? 4u + ((len - 4u) * 37u) / 64u : 0u;       // stream-1 base inside `out` (rccdf.c:126)
+        bool ovf = alive && len < 10u;                                         // tiny inputs: always raw
+        const u32 pairs = len & ~1u;
+        // OVERFLOWI (rccdf.c:46) on the two lanes' word counts
+        auto overflowi = [&]() {
+            const u32 mine = e.cw.nwords, other = trc_quad_xor1(mine), n0 = b ? other : mine, n1 = b ? mine : other;
+            return ((int)(off1 + 4u * n1) >= lim) || (4u + 4u * n0 >= off1);
+        };
+
+        const u32 S = chunk / TRC_SEG, sh0 = 8u * b, sh1 = 16u + 8u * b;
+        tin.issue(wc, 0, true);
+        for (u32 s = 0; s < S; s++) {
+            tin.commit();
+            if (s + 1 < S) tin.issue(wc, (s + 1) * TRC_SEG, true);
+            uint4 pc0 = tin.read(0), pc1 = tin.read(1), pc2 = tin.read(2), pc3 = tin.read(3);
+#pragma nounroll
+            for (u32 k = 0; k < 4; k++) {
+                uint4 v = pc0; pc0 = pc1; pc1 = pc2; pc2 = pc3;
+                const u32 p0 = s * TRC_SEG + k * 16u;
+                const bool act = alive && !ovf && p0 < len;
+                const bool full = act && p0 + 16u <= len;
+                if (full) {
+#pragma nounroll
+                    for (u32 d = 0; d < 4; d++) {               // a dword = two pairs: this lane's bytes are b and b + 2
+                        const u32 wd = v.x; v.x = v.y; v.y = v.z; v.z = v.w;
+                        const u32 ta = tab[(wd >> sh0) & 255u], tb = tab[(wd >> sh1) & 255u];
+                        e.sym_rec(true, ta & 0xffffu, ta >> 16); e.sym_rec(true, tb & 0xffffu, tb >> 16); e.flush(so);
+                    }
+                } else if (act) {                               // last chunk's final partial piece (both lanes of its pair walk it)
+                    const u8 *mine = in + (u64)c * chunk;
+                    for (u32 pos = p0; pos < len; pos++) {
+                        const u32 t = tab[mine[pos]];
+                        const bool second = pos < pairs && (pos & 1u);          // odd-index byte of a pair; the odd tail byte is stream 0's
+                        if ((second ? 1u : 0u) == b) e.sym(so, t & 0xffffu, t >> 16);
+                        if (second) ovf = ovf || overflowi();   // pair complete (never after the odd tail byte)
+                    }
+                }
+                so.drain(false, alive);
+                const bool o = overflowi();                     // (all lanes: the exchange must not sit in a branch)
+                if (full) ovf = ovf || o;
+            }
+        }
+        u32 out_len = 0;
+        if (alive && !ovf) e.finish(so);
+        {
+            const u32 mine = so.wpos, other = trc_quad_xor1(mine);
+            if (alive) {
+                out_len = mine + other;                         // 4 + len0 + len1
+                if (!ovf && (int)out_len >= lim) ovf = true;
+                if (ovf) out_len = len;
+            }
+        }
+        so.drain(true, alive && !ovf);
+        if (alive && !ovf && b == 0u) *(u32 *)(scrA + (u64)c * strideA) = so.wpos - 4u;   // header: len0 (the segment holding it is already in place)
+        if (alive && b == 0u) clen[c] = out_len;
+        gs = trc_wave_sum(b == 0u ? out_len : 0u);
+    }
+    if (lane == 0) wsum[wv] = gs;
+    __syncthreads();
+    if (tid == 0) gsum[blockIdx.x] = wsum[0] + wsum[1];
+}
+
+__global__ __launch_bounds__(896) void trc_rcs2p_dec_kernel(
+    const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
+    u64 n, u32 chunk, u32 nchunks, const u8 *__restrict__ lut_g, const u32 *__restrict__ tab_g, u8 *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    u8 *lut = smem;                                            // 32768
+    u32 *tab = (u32 *)(smem + 32768);                          // 256 x {f<<16 | c0}
+    const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, BLOCK = blockDim.x;
+    u8 *wbase = smem + 32768 + 1024 + wv * RCS_WAVE_LDS(1);
+    if (BLOCK >= 704u) {
+        uint4 t0 = ((const uint4 *)lut_g)[tid], t1 = ((const uint4 *)lut_g)[tid + BLOCK], t2 = make_uint4(0, 0, 0, 0);
+        u32 td = 0;
+        if (tid + 2u * BLOCK < 2048u) t2 = ((const uint4 *)lut_g)[tid + 2u * BLOCK];
+        if (tid < 256u) td = tab_g[tid];
+        ((uint4 *)lut)[tid] = t0; ((uint4 *)lut)[tid + BLOCK] = t1;
+        if (tid + 2u * BLOCK < 2048u) ((uint4 *)lut)[tid + 2u * BLOCK] = t2;
+        if (tid < 256u) tab[tid] = td;
+    } else {
+        for (u32 i = tid; i < 2048; i += BLOCK) ((uint4 *)lut)[i] = ((const uint4 *)lut_g)[i];
+        for (u32 i = tid; i < 256; i += BLOCK) tab[i] = tab_g[i];
+    }
+    __syncthreads();
+
+    WaveChunks wc;
+    wc.c0 = (blockIdx.x * (BLOCK / 64) + wv) * 32u; wc.chunk = chunk; wc.nchunks = nchunks;
+    wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
+    if (wc.c0 >= nchunks) return;
+    wc.rows = nchunks - wc.c0 < 32u ? nchunks - wc.c0 : 32u;
+    // the directory of the whole group of 64 chunks (payload offsets are per group): lane L reads chunk (group base + L), the
+    // pair takes its chunk's numbers from there
+    const u32 g0 = wc.c0 & ~63u, cg = g0 + lane;
+    const u32 lenL = cg < nchunks ? ((cg == nchunks - 1u) ? wc.lastlen : chunk) : 0u;
+    const u32 clL = cg < nchunks ? trc_min(clen[cg], lenL) : 0u;   // a directory entry above the chunk length (corrupt input) reads as raw
+    const u32 exL = trc_wave_incl_scan(clL) - clL;
+    const u64 gbase = trc_group_base(goff, gsum, wc.c0 >> 6);
+    const u32 ci = lane >> 1, b = lane & 1u, srcl = (wc.c0 & 32u) + ci;
+    const u32 cl = (u32)__shfl((int)clL, (int)srcl, 64), ex = (u32)__shfl((int)exL, (int)srcl, 64), len = (u32)__shfl((int)lenL, (int)srcl, 64);
+    const bool alive = ci < wc.rows;
+    const u32 c = wc.c0 + ci;
+    const u64 off = gbase + ex;
+    const bool coded = alive && cl != len;
+
+    QuadOut tout; tout.base = out + (u64)wc.c0 * chunk;
+    StreamIn si;
+    si.rings = wbase; si.sel = wbase + TRC_SRING_BYTES;
+    const u32 len0 = coded ? trc_min(trc_ld32_a2(payload + off), trc_sub_sat(cl, 4u)) : 0u;   // a corrupt header cannot point outside the chunk's payload
+    si.gbase = payload;
+    si.soff = off + 4u + (b ? len0 : 0u);
+    si.lim = b ? trc_sub_sat(cl, 4u + len0) : len0;
+    si.prime(coded);
+    RcDec d; d.init(si);
+
+    const u32 S = chunk / TRC_SEG;
+    const u32 pairs = len & ~1u;
+    u8 *dst = out + (u64)c * chunk;
+    for (u32 s = 0; s < S; s++) {
+        uint4 pc0 = make_uint4(0, 0, 0, 0), pc1 = pc0, pc2 = pc0, pc3 = pc0;
+#pragma nounroll
+        for (u32 kk = 0; kk < 2; kk++) {
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const u32 p0 = s * TRC_SEG + (2u * kk + (u32)j) * 16u;
+                si.period(coded && p0 < len, j);
+                uint4 v = make_uint4(0, 0, 0, 0);
+                const bool full = coded && p0 + 16u <= len;
+#pragma nounroll
+                for (u32 q = 0; q < 4; q++) {                   // a dword = two pairs: this lane decodes bytes b and b + 2 of it
+                    u32 m = 0;
+                    if (full) {
+                        // two symbols of one stream: at most one of them renormalises (trc_rc.h RcEncD), one look-ahead word
+                        const u32 w = si.peek32();
+                        const u32 xa = lut[d.quotient15()];
+                        const u32 ta = tab[xa];
+                        const bool ra = d.consume_w(true, ta & 0xffffu, (ta & 0xffffu) + (ta >> 16), w);
+                        const u32 xb = lut[d.quotient15()];
+                        const u32 tb = tab[xb];
+                        const bool rb = d.consume_w(true, tb & 0xffffu, (tb & 0xffffu) + (tb >> 16), w);
+                        si.skip_if(ra || rb);
+                        m = (xa | (xb << 16)) << (8u * b);
+                    }
+                    const u32 both = m | trc_quad_xor1(m);      // (every lane: the exchange must not sit in a branch)
+                    v.x = v.y; v.y = v.z; v.z = v.w; v.w = both;
+                }
+                if (!full && coded && p0 < len) {               // last chunk's final partial piece (both lanes of its pair walk it)
+                    for (u32 pos = p0; pos < len; pos++) {
+                        const bool second = pos < pairs && (pos & 1u);
+                        if ((second ? 1u : 0u) == b) {
+                            const u32 x = lut[d.quotient15()];
+                            const u32 t = tab[x];
+                            d.consume_if(si, true, t & 0xffffu, (t & 0xffffu) + (t >> 16));
+                            dst[pos] = (u8)x;
+                        }
+                    }
+                }
+                pc0 = pc1; pc1 = pc2; pc2 = pc3; pc3 = v;
+            }
+        }
+        tout.put(0, pc0); tout.put(1, pc1); tout.put(2, pc2); tout.put(3, pc3);
+        tout.flush(wc, s * TRC_SEG, true);
+    }
+    // raw chunks: lanes 0..31 carry their chunks' numbers for the wave copy
+    {
+        const u32 from = (lane & 31u) << 1;
+        const u32 olo = (u32)__shfl((int)(u32)off, (int)from, 64), ohi = (u32)__shfl((int)(u32)(off >> 32), (int)from, 64);
+        const u32 l2 = (u32)__shfl((int)len, (int)from, 64), c2 = (u32)__shfl((int)cl, (int)from, 64);
+        const bool raw = lane < wc.rows && c2 == l2 && l2 != 0u;
+        trc_wave_copy_raw(__ballot(raw), ((u64)ohi << 32) | olo, l2, out + (u64)wc.c0 * chunk, chunk, payload);
+    }
+}
+
 // ------------------------------------------------------------------------------------- launch ---
+// TRC_RCS2_PAIR=0: the one-lane-per-chunk form of the two-stream coder (rounds 1-2), kept for A/B measurements
+static bool rcs2_pair() { static const bool on = !(getenv("TRC_RCS2_PAIR") && atoi(getenv("TRC_RCS2_PAIR")) == 0); return on; }
+
 void trc_launch_rcs_enc(int nstreams, const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w,
                         uint32_t *d_clen, hipStream_t s)
 {
@@ -258,6 +472,9 @@ void trc_launch_rcs_enc(int nstreams, const uint8_t *d_in, size_t n, uint32_t ch
     if (nstreams == 1)
         TRC_LAUNCH_TIMED((trc_rcs_enc_kernel<1, 0>), dim3(w.ngroups), dim3(64), 1024 + RCS_WAVE_LDS(1), s,
                            d_in, (u64)n, chunk, w.nchunks, tab, w.scratch, w.stride, w.scratch, w.stride, d_clen, w.gsum);
+    else if (nstreams == 2 && rcs2_pair())
+        TRC_LAUNCH_TIMED(trc_rcs2p_enc_kernel, dim3(w.ngroups), dim3(128), 1024 + 64 + 2 * RCS_WAVE_LDS(1), s,
+                           d_in, (u64)n, chunk, w.nchunks, tab, w.scratch, w.stride, w.scratch2, w.stride2, d_clen, w.gsum);
     else if (nstreams == 2)
         TRC_LAUNCH_TIMED((trc_rcs_enc_kernel<2, 0>), dim3(w.ngroups), dim3(64), 1024 + RCS_WAVE_LDS(2), s,
                            d_in, (u64)n, chunk, w.nchunks, tab, w.scratch, w.stride, w.scratch2, w.stride2, d_clen, w.gsum);
@@ -283,6 +500,15 @@ void trc_launch_rcs_dec(int nstreams, const uint8_t *d_payload, const uint32_t *
                         const TrcWork &w, uint8_t *d_out, hipStream_t s)
 {
     if (nstreams == 1)      launch_dec<1, 0>(d_payload, d_clen, n, chunk, w, d_out, s);
+    else if (nstreams == 2 && rcs2_pair()) {
+        const u32 nwaves = (w.nchunks + 31u) / 32u;
+        TRC_RAISE_LDS_ONCE(trc_rcs2p_dec_kernel, 32768 + 1024 + 14u * RCS_WAVE_LDS(1));
+        u32 wpb = (nwaves + 255u) / 256u;
+        wpb = wpb < 1u ? 1u : wpb > 14u ? 14u : wpb;
+        TRC_LAUNCH_TIMED(trc_rcs2p_dec_kernel, dim3((nwaves + wpb - 1) / wpb), dim3(64 * wpb), 32768 + 1024 + wpb * RCS_WAVE_LDS(1), s,
+                           d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, w.tables + TRC_TAB_LUT,
+                           (const u32 *)(w.tables + TRC_TAB_DEC), d_out);
+    }
     else if (nstreams == 2) launch_dec<2, 0>(d_payload, d_clen, n, chunk, w, d_out, s);
     else                    launch_dec<1, 1>(d_payload, d_clen, n, chunk, w, d_out, s);
 }
