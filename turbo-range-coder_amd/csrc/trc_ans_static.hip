@@ -292,10 +292,18 @@ __device__ __forceinline__ void ans_get_pair(u32 &s0, u32 &s1, u32 lbase, u32 &h
     const u32 dw0 = *(const trc_lds_u32 *)(uintptr_t)a;
     const u32 dw1 = *(const trc_lds_u32 *)(uintptr_t)(a + 256u);
     const u32 sl0 = s0 & (TRC_PROB_ONE - 1), sl1 = s1 & (TRC_PROB_ONE - 1);
+#ifdef TRC_DEC_ABL_NOLUT                                        // timing ablations (results wrong by construction)
+    x0 = sl0 >> 7; x1 = sl1 >> 7;
+#else
     x0 = *(const trc_lds_u8 *)(uintptr_t)(DEC_LDS_LUT + sl0);
     x1 = *(const trc_lds_u8 *)(uintptr_t)(DEC_LDS_LUT + sl1);
+#endif
+#ifdef TRC_DEC_ABL_NODTAB
+    const trc_v2u e0 = { x0 + 1u, sl0 }, e1 = { x1 + 1u, sl1 };
+#else
     const trc_v2u e0 = *(const trc_lds_u64 *)(uintptr_t)(DEC_LDS_DTAB + (x0 << 3));
     const trc_v2u e1 = *(const trc_lds_u64 *)(uintptr_t)(DEC_LDS_DTAB + (x1 << 3));
+#endif
     u32 t0 = __umul24(e0.x, s0 >> TRC_PROB_BITS) + e0.y + sl0;
     u32 t1 = __umul24(e1.x, s1 >> TRC_PROB_BITS) + e1.y + sl1;
     const u32 w32 = __builtin_amdgcn_alignbit(dw1, dw0, hc << 4);                        // units hc, hc + 1 (the shift uses 5 bits: 16 x parity)
@@ -351,6 +359,9 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
     }
     __syncthreads();
     if (!valid) return;
+#ifdef TRC_DEC_ABL_EXIT
+    return;
+#endif
 
     const u32 cl = alive ? trc_min(clen[c], len) : 0u;        // a directory entry above the chunk length (corrupt input) reads as raw
     const u32 ex = trc_wave_incl_scan(cl) - cl;
@@ -373,6 +384,9 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
     const u32 body4 = len & ~3u;
     u8 *dst = out + (u64)c * chunk;
     const u32 rbase = (u32)(uintptr_t)(si.rings - smem) + AnsStreamIn::ra(lane, 0);    // this lane's ring, as an LDS byte address
+#ifdef TRC_DEC_ABL_EXIT2
+    if (chunk) return;
+#endif
     u32 sel_lo = 0x05040100u, sel_hi = 0x05040302u;            // byte selectors of the pair step's permutes (VGPR operands: VCC takes the one constant-bus slot)
     asm volatile("" : "+v"(sel_lo), "+v"(sel_hi));
     for (u32 s = 0; s < S; s++) {

@@ -394,7 +394,10 @@ struct StreamInT {
     __device__ __forceinline__ u32 avail() const { return lbytes - rpos; }
     __device__ __forceinline__ void skip_if(bool take) { rpos += take ? 4u : 0u; }
 
-    // first fill: every live lane fetches its own first 128 bytes (8 independent loads, one round trip)
+    // first fill: 128 bytes per live lane, fetched by QUADS (round 3): helper quad q takes lanes q, 16 + q, 32 + q, 48 + q in
+    // turn, its four lanes 16 bytes each of a 64-byte segment -- the texture-address unit sees one 64-byte request where the
+    // per-lane form (every lane its own eight 16-byte loads at 2-byte alignment) gave it four or more: 6.3 -> ~2 us at the
+    // start of every decoder wave (ablation in profiles/r03_notes.md).  Eight loads in flight, one round trip.
     __device__ __forceinline__ void prime(bool alive)
     {
         rpos = 0; lbytes = 0; infl = 0; mineA = mineB = false; hokA = hokB = false;
@@ -405,19 +408,27 @@ struct StreamInT {
             srel = (u32)(soff - wbase);
         }
         hvA = hvB = make_uint4(0, 0, 0, 0); hdA = hdB = 0;
-        if (alive) {
-            uint4 v[8];
+        const u64 amask = __ballot(alive);
+        if (!amask) return;
+        const u32 lane = trc_lane(), q = lane >> 2, part = lane & 3u;
+        uint4 v[8];
+        u32 at[4];
 #pragma unroll
-            for (int i = 0; i < 8; i++) v[i] = trc_ld16_a2(gbase + soff + 16 * i);
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                *(u32 *)(rings + ra(trc_lane(), 16u * i)) = v[i].x;      *(u32 *)(rings + ra(trc_lane(), 16u * i + 4u)) = v[i].y;
-                *(u32 *)(rings + ra(trc_lane(), 16u * i + 8u)) = v[i].z; *(u32 *)(rings + ra(trc_lane(), 16u * i + 12u)) = v[i].w;
-            }
-            *(u32 *)(rings + ra(trc_lane(), TRC_SRING)) = v[0].x;          // guard (see put_piece)
-            lbytes = TRC_SRING;   // (starting odd lanes with half a ring, to spread the lanes' refill requests over the periods, measured
-                                  // 1-2 % slower at chunk 512 and 2 % faster at 1024: not kept, profiles/r03_notes.md)
+        for (u32 g = 0; g < 4; g++) {
+            const u32 j = g * 16u + q;                          // the lane this quad serves in turn g
+            const u32 sr = (u32)__shfl((int)srel, (int)j, 64);
+            at[g] = ((amask >> j) & 1u) ? rw + ra(j, 0) + part * PIECE_STEP : ~0u;
+            const u8 *src = gbase + wbase + sr + (part << 4);
+            v[2 * g] = make_uint4(0, 0, 0, 0); v[2 * g + 1] = v[2 * g];
+            if (at[g] != ~0u) { v[2 * g] = trc_ld16_a2(src); v[2 * g + 1] = trc_ld16_a2(src + TRC_SEG); }
         }
+#pragma unroll
+        for (u32 g = 0; g < 4; g++)
+            if (at[g] != ~0u) {
+                put_piece(at[g] | (part == 0u ? 1u : 0u), v[2 * g]);               // ring offset 0: its first dword is mirrored behind the ring
+                put_piece(at[g] + (ra(0, TRC_SEG) - ra(0, 0)), v[2 * g + 1]);      // ring offset 64
+            }
+        if (alive) lbytes = TRC_SRING;
     }
     // Round 3: a refill round costs ONE cross-lane round trip and the landing of a piece one address operation.
     //   * the up to 16 lanes picked in a round PUSH what their helpers need -- the source offset of the segment and the LDS
