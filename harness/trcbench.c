@@ -20,6 +20,7 @@
 #include "../include/anscdf.h"
 
 int trc_set_chunk(unsigned chunk);           /* from include/trc_hip.h */
+int trc_host_pin(void *p, size_t len);       /* page-lock a buffer: host-pointer calls then DMA straight from / to it */
 const char *trc_last_error(void);
 
 static int g_elem = 0;      /* element bytes of integer input (2 / 4), 0 = bytes */
@@ -145,12 +146,13 @@ static int bench(unsigned char *in, size_t n, unsigned char *out, unsigned char 
 int main(int argc, char **argv)
 {
     const char *ids = "1,42,44,45,46,47,56,65,79", *file = 0;
-    int runs = 3, kind = -1;
+    int runs = 3, kind = -1, pin = 0;
     size_t n = 0;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "-e") && i + 1 < argc) ids = argv[++i];
         else if (!strcmp(argv[i], "-I") && i + 1 < argc) runs = atoi(argv[++i]);
         else if (!strcmp(argv[i], "-c") && i + 1 < argc) { if (trc_set_chunk((unsigned)atoi(argv[++i]))) return 2; }
+        else if (!strcmp(argv[i], "--pin")) pin = 1;   /* page-lock in / out / cpy once (what a caller that reuses its buffers would do) */
         else if (!strcmp(argv[i], "--zipf") && i + 1 < argc) { kind = 0; n = strtoull(argv[++i], 0, 10); }
         else if (!strcmp(argv[i], "--text") && i + 1 < argc) { kind = 1; n = strtoull(argv[++i], 0, 10); }
         else if (!strcmp(argv[i], "--uniform") && i + 1 < argc) { kind = 2; n = strtoull(argv[++i], 0, 10); }
@@ -168,15 +170,17 @@ int main(int argc, char **argv)
         fclose(f);
         unsigned char *in = malloc(n * 4 / 3 + 1024); memcpy(in, tmp, n); free(tmp);
         unsigned char *out = malloc(n * 4 / 3 + 1024), *cpy = malloc(n * 4 / 3 + 1024);
+        if (pin && (trc_host_pin(in, n * 4 / 3 + 1024) || trc_host_pin(out, n * 4 / 3 + 1024) || trc_host_pin(cpy, n * 4 / 3 + 1024))) { fprintf(stderr, "--pin: %s\n", trc_last_error()); return 2; }
         printf("file %s: %zu bytes\n      C Size  ratio%%    E MB/s     D MB/s   Name (host pointers: PCIe included)\n", file, n);
         int bad = 0; char *s = strdup(ids), *sv = 0;       /* strtok_r: the HIP runtime uses strtok itself while initialising */
         for (char *t = strtok_r(s, ",", &sv); t; t = strtok_r(0, ",", &sv)) bad |= bench(in, n, out, cpy, atoi(t), runs);
         return bad;
     }
-    if (kind < 0 || !n) { fprintf(stderr, "usage: trcbench [-e ids] [-I runs] [-c chunk] (file | --zipf N | --text N | --uniform N | --nibble N | --int16 N | --int32 N)\n"); return 2; }
+    if (kind < 0 || !n) { fprintf(stderr, "usage: trcbench [-e ids] [-I runs] [-c chunk] [--pin] (file | --zipf N | --text N | --uniform N | --nibble N | --int16 N | --int32 N)\n"); return 2; }
     unsigned char *in = malloc(n * 4 / 3 + 1024), *out = malloc(n * 4 / 3 + 1024), *cpy = malloc(n * 4 / 3 + 1024);
     gen(in, n, kind);
-    printf("synthetic kind %d: %zu bytes\n      C Size  ratio%%    E MB/s     D MB/s   Name (host pointers: PCIe included)\n", kind, n);
+    if (pin && (trc_host_pin(in, n * 4 / 3 + 1024) || trc_host_pin(out, n * 4 / 3 + 1024) || trc_host_pin(cpy, n * 4 / 3 + 1024))) { fprintf(stderr, "--pin: %s\n", trc_last_error()); return 2; }
+    printf("synthetic kind %d: %zu bytes%s\n      C Size  ratio%%    E MB/s     D MB/s   Name (host pointers: PCIe included)\n", kind, n, pin ? " (buffers page-locked)" : "");
     int bad = 0; char *s = strdup(ids), *sv = 0;
     for (char *t = strtok_r(s, ",", &sv); t; t = strtok_r(0, ",", &sv)) bad |= bench(in, n, out, cpy, atoi(t), runs);
     return bad;

@@ -183,6 +183,13 @@ size_t trc_container_bound(size_t n, uint32_t chunk);
 size_t trc_encode_host(int codec, const void *in, size_t n, uint32_t chunk, void *out, size_t outcap,
                        const uint16_t *cdf, unsigned cdfnum);
 
+/* Host-pointer calls and page-locked memory.  A pageable caller buffer travels through pinned staging slots (copy threads
+ * + DMA: 38-40 GB/s per direction on the MI355X box); a page-locked one -- hipHostMalloc, or registered with the pair
+ * below -- is read / written by DMA directly, detected per call with hipPointerGetAttributes.  Registration costs ~55 us
+ * per MB, so it pays for buffers that are reused, as the reference harness reuses (in, out) for every timed repetition. */
+int trc_host_pin(void *p, size_t len);
+int trc_host_unpin(void *p);
+
 /* Validate a TRC1 container held in buf[0..buflen) BEFORE handing it to a reference-named decoder: those prototypes
  * carry no input length, so a caller reading untrusted files must check that everything the decoder will touch lies
  * inside its buffer.  Checks header fields, codec (0 = any), the original length (outlen, (size_t)-1 = any), that the

@@ -182,6 +182,11 @@ def test_c_harness_links_and_roundtrips(torch_cuda):
         assert "MISMATCH" not in r.stdout and "failed" not in r.stdout, r.stdout
         assert r.stdout.count(":") >= 17, r.stdout            # every requested id printed its row
         assert ("nibble" in r.stdout) == (args[0] == "--nibble")   # values 0..15 route ids 46/47/56-58 to the one-table coders
+    # page-locked caller buffers (--pin: trc_host_pin): the host-pointer calls DMA straight from / to them, no staging copies
+    r = subprocess.run([exe, "-I", "2", "--pin", "-e", "1,42,45,46,56,65,79", "--text", "20000003"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "MISMATCH" not in r.stdout and "failed" not in r.stdout and "page-locked" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([exe, "-I", "1", "--pin", "-e", "42,65", "--uniform", "3000001"], capture_output=True, text=True, timeout=300)   # raw return through pinned `out`
+    assert r.returncode == 0 and "MISMATCH" not in r.stdout and "failed" not in r.stdout, r.stdout + r.stderr
     for args in (["--int16", "2000000"], ["--int32", "4000000"]):        # integer series: the Turbo-VLC coders
         r = subprocess.run([exe, "-I", "1", "-e", "50,52,53,60,61,62,63"] + args, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "MISMATCH" not in r.stdout and "failed" not in r.stdout, r.stdout + r.stderr

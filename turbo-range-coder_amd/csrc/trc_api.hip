@@ -551,6 +551,21 @@ int grow_pins(HostCtx &c, size_t need)
     c.cap_pin = need;
     return TRC_OK;
 }
+// Is [p, p + len) page-locked host memory the GPU can address (hipHostMalloc, or registered with hipHostRegister /
+// trc_host_pin)?  Then a host-pointer call moves its bytes by DMA straight from / to the caller's buffer; pageable
+// buffers go through the pinned staging slots and the copy threads.
+bool host_is_pinned(const void *p, size_t len)
+{
+    static const bool off = getenv("TRC_HOST_NO_DIRECT") != nullptr;      // tuning aid: always stage
+    if (off || !p || !len) return false;
+    const char *ends[2] = { (const char *)p, (const char *)p + len - 1 };
+    for (const char *q : ends) {
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (a.type != hipMemoryTypeHost) return false;
+    }
+    return true;
+}
 // cdfnum = index of the terminating 1<<15 (cdf is strictly increasing from 0)
 int host_cdfnum(const cdf_t *cdf)
 {
@@ -625,8 +640,10 @@ static size_t host_encode(int codec, const unsigned char *in, size_t inlen, unsi
     const size_t per = slice_plan(chunk, nchunks, sc), nsl = sc.size() - 1;
     const size_t slice_bytes = per * (size_t)chunk;
     const size_t wb = trc_work_bytes(codec, slice_bytes < inlen ? slice_bytes : inlen, chunk);
+    // page-locked caller buffers are read / written by DMA directly (no staging copy on that side)
+    const bool in_direct = host_is_pinned(in, inlen), out_direct = host_is_pinned(out, outcap ? outcap : inlen);
     if (grow(&c.d_in, &c.cap_in, inlen) || grow(&c.d_cont, &c.cap_cont, hdrsz + dir + inlen + 64) || grow(&c.d_work, &c.cap_work, wb) ||
-        grow_pins(c, slice_bytes + 4 * per + 64)) return 0;
+        ((!in_direct || !out_direct) && grow_pins(c, slice_bytes + 4 * per + 64))) return 0;
     uint16_t *d_cdf = (uint16_t *)c.d_small;
     uint64_t *d_tot = (uint64_t *)(c.d_small + 2048);
     uint32_t *d_clen = (uint32_t *)(c.d_cont + hdrsz);
@@ -648,6 +665,10 @@ static size_t host_encode(int codec, const unsigned char *in, size_t inlen, unsi
     auto put_in = [&](size_t i) -> bool {                                   // stage + H2D of slice i
         const int k = (int)(i % TRC_NSLOT);
         const size_t o = slice_off(i), l = slice_len(i);
+        if (in_direct) {
+            if (hipMemcpyAsync(c.d_in + o, in + o, l, hipMemcpyHostToDevice, c.s_in) != hipSuccess) return false;
+            return hipEventRecord(c.ev_in[k], c.s_in) == hipSuccess;
+        }
         if (i >= TRC_NSLOT && hipEventSynchronize(c.ev_in[k]) != hipSuccess) return false;   // slot free: its last H2D is done
         c.pool_in->copy(c.pin_in[k], in + o, l);
         if (hipMemcpyAsync(c.d_in + o, c.pin_in[k], l, hipMemcpyHostToDevice, c.s_in) != hipSuccess) return false;
@@ -656,6 +677,8 @@ static size_t host_encode(int codec, const unsigned char *in, size_t inlen, unsi
     struct Pending { size_t i, pos, tot; bool live; } pend = { 0, 0, 0, false };
     auto fetch = [&](Pending &p) -> bool {                                  // unstage slice p.i (its D2H was enqueued earlier): starts the copy, returns
         if (!p.live) return true;
+        p.live = false;
+        if (out_direct) return true;                                        // its D2H writes `out` itself; the stream is drained at the end
         const int k = (int)(p.i % TRC_NSLOT);
         if (hipEventSynchronize(c.ev_out[k]) != hipSuccess) return false;
         const size_t nc = sc[p.i + 1] - sc[p.i];
@@ -683,8 +706,13 @@ static size_t host_encode(int codec, const unsigned char *in, size_t inlen, unsi
         const size_t nc = sc[i + 1] - c0;
         // (slot k's previous content, slice i-3, left it two fetches ago: start() waits for the copy before it)
         HCHK(hipStreamWaitEvent(c.s_out, c.ev_k[k], 0));
-        HCHK(hipMemcpyAsync(c.pin_out[k], d_clen + c0, 4 * nc, hipMemcpyDeviceToHost, c.s_out));
-        HCHK(hipMemcpyAsync(c.pin_out[k] + 4 * per, d_payload + dpos, tot, hipMemcpyDeviceToHost, c.s_out));
+        if (out_direct) {
+            HCHK(hipMemcpyAsync(out + hdrsz + 4 * c0, d_clen + c0, 4 * nc, hipMemcpyDeviceToHost, c.s_out));
+            HCHK(hipMemcpyAsync(out + hdrsz + dir + ppos, d_payload + dpos, tot, hipMemcpyDeviceToHost, c.s_out));
+        } else {
+            HCHK(hipMemcpyAsync(c.pin_out[k], d_clen + c0, 4 * nc, hipMemcpyDeviceToHost, c.s_out));
+            HCHK(hipMemcpyAsync(c.pin_out[k] + 4 * per, d_payload + dpos, tot, hipMemcpyDeviceToHost, c.s_out));
+        }
         HCHK(hipEventRecord(c.ev_out[k], c.s_out));
         pend = { i, ppos, tot, true };
         ppos += tot;
@@ -693,6 +721,7 @@ static size_t host_encode(int codec, const unsigned char *in, size_t inlen, unsi
     if (!fetch(pend)) { fail(TRC_E_HIP, "host encode: fetch failed"); return 0; }
     c.pool_out->wait();
     HCHK(hipStreamSynchronize(c.s_in));
+    if (out_direct) HCHK(hipStreamSynchronize(c.s_out));
     guard.ok = true;                                                        // everything of this call has landed
     if (raw) { memcpy(out, in, inlen); return inlen; }                      // reference convention: == inlen => raw
     trc_container_hdr h;
@@ -737,8 +766,10 @@ static size_t host_decode(int codec, const unsigned char *in, size_t outlen, uns
     const size_t per = slice_plan(chunk, nchunks, sc), nsl = sc.size() - 1;
     const size_t slice_bytes = per * (size_t)chunk;
     const size_t wb = trc_work_bytes(codec, slice_bytes < outlen ? slice_bytes : outlen, chunk);
+    // page-locked caller buffers are read / written by DMA directly (no staging copy on that side)
+    const bool in_direct = host_is_pinned(in, hdrsz + dir + (size_t)h.payload), out_direct = host_is_pinned(out, outlen);
     if (grow(&c.d_in, &c.cap_in, outlen) || grow(&c.d_cont, &c.cap_cont, hdrsz + dir + outlen + 64 + 2 * nsl) || grow(&c.d_work, &c.cap_work, wb) ||
-        grow_pins(c, slice_bytes + 4 * per + 64)) return 0;
+        ((!in_direct || !out_direct) && grow_pins(c, slice_bytes + 4 * per + 64))) return 0;
     uint16_t *d_cdf = (uint16_t *)c.d_small;
     uint32_t *d_clen = (uint32_t *)(c.d_cont + hdrsz);
     uint8_t *d_payload = c.d_cont + hdrsz + dir;
@@ -765,6 +796,11 @@ static size_t host_decode(int codec, const unsigned char *in, size_t outlen, uns
     auto put_in = [&](size_t i) -> bool {                                   // stage + H2D of slice i's directory and payload
         const int k = (int)(i % TRC_NSLOT);
         const size_t c0 = sc[i], nc = sc[i + 1] - c0, pl = pstart[i + 1] - pstart[i];
+        if (in_direct) {
+            if (hipMemcpyAsync(d_clen + c0, in + hdrsz + 4 * c0, 4 * nc, hipMemcpyHostToDevice, c.s_in) != hipSuccess) return false;
+            if (hipMemcpyAsync(d_payload + ((pstart[i] + 1) & ~(size_t)1) + 2 * i, in + hdrsz + dir + pstart[i], pl, hipMemcpyHostToDevice, c.s_in) != hipSuccess) return false;
+            return hipEventRecord(c.ev_in[k], c.s_in) == hipSuccess;
+        }
         if (i >= TRC_NSLOT && hipEventSynchronize(c.ev_in[k]) != hipSuccess) return false;
         memcpy(c.pin_in[k], in + hdrsz + 4 * c0, 4 * nc);
         c.pool_in->copy(c.pin_in[k] + 4 * per, in + hdrsz + dir + pstart[i], pl);
@@ -776,10 +812,11 @@ static size_t host_decode(int codec, const unsigned char *in, size_t outlen, uns
     struct Pending { size_t i; bool live; } pend = { 0, false };
     auto fetch = [&](Pending &p) -> bool {
         if (!p.live) return true;
+        p.live = false;
+        if (out_direct) return true;                                        // its D2H wrote `out` itself; the stream is drained at the end
         const int k = (int)(p.i % TRC_NSLOT);
         if (hipEventSynchronize(c.ev_out[k]) != hipSuccess) return false;
         c.pool_out->start(out + slice_off(p.i), c.pin_out[k], slice_len(p.i));
-        p.live = false;
         return true;
     };
     if (!put_in(0) || (nsl > 1 && !put_in(1))) { fail(TRC_E_HIP, "host decode: staging failed"); return 0; }   // two slices ahead, as in host_encode
@@ -794,7 +831,7 @@ static size_t host_decode(int codec, const unsigned char *in, size_t outlen, uns
         // slice i's way back is queued BEFORE slice i-1 is copied out of its staging slot (different slots): the D2H
         // engine never waits for the host
         HCHK(hipStreamWaitEvent(c.s_out, c.ev_k[k], 0));
-        HCHK(hipMemcpyAsync(c.pin_out[k], c.d_in + o, l, hipMemcpyDeviceToHost, c.s_out));
+        HCHK(hipMemcpyAsync(out_direct ? out + o : c.pin_out[k], c.d_in + o, l, hipMemcpyDeviceToHost, c.s_out));
         HCHK(hipEventRecord(c.ev_out[k], c.s_out));
         if (!fetch(pend)) { fail(TRC_E_HIP, "host decode: fetch failed"); return 0; }                         // slice i-1: out-pool copies it to `out` ...
         if (i + 2 < nsl && !put_in(i + 2)) { fail(TRC_E_HIP, "host decode: staging failed"); return 0; }   // ... while slice i+2 is staged by the in-pool
@@ -803,8 +840,26 @@ static size_t host_decode(int codec, const unsigned char *in, size_t outlen, uns
     if (!fetch(pend)) { fail(TRC_E_HIP, "host decode: fetch failed"); return 0; }
     c.pool_out->wait();
     HCHK(hipStreamSynchronize(c.s_in));
+    if (out_direct) HCHK(hipStreamSynchronize(c.s_out));
     guard.ok = true;
     return outlen;
+}
+
+// Page-lock a caller's buffer for the host-pointer calls (hipHostRegister / hipHostUnregister behind plain C: a harness needs
+// no HIP header).  Registration costs ~55 us per MB: once per buffer, not per call.
+extern "C" int trc_host_pin(void *p, size_t len)
+{
+    if (!p || !len) return fail(TRC_E_ARG, "host_pin: bad arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(TRC_E_NODEV, "no HIP device");
+    HIPCHK(hipHostRegister(p, len, hipHostRegisterDefault));
+    return TRC_OK;
+}
+extern "C" int trc_host_unpin(void *p)
+{
+    if (!p) return fail(TRC_E_ARG, "host_unpin: bad arguments");
+    HIPCHK(hipHostUnregister(p));
+    return TRC_OK;
 }
 
 extern "C" size_t trc_container_bound(size_t n, uint32_t chunk)
