@@ -8,7 +8,7 @@ i=0
 for CT in "$@"; do
   i=$((i+1))
   rm -rf gpurun_out/pmc_${TAG}_$i
-  (cd /tmp && timeout 600 rocprofv3 --pmc $CT --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_${TAG}_$i -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu $BARGS > $GRAFT_REPO_ROOT/gpurun_out/pmc_${TAG}_$i.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --pmc $CT --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_${TAG}_$i -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu --no-beyond $BARGS > $GRAFT_REPO_ROOT/gpurun_out/pmc_${TAG}_$i.log 2>&1)
   f=$(find gpurun_out/pmc_${TAG}_$i -name "*counter_collection.csv" | head -1)
   echo "== pass $i: $CT -> $f"
   [ -n "$f" ] && python scripts/pmc_summary.py "$f"

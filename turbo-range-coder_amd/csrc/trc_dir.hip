@@ -227,34 +227,59 @@ void trc_launch_gather(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcW
 // ---------------------------------------------------------------------------------------------
 // cdfini on device (reference: rccdf.c:50-68).  Histogram with per-wave LDS privatisation, then
 // one wave builds the CDF with the reference's normalisation rule.
-// Histogram: 16 private copies per workgroup (one per group of 16 lanes: lane & 15 ... chosen so that the lanes of one
-// LDS-atomic instruction spread over the copies), 16 KiB of LDS.  Text puts 17 % of all bytes on one symbol: with one copy
-// per wave (round 1) up to a dozen lanes of every atomic hit the same counter and serialised -- 66 us for 100 MB.
-#define TRC_HIST_COPIES 16
+// Histogram (round 3): every LANE counts into its own column -- 128 rows (bins 2r | 2r+1 packed as two 16-bit halves of a
+// dword) x 64 lanes per wave, 32 KiB of LDS per wave, a workgroup of four waves per CU.  The update is one ds_add_u32 whose 64
+// lanes touch 64 different dwords in two conflict-free groups (bank = lane mod 32): no two lanes ever meet on a counter, whatever
+// the data (rounds 1-2 used LDS atomics on 1 / 16 shared copies per workgroup: text puts 17 % of all bytes on one symbol and
+// the lanes of an instruction serialised on it -- 66 / 56 us for 100 MB).  A lane counts at most 65 520 bytes between two
+// reductions, so the halves cannot overflow.
+#define TRC_HIST_WAVE_LDS (128u * 64u * 4u)
+#define TRC_HIST_ROUND_VECS 4095u                                 // uint4 per lane per round: 65 520 bytes < 2^16
 __global__ __launch_bounds__(256) void trc_hist_kernel(const u8 *__restrict__ in, u64 n, u64 *__restrict__ hist)
 {
-    __shared__ u32 h[TRC_HIST_COPIES][256];
-    const u32 tid = threadIdx.x;
-    u32 *mine = h[tid & (TRC_HIST_COPIES - 1)];
-    for (u32 i = tid; i < TRC_HIST_COPIES * 256; i += 256) (&h[0][0])[i] = 0;
-    __syncthreads();
-    const u64 nvec = n >> 4;
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    typedef __attribute__((address_space(3))) u32 lds_u32;
+    const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    u32 *mine = (u32 *)(smem + wv * TRC_HIST_WAVE_LDS);            // [128 rows][64 lanes]
+    u64 *tot = (u64 *)(smem + 4u * TRC_HIST_WAVE_LDS);             // [256] per workgroup
+    const u32 col = trc_lds_addr(mine) + lane * 4u;
+    tot[tid] = 0;
+    const u64 nvec = n >> 4, stride = (u64)gridDim.x * 256;
     const uint4 *v = (const uint4 *)in;
-    for (u64 i = (u64)blockIdx.x * 256 + tid; i < nvec; i += (u64)gridDim.x * 256) {
-        const uint4 q = v[i];
-        const u32 w[4] = { q.x, q.y, q.z, q.w };
+    auto count = [&](u32 w) {                                       // four bytes -> four ds_add_u32 on this lane's column
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            atomicAdd(&mine[w[k] & 255], 1u);         atomicAdd(&mine[(w[k] >> 8) & 255], 1u);
-            atomicAdd(&mine[(w[k] >> 16) & 255], 1u); atomicAdd(&mine[w[k] >> 24], 1u);
+            const u32 b = (w >> (8 * k)) & 255u;
+            __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)(col + (b >> 1) * 256u), (b & 1u) ? 0x10000u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
+    };
+    for (u64 r0 = 0; r0 == 0 || r0 < nvec; r0 += stride * TRC_HIST_ROUND_VECS) {      // (r0 is uniform: every wave runs every round)
+        for (u32 r = lane; r < 128u * 64u; r += 64u) mine[r] = 0;  // own wave's counters (row-major: lanes write consecutive dwords)
+        u64 i = r0 + (u64)blockIdx.x * 256 + tid;
+        u32 left = TRC_HIST_ROUND_VECS;
+        for (; left >= 4u && i + 3 * stride < nvec; left -= 4u, i += 4 * stride) {      // four loads in flight per lane
+            const uint4 q0 = v[i], q1 = v[i + stride], q2 = v[i + 2 * stride], q3 = v[i + 3 * stride];
+            count(q0.x); count(q0.y); count(q0.z); count(q0.w); count(q1.x); count(q1.y); count(q1.z); count(q1.w);
+            count(q2.x); count(q2.y); count(q2.z); count(q2.w); count(q3.x); count(q3.y); count(q3.z); count(q3.w);
+        }
+        for (; left && i < nvec; left--, i += stride) { const uint4 q = v[i]; count(q.x); count(q.y); count(q.z); count(q.w); }
+        if (r0 == 0 && blockIdx.x == 0 && wv == 0)                  // the input's last n % 16 bytes, once
+            for (u64 t = (nvec << 4) + lane; t < n; t += 64) { const u32 b = in[t]; mine[(b >> 1) * 64u + lane] += (b & 1u) ? 0x10000u : 1u; }
+        // reduce this wave's columns: lane l sums rows l and l + 64, walking the columns rotated by l (bank = column mod 32)
+        u32 lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
+        for (u32 c = 0; c < 64u; c++) {
+            const u32 cc = (c + lane) & 63u;
+            const u32 a = mine[lane * 64u + cc], b = mine[(lane + 64u) * 64u + cc];
+            lo0 += a & 0xffffu; hi0 += a >> 16; lo1 += b & 0xffffu; hi1 += b >> 16;
+        }
+        __syncthreads();                                            // (first round: orders the zeroing of tot[])
+        atomicAdd((unsigned long long *)&tot[2 * lane], (unsigned long long)lo0);
+        atomicAdd((unsigned long long *)&tot[2 * lane + 1], (unsigned long long)hi0);
+        atomicAdd((unsigned long long *)&tot[2 * (lane + 64)], (unsigned long long)lo1);
+        atomicAdd((unsigned long long *)&tot[2 * (lane + 64) + 1], (unsigned long long)hi1);
     }
-    if (blockIdx.x == 0) for (u64 i = (nvec << 4) + tid; i < n; i += 256) atomicAdd(&mine[in[i]], 1u);
     __syncthreads();
-    u32 t = 0;
-#pragma unroll
-    for (int c = 0; c < TRC_HIST_COPIES; c++) t += h[c][tid];
-    if (t) atomicAdd((unsigned long long *)&hist[tid], (unsigned long long)t);
+    if (tot[tid]) atomicAdd((unsigned long long *)&hist[tid], (unsigned long long)tot[tid]);
 }
 __global__ __launch_bounds__(256) void trc_cdf_build_kernel(const u64 *__restrict__ hist, u64 n, u32 cdfnum,
                                                             u16 *__restrict__ cdf, int *__restrict__ status)
@@ -287,8 +312,11 @@ void trc_launch_hist(const uint8_t *d_in, size_t n, uint64_t *d_hist, hipStream_
     (void)hipMemsetAsync(d_hist, 0, 256 * sizeof(uint64_t), s);
     u64 blocks = ((n >> 4) + 255) / 256;
     if (blocks < 1) blocks = 1;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(trc_hist_kernel, dim3((u32)blocks), dim3(256), 0, s, d_in, (u64)n, d_hist);
+    if (blocks > 256) blocks = 256;                             // one workgroup (4 x 32 KiB of counters) per CU
+    const size_t sm = 4u * TRC_HIST_WAVE_LDS + 256u * sizeof(u64);
+    static bool raised = false;
+    if (!raised) { (void)hipFuncSetAttribute((const void *)trc_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); raised = true; }
+    hipLaunchKernelGGL(trc_hist_kernel, dim3((u32)blocks), dim3(256), sm, s, d_in, (u64)n, d_hist);
 }
 void trc_launch_cdf_build(const uint64_t *d_hist, size_t n_total, uint16_t *d_cdf, unsigned cdfnum, int32_t *d_status, hipStream_t s)
 {
