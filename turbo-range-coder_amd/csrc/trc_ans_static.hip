@@ -284,14 +284,16 @@ __device__ __forceinline__ u32 ans_get(u32 &st, AnsStreamIn &si)
     si.rpos += rn ? 2u : 0u;
     return x;
 }
-// a pair of symbols, s0 first; hc = halfword cursor into the lane's ring (lbase = LDS address of its dword 0)
-__device__ __forceinline__ void ans_get_pair(u32 &s0, u32 &s1, u32 lbase, u32 &hc, u32 &x0, u32 &x1, u32 sel_lo, u32 sel_hi)
+// a pair of symbols, s0 first; hc = halfword cursor into the lane's ring (lbase = LDS address of its dword 0).
+// sl0 / sl1 travel with the states: the slots (state & 0x7fff) of the NEXT pair are the last two instructions of the
+// renormalisation block -- left to the compiler they followed the block, behind the wait state it puts after an asm
+// statement whose outputs the next VALU instruction reads (an s_nop per pair).
+__device__ __forceinline__ void ans_get_pair(u32 &s0, u32 &s1, u32 &sl0, u32 &sl1, u32 lbase, u32 &hc, u32 &x0, u32 &x1, u32 sel_lo, u32 sel_hi)
 {
     u32 a;
     asm("v_bfe_u32 %0, %1, 1, 5\n\tv_lshl_add_u32 %0, %0, 8, %2" : "=&v"(a) : "v"(hc), "v"(lbase));
     const u32 dw0 = *(const trc_lds_u32 *)(uintptr_t)a;
     const u32 dw1 = *(const trc_lds_u32 *)(uintptr_t)(a + 256u);
-    const u32 sl0 = s0 & (TRC_PROB_ONE - 1), sl1 = s1 & (TRC_PROB_ONE - 1);
 #ifdef TRC_DEC_ABL_NOLUT                                        // timing ablations (results wrong by construction)
     x0 = sl0 >> 7; x1 = sl1 >> 7;
 #else
@@ -317,8 +319,11 @@ __device__ __forceinline__ void ans_get_pair(u32 &s0, u32 &s1, u32 lbase, u32 &h
         "v_addc_co_u32_e64 %[hc], %[cy], 0, %[hc], vcc\n\t"
         "v_perm_b32 %[c1], %[t1], %[w], %[sl]\n\t"
         "v_cndmask_b32_e64 %[t1], %[t1], %[c1], %[m1]\n\t"
-        "v_addc_co_u32_e64 %[hc], %[cy], 0, %[hc], %[m1]"
-        : [t0] "+v"(t0), [t1] "+v"(t1), [hc] "+v"(hc), [c0] "=&v"(c0), [c1] "=&v"(c1), [sl] "=&v"(sl), [m1] "=&s"(m1), [cy] "=&s"(cy)
+        "v_addc_co_u32_e64 %[hc], %[cy], 0, %[hc], %[m1]\n\t"
+        "v_and_b32_e32 %[n0], 0x7fff, %[t0]\n\t"
+        "v_and_b32_e32 %[n1], 0x7fff, %[t1]"
+        : [t0] "+v"(t0), [t1] "+v"(t1), [hc] "+v"(hc), [c0] "=&v"(c0), [c1] "=&v"(c1), [sl] "=&v"(sl), [m1] "=&s"(m1), [cy] "=&s"(cy),
+          [n0] "=&v"(sl0), [n1] "=&v"(sl1)
         : [w] "v"(w32), [low] "s"(TRC_ANS_LOW), [slo] "v"(sel_lo), [shi] "v"(sel_hi) : "vcc");
     s0 = t0; s1 = t1;
 }
@@ -405,6 +410,7 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
             if (coded && p0 + 16u <= len) {
                 u32 w[4];
                 u32 hc = si.rpos >> 1;
+                u32 slb = sb & (TRC_PROB_ONE - 1), sla = sa & (TRC_PROB_ONE - 1);
 #ifdef TRC_DEC_ABL_NOSYMS
                 w[0] = sa; w[1] = sb; w[2] = hc; w[3] = p0; hc += 5;
                 for (int d = 0; d < 0; d++) {
@@ -413,8 +419,8 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
                 for (int d = 0; d < 4; d++) {
 #endif
                     u32 x0, x1, x2, x3;
-                    ans_get_pair(sb, sa, rbase, hc, x0, x1, sel_lo, sel_hi);
-                    ans_get_pair(sb, sa, rbase, hc, x2, x3, sel_lo, sel_hi);
+                    ans_get_pair(sb, sa, slb, sla, rbase, hc, x0, x1, sel_lo, sel_hi);
+                    ans_get_pair(sb, sa, slb, sla, rbase, hc, x2, x3, sel_lo, sel_hi);
                     w[d] = (((((x3 << 8) | x2) << 8) | x1) << 8) | x0;
                 }
                 si.rpos = hc << 1;
