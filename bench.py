@@ -15,7 +15,7 @@ MB = 10^6 (reference include_/time_.h:113,233), i.e. N / (t_enc + t_dec) per SUR
 
 Workload (configs[1]): "text100m" -- 100 000 000 i.i.d. bytes from an English-like order-0 table,
 the enwik8 stand-in of SURVEY 8d (no corpus, no network); set ENWIK8=/path/to/enwik8 to use the real
-file.  Coder: static-CDF rANS, payload(chunk) bit-identical to anscdf4senc(chunk); CDF from cdfini
+file (ENWIK8BWT=/path for the adaptive coders' run-heavy workload, BASELINE config 3).  Coder: static-CDF rANS, payload(chunk) bit-identical to anscdf4senc(chunk); CDF from cdfini
 on device (untimed, as in the reference harness turborc.c:429-433).
 
 Other workloads (each prints its own JSON line, same contract):
@@ -101,6 +101,10 @@ def make_input(n, rank, kind="text"):
         reps = (n + d.size - 1) // d.size
         return np.tile(d, reps)[:n].copy(), "enwik8"
     if kind == "bwt":
+        path = os.environ.get("ENWIK8BWT")                     # BASELINE config 3's corpus, where a box has it
+        if path and os.path.exists(path):
+            d = np.fromfile(path, dtype=np.uint8)
+            return np.tile(d, (n + d.size - 1) // d.size)[:n].copy(), "enwik8bwt"
         return T.runs_bytes(n, 3 + rank), "bwt%dm" % (n // 1000000)
     if kind in ("i16", "i32"):                               # slow random walk: what the zigzag-delta coders are for
         return T.int_bytes(n, 2 if kind == "i16" else 4, "walk", 9 + rank), "walk%dm-%s" % (n // 1000000, kind)

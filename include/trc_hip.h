@@ -183,6 +183,12 @@ size_t trc_container_bound(size_t n, uint32_t chunk);
 size_t trc_encode_host(int codec, const void *in, size_t n, uint32_t chunk, void *out, size_t outcap,
                        const uint16_t *cdf, unsigned cdfnum);
 
+/* Bounded decode for untrusted input: the reference-named decoders carry no input length, this one does -- the container is
+ * validated against `inlen` (trc_container_check) before anything is read; inlen == outlen means "stored raw" and is copied.
+ * cdf / cdfnum: static coders only (cdfnum 0: derived from the CDF's terminating 32768).  Returns outlen, 0 on error. */
+size_t trc_decode_host(int codec, const void *in, size_t inlen, void *out, size_t outlen,
+                       const uint16_t *cdf, unsigned cdfnum);
+
 /* Host-pointer calls and page-locked memory.  A pageable caller buffer travels through pinned staging slots (copy threads
  * + DMA: 38-40 GB/s per direction on the MI355X box); a page-locked one -- hipHostMalloc, or registered with the pair
  * below -- is read / written by DMA directly, detected per call with hipPointerGetAttributes.  Registration costs ~55 us

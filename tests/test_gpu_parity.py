@@ -225,6 +225,41 @@ def test_static_rans_buckets_with_many_symbols(torch_cuda):
         device_roundtrip(torch_cuda, trc.ANS4S, d, chunk, cdf, cdfnum)
 
 
+def test_bounded_host_decoder(torch_cuda):
+    """trc_decode_host: the decoder that is told how long its input really is.  A valid container round-trips; a truncated
+    buffer, a header that claims more payload than the buffer holds and a directory that does not add up are REJECTED
+    before anything is decoded (the reference-named decoders cannot know: their prototypes carry no input length)."""
+    import ctypes as C
+    L = trc.lib()
+    L.trc_decode_host.restype = C.c_size_t
+    L.trc_decode_host.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint]
+    for codec in (trc.ANS4S, trc.RCS2, trc.RCA, trc.RCB):
+        d = gen("text", 300001, 91)
+        _, cdf, cdfnum = T.orc_cdfini(d)
+        comp = trc.host_encode(codec, d, cdf, cdfnum)
+        assert comp.size < d.size
+        st = codec in trc.STATIC
+        cp = cdf.ctypes.data_as(C.c_void_p) if st else None
+
+        def dec(buf, inlen):
+            out = np.full(d.size + 64, 0xA5, dtype=np.uint8)
+            src = np.zeros(buf.size + 4096, dtype=np.uint8); src[:buf.size] = buf
+            r = L.trc_decode_host(codec, src.ctypes.data_as(C.c_void_p), inlen, out.ctypes.data_as(C.c_void_p), d.size, cp, cdfnum if st else 0)
+            return r, out
+        r, out = dec(comp, comp.size)
+        assert r == d.size and np.array_equal(out[:d.size], d) and (out[d.size:] == 0xA5).all()
+        r, _ = dec(comp, comp.size - 1)                                   # truncated
+        assert r == 0 and b"container" in L.trc_last_error()
+        forged = comp.copy(); forged[24:32] = np.frombuffer(np.uint64(comp.size * 2).tobytes(), dtype=np.uint8)      # header.payload
+        r, _ = dec(forged, comp.size)
+        assert r == 0
+        bad = comp.copy(); bad[32:36] = np.frombuffer(np.uint32(7).tobytes(), dtype=np.uint8)                        # clen[0]: sums no longer match
+        r, _ = dec(bad, comp.size)
+        assert r == 0
+        r, out = dec(d, d.size)                                           # stored raw: inlen == outlen
+        assert r == d.size and np.array_equal(out[:d.size], d)
+
+
 def test_host_pointer_layer_is_thread_safe(torch_cuda):
     """host-pointer calls from several threads at once.  Calls on one device serialise on the device
     context's lock and use that context's own copy-thread pools (round 2 had process-wide pools behind per-device locks);

@@ -875,6 +875,20 @@ extern "C" size_t trc_encode_host(int codec, const void *in, size_t n, uint32_t 
     return host_encode(codec, (const unsigned char *)in, n, (unsigned char *)out, (const cdf_t *)cdf, (int)cdfnum, chunk, outcap);
 }
 
+// The bounded decoder: like the reference-named decoder of `codec`, but the caller states how many bytes `in` really holds and the
+// container is validated against THAT before anything is read (the reference prototypes carry no input length, so through them a
+// forged header can make a decoder read past a short buffer).  Raw streams (inlen == outlen) are copied.  Returns outlen, 0 on error.
+extern "C" size_t trc_decode_host(int codec, const void *in, size_t inlen, void *out, size_t outlen,
+                                  const uint16_t *cdf, unsigned cdfnum)
+{
+    if (!codec_ok(codec)) { fail(TRC_E_ARG, "codec %d not available", codec); return 0; }
+    if (!in || !out) { fail(TRC_E_ARG, "decode_host: bad arguments"); return 0; }
+    if (outlen == 0) return 0;
+    if (inlen == outlen) { memcpy(out, in, outlen); return outlen; }        // stored raw (the reference's convention)
+    if (trc_container_check(in, inlen, codec, outlen)) return 0;
+    return host_decode(codec, (const unsigned char *)in, outlen, (unsigned char *)out, (const cdf_t *)cdf, (int)cdfnum);
+}
+
 // ---- container validation for untrusted input (the reference prototypes carry no input length) ------
 // Everything a decoder will read from buf is checked against buflen: header fields, the directory, and that the
 // directory's (clamped) lengths add up to exactly the stated payload, which must end inside the buffer.
