@@ -225,6 +225,40 @@ def test_static_rans_buckets_with_many_symbols(torch_cuda):
         device_roundtrip(torch_cuda, trc.ANS4S, d, chunk, cdf, cdfnum)
 
 
+def test_static_rans_decoder_both_forms(torch_cuda):
+    """the static rANS decoder exists in two forms -- one lane per chunk (calls that fill the chip), two lanes per chunk, one per
+    rANS state (calls that do not: fewer than 2048 waves) -- chosen by the number of chunks.  Both must decode the same containers:
+    each is forced in a process of its own (TRC_ANS_PAIR is read once) on inputs with ragged tails, raw chunks among coded ones
+    and every chunk length class (n % 4 = 0..3 decides which state codes the tail)."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np, torch
+        sys.path[:0] = [%r, %r]
+        import trc, trc_testlib as T
+        from golden.make_golden import gen
+        for kind, n, chunk in (("text", 300001, 512), ("zipf", 70002, 1024), ("text", 1000003, 4096), ("runs", 5000, 256), ("text", 64 * 512 * 3 + 7, 512)):
+            d = gen(kind, n, 5)
+            if kind == "text":
+                d = d.copy(); d[4096:4096 + 1500] = np.random.default_rng(3).integers(0, 256, 1500, dtype=np.uint8)   # raw chunks
+            _, cdf, cdfnum = T.orc_cdfini(d)
+            dc = trc.DeviceCoder(trc.ANS4S, n, chunk, "cuda:0"); dc.set_cdf(cdf, cdfnum)
+            d_in = torch.from_numpy(np.concatenate([d, np.zeros(512, np.uint8)])).to("cuda:0")
+            dc.encode(d_in, n)
+            clen, payload = dc.result(n)
+            ep, ec, _ = T.orc_chunked_enc(trc.ANS4S, d, chunk, cdf, cdfnum)
+            assert np.array_equal(clen, ec) and np.array_equal(payload, ep)
+            out = torch.full((n + 512,), 0xA5, dtype=torch.uint8, device="cuda:0")
+            dc.decode(out, n); torch.cuda.synchronize()
+            o = out.cpu().numpy()
+            assert np.array_equal(o[:n], d), (kind, n, chunk)
+            assert (o[n:] == 0xA5).all()
+        print("ok")
+    """) % (os.path.dirname(os.path.abspath(trc.__file__)), os.path.dirname(os.path.abspath(__file__)))
+    for form in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, TRC_ANS_PAIR=form))
+        assert r.returncode == 0 and "ok" in r.stdout, (form, r.stdout[-2000:] + r.stderr[-3000:])
+
+
 def test_bounded_host_decoder(torch_cuda):
     """trc_decode_host: the decoder that is told how long its input really is.  A valid container round-trips; a truncated
     buffer, a header that claims more payload than the buffer holds and a directory that does not add up are REJECTED

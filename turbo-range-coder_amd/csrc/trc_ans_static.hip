@@ -441,6 +441,149 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
     trc_wave_copy_raw(__ballot(alive && cl == len && len != 0), off, len, out + (u64)wc.c0 * chunk, chunk, payload);
 }
 
+// ---------------------------------------------------------------- decode, two LANES per chunk ---
+// Round 3, for calls that cannot fill the chip with one lane per chunk (fewer than 2048 waves: 100 MB at chunk 1024 and up).
+// A wave's time is its own instruction count, and with one lane per chunk a lane runs BOTH states of its chunk.  Here lanes 2i
+// and 2i + 1 take chunk i of the wave, one state each (even lane: the state of the even-index symbols): twice the waves, each
+// with little more than half the instructions per symbol pair.  The two states share the chunk's word stream -- a unit goes to
+// whichever symbol renormalises first, in symbol order -- so a step exchanges the renormalisation flags inside the pair (DPP) and
+// both lanes advance one shared cursor: the even lane takes the unit behind the cursor, the odd lane that one or the next,
+// depending on the even lane's flag.  The stream's ring belongs to the even lane (the odd lane reads its partner's column and never
+// asks for a refill); the two lanes' bytes are merged by DPP into identical 16-byte pieces before the output transpose (pair
+// mode of QuadOut, as in trc_rcs2p_dec_kernel).
+__device__ __forceinline__ u32 ans_get_half(u32 &s, u32 lbase, u32 &hc, u32 b, u32 seld)
+{
+    u32 a;
+    asm("v_bfe_u32 %0, %1, 1, 5\n\tv_lshl_add_u32 %0, %0, 8, %2" : "=&v"(a) : "v"(hc), "v"(lbase));
+    const u32 dw0 = *(const trc_lds_u32 *)(uintptr_t)a;
+    const u32 dw1 = *(const trc_lds_u32 *)(uintptr_t)(a + 256u);
+    const u32 sl = s & (TRC_PROB_ONE - 1);
+    const u32 x = *(const trc_lds_u8 *)(uintptr_t)(DEC_LDS_LUT + sl);
+    const trc_v2u e = *(const trc_lds_u64 *)(uintptr_t)(DEC_LDS_DTAB + (x << 3));
+    const u32 t = __umul24(e.x, s >> TRC_PROB_BITS) + e.y + sl;
+    const u32 w32 = __builtin_amdgcn_alignbit(dw1, dw0, hc << 4);        // units hc, hc + 1
+    const u32 rn = t < TRC_ANS_LOW ? 1u : 0u;
+    const u32 oth = trc_quad_xor1(rn);                                   // the partner's flag
+    // even lane (b = 0): the unit behind the cursor; odd lane: that one, or the next if the even lane took it.  The byte
+    // selector of `state << 16 | unit` is 0x05040100 for the window's low unit, + 0x0202 for its high unit (seld = 0x0202 * b)
+    const u32 sel = 0x05040100u + oth * seld;
+    const u32 c = __builtin_amdgcn_perm(t, w32, sel);
+    s = rn ? c : t;
+    hc += rn + oth;
+    return x;
+}
+
+__global__ __launch_bounds__(896) void trc_ans4s_dec2_kernel(
+    const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
+    u64 n, u32 chunk, u32 nchunks,
+    const u8 *__restrict__ lut_g, const u32 *__restrict__ dtab_g, u8 *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, BLOCK = blockDim.x;
+    u8 *wbase = smem + DEC_LDS_WAVES + wv * DEC_WAVE_LDS;
+    {
+        uint2 *dtab = (uint2 *)(smem + DEC_LDS_DTAB);
+        if (BLOCK >= 704u) {
+            uint4 t0 = make_uint4(0, 0, 0, 0), t1 = t0, t2 = t0; u32 td = 0;
+            t0 = ((const uint4 *)lut_g)[tid];
+            t1 = ((const uint4 *)lut_g)[tid + BLOCK];
+            if (tid + 2u * BLOCK < 2048u) t2 = ((const uint4 *)lut_g)[tid + 2u * BLOCK];
+            if (tid < 256u) td = dtab_g[tid];
+            ((uint4 *)smem)[tid] = t0; ((uint4 *)smem)[tid + BLOCK] = t1;
+            if (tid + 2u * BLOCK < 2048u) ((uint4 *)smem)[tid + 2u * BLOCK] = t2;
+            if (tid < 256u) dtab[tid] = make_uint2(td >> 16, 0u - (td & 0xffffu));
+        } else {
+            for (u32 i = tid; i < 2048; i += BLOCK) ((uint4 *)smem)[i] = ((const uint4 *)lut_g)[i];
+            for (u32 i = tid; i < 256; i += BLOCK) { const u32 d = dtab_g[i]; dtab[i] = make_uint2(d >> 16, 0u - (d & 0xffffu)); }
+        }
+    }
+    __syncthreads();
+
+    WaveChunks wc;
+    wc.c0 = (blockIdx.x * (BLOCK / 64) + wv) * 32u; wc.chunk = chunk; wc.nchunks = nchunks;
+    wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
+    if (wc.c0 >= nchunks) return;
+    wc.rows = nchunks - wc.c0 < 32u ? nchunks - wc.c0 : 32u;
+    // the directory of the whole group of 64 chunks (payload offsets are per group): lane L reads chunk (group base + L), the
+    // pair takes its chunk's numbers from there
+    const u32 g0 = wc.c0 & ~63u, cg = g0 + lane;
+    const u32 lenL = cg < nchunks ? ((cg == nchunks - 1u) ? wc.lastlen : chunk) : 0u;
+    const u32 clL = cg < nchunks ? trc_min(clen[cg], lenL) : 0u;   // a directory entry above the chunk length (corrupt input) reads as raw
+    const u32 exL = trc_wave_incl_scan(clL) - clL;
+    const u64 gbase = trc_group_base(goff, gsum, wc.c0 >> 6);
+    const u32 ci = lane >> 1, b = lane & 1u, srcl = (wc.c0 & 32u) + ci;
+    const u32 cl = (u32)__shfl((int)clL, (int)srcl, 64), ex = (u32)__shfl((int)exL, (int)srcl, 64), len = (u32)__shfl((int)lenL, (int)srcl, 64);
+    const bool alive = ci < wc.rows;
+    const u32 c = wc.c0 + ci;
+    const u64 off = gbase + ex;
+    const bool coded = alive && cl != len;
+    const bool owner = coded && b == 0u;                       // the even lane owns the chunk's stream (ring, refills)
+
+    QuadOut tout; tout.base = out + (u64)wc.c0 * chunk;
+    AnsStreamIn si;
+    si.rings = wbase; si.sel = wbase + TRC_SRING_BYTES;
+    si.gbase = payload; si.soff = off + 8; si.lim = trc_sub_sat(cl, 8u);   // words follow the two states
+    u32 st = 0;
+    if (coded) st = trc_ld32_a2(payload + off + (b ? 0u : 4u));             // [enc state 1][enc state 0]: the even lane runs state 0
+    si.prime(owner);
+
+    const u32 S = chunk / TRC_SEG;
+    const u32 body4 = len & ~3u;
+    u8 *dst = out + (u64)c * chunk;
+    const u32 rbase = (u32)(uintptr_t)(si.rings - smem) + AnsStreamIn::ra(lane & ~1u, 0);   // the PAIR's ring (the even lane's column)
+    const u32 seld = b ? 0x0202u : 0u, sh0 = 8u * b;
+    u32 hc = 0;                                                // the pair's halfword cursor (both lanes keep it)
+    for (u32 s = 0; s < S; s++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 p0 = s * TRC_SEG + (u32)k * 16u;          // chunk offset of this 16-byte piece
+            si.rpos = hc << 1;
+            si.period(owner && p0 < len, k & 1);
+            if (k == 0 && s > 0) tout.flush(wc, (s - 1u) * TRC_SEG, true);   // the segment before, behind this period's commit
+            const bool full = coded && p0 + 16u <= len;
+            u32 w[4];
+#pragma unroll
+            for (int d = 0; d < 4; d++) {                       // a dword = two pairs of symbols: this lane's bytes are b and b + 2
+                u32 m = 0;
+                if (full) {
+                    const u32 xa = ans_get_half(st, rbase, hc, b, seld);
+                    const u32 xb = ans_get_half(st, rbase, hc, b, seld);
+                    m = (xa | (xb << 16)) << sh0;
+                }
+                w[d] = m | trc_quad_xor1(m);                    // (every lane: the exchange must not sit in a branch)
+            }
+            if (!full && coded && p0 < len) {                   // last chunk's final partial piece: symbol by symbol, both lanes walking it
+                for (u32 pos = p0; pos < len; pos++) {
+                    const bool mine = ((pos < body4 && (pos & 1u)) ? 1u : 0u) == b;        // odd positions of whole groups: state 1; the tail: state 0
+                    u32 rn = 0;
+                    if (mine) {
+                        const u32 sl = st & (TRC_PROB_ONE - 1);
+                        const u32 x = *(const trc_lds_u8 *)(uintptr_t)(DEC_LDS_LUT + sl);
+                        const trc_v2u e = *(const trc_lds_u64 *)(uintptr_t)(DEC_LDS_DTAB + (x << 3));
+                        const u32 t = __umul24(e.x, st >> TRC_PROB_BITS) + e.y + sl;
+                        const u32 a = rbase + (((hc >> 1) & 31u) << 8) + ((hc & 1u) << 1);
+                        const u32 unit = trc_ldsr16(a);
+                        rn = t < TRC_ANS_LOW ? 1u : 0u;
+                        st = rn ? (t << 16) | unit : t;
+                        dst[pos] = (u8)x;
+                    }
+                    hc += rn + trc_quad_xor1(rn);
+                }
+            }
+            tout.put((u32)k, make_uint4(w[0], w[1], w[2], w[3]));
+        }
+    }
+    tout.flush(wc, (S - 1u) * TRC_SEG, true);
+    // raw chunks: lanes 0..31 carry their chunks' numbers for the wave copy
+    {
+        const u32 from = (lane & 31u) << 1;
+        const u32 olo = (u32)__shfl((int)(u32)off, (int)from, 64), ohi = (u32)__shfl((int)(u32)(off >> 32), (int)from, 64);
+        const u32 l2 = (u32)__shfl((int)len, (int)from, 64), c2 = (u32)__shfl((int)cl, (int)from, 64);
+        const bool raw = lane < wc.rows && c2 == l2 && l2 != 0u;
+        trc_wave_copy_raw(__ballot(raw), ((u64)ohi << 32) | olo, l2, out + (u64)wc.c0 * chunk, chunk, payload);
+    }
+}
+
 // ------------------------------------------------------------------------------------- launch ---
 // Encoder launch shape.  LDS per workgroup = REP x 4 KiB of symbol table + 8.3 KiB per wave; a CU holds 160 KiB.
 //   REP 1 (default): 4 waves share one 4 KiB table, 37 KiB per workgroup -> 16 waves per CU
@@ -483,6 +626,16 @@ void trc_launch_ans4s_dec(const uint8_t *d_payload, const uint32_t *d_clen, size
     const u8 *lut = w.tables + TRC_TAB_LUT;
     const u32 *dtab = (const u32 *)(w.tables + TRC_TAB_DEC);
     const u32 nwaves = w.ngroups;
+    static const int env_pair = getenv("TRC_ANS_PAIR") ? atoi(getenv("TRC_ANS_PAIR")) : -1;      // tuning aid: 0 / 1 force the form
+    if (env_pair == 1 || (env_pair != 0 && nwaves < 2048u)) {  // too few chunks to fill the chip with one lane each: two lanes per chunk
+        const u32 nw2 = (w.nchunks + 31u) / 32u;
+        TRC_RAISE_LDS_ONCE(trc_ans4s_dec2_kernel, DEC_LDS_WAVES + 14 * DEC_WAVE_LDS);
+        u32 wpb2 = (nw2 + 255u) / 256u;
+        wpb2 = wpb2 < 1u ? 1u : wpb2 > 14u ? 14u : wpb2;
+        TRC_LAUNCH_TIMED(trc_ans4s_dec2_kernel, dim3((nw2 + wpb2 - 1) / wpb2), dim3(64 * wpb2), DEC_LDS_WAVES + wpb2 * DEC_WAVE_LDS, s,
+                           d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, lut, dtab, d_out);
+        return;
+    }
     TRC_RAISE_LDS_ONCE(trc_ans4s_dec_kernel, DEC_LDS_WAVES + 14 * DEC_WAVE_LDS);
     // the 34 KiB of tables are per workgroup, so waves share a workgroup -- but no more than it takes to
     // give every one of the 256 CUs a workgroup (1526 waves: 6 per workgroup -> 255 workgroups); up to 14 fit
