@@ -23,7 +23,9 @@
 typedef short trc_s2 __attribute__((ext_vector_type(2)));
 
 #define TRC_NIBK_BYTES  512u                      // K table, per wave
+#ifndef TRC_NIB_ROW
 #define TRC_NIB_ROW     560u                      // bytes per lane, byte model (17 tables)
+#endif
 #define TRC_NIB1_ROW    48u                       // bytes per lane, single table
 #define TRC_NIB2_ROW    80u                       // bytes per lane, two tables (Turbo-VLC coders): 20 dwords, conflict free like the others
 #define TRC_NIB3_ROW    112u                      // bytes per lane, three tables (vnibble coders): 28 dwords, lane*28 mod 64 hits 16 distinct bank groups
