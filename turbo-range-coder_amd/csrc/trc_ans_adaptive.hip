@@ -27,7 +27,7 @@
 #include "trc_launch.h"
 
 #define ANSA_MODEL_LDS(NIB) ((NIB) ? TRC_NIB1_BYTES : TRC_NIB_BYTES)
-#define ANSA_CODE_LDS       (TRC_TILE_BYTES + TRC_SRING_BYTES + TRC_SEL_BYTES)
+#define ANSA_CODE_LDS       (TRC_TILE_BYTES + TRC_SRING_BYTES)
 
 // geometry of the record space of one wave's chunks (record bytes per input byte: 8 / 4)
 template <bool NIB>
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(64) void trc_ansa_code_kernel(
 
     TileIn tin; tin.tile = smem; tin.base = recs + (u64)wc.c0 * wr.chunk;
     StreamOut<true> so;
-    so.rings = smem + TRC_TILE_BYTES; so.sel = smem + TRC_TILE_BYTES + TRC_SRING_BYTES;
+    so.rings = smem + TRC_TILE_BYTES;
     so.scratch = scratch; so.stride = stride; so.c0 = wc.c0; so.wpos = 0; so.nfl = 0;
     u32 st[4] = { TRC_ANS_LOW, TRC_ANS_LOW, TRC_ANS_LOW, TRC_ANS_LOW };
     bool ovf = false;

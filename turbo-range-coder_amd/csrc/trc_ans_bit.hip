@@ -17,7 +17,7 @@
 #include "trc_launch.h"
 
 #define ANSB_MODEL_BYTES (256u * 64u * 2u)                 // [ctx][lane] u16
-#define ANSB_CODE_LDS    (TRC_TILE_BYTES + TRC_SRING_BYTES + TRC_SEL_BYTES)
+#define ANSB_CODE_LDS    (TRC_TILE_BYTES + TRC_SRING_BYTES)
 
 // bit 1: p += (2^15 - p) >> 5, bit 0: p -= p >> 5 -- as mask arithmetic (written as ?: the compiler made a divergent if / else of it,
 // eight per byte)
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64) void trc_ansb_code_kernel(
 
     TileIn tin; tin.tile = smem; tin.base = recs + (u64)wc.c0 * wr.chunk;
     StreamOut<true> so;
-    so.rings = smem + TRC_TILE_BYTES; so.sel = smem + TRC_TILE_BYTES + TRC_SRING_BYTES;
+    so.rings = smem + TRC_TILE_BYTES;
     so.scratch = scratch; so.stride = stride; so.c0 = wc.c0; so.wpos = 0; so.nfl = 0;
     u32 st[4] = { TRC_ANS_LOW, TRC_ANS_LOW, TRC_ANS_LOW, TRC_ANS_LOW };
     bool ovf = false;

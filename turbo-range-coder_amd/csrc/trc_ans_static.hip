@@ -17,8 +17,8 @@
 #include "trc_io.h"
 #include "trc_launch.h"
 
-#define ENC_WAVE_LDS (TRC_SRING_BYTES + TRC_SEL_BYTES)       // input arrives through an in-register quad transpose
-#define DEC_WAVE_LDS (TRC_SRING_BYTES + TRC_SEL_BYTES)       // 8.3 KiB: 12 waves + 34 KiB of tables fit one CU
+#define ENC_WAVE_LDS (TRC_SRING_BYTES)       // input arrives through an in-register quad transpose
+#define DEC_WAVE_LDS (TRC_SRING_BYTES)       // 8.3 KiB: 12 waves + 34 KiB of tables fit one CU
 #ifndef TRC_DEC_LATE_FLUSH
 #define TRC_DEC_LATE_FLUSH 1    // decoder: a segment's output stores behind the next period's commit (0: before it, as in round 2)
 #endif
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(BLOCK) void trc_ans4s_enc_kernel(
     const u32 len = alive ? wc.len_of(lane) : 0u;
     QuadIn tin; tin.base = in + (u64)wc.c0 * chunk;
     StreamOut<true> so;
-    so.rings = wbase; so.sel = wbase + TRC_SRING_BYTES;
+    so.rings = wbase;
     so.scratch = scratch; so.stride = stride; so.c0 = wc.c0; so.wpos = 0; so.nfl = 0;
     const u32 tbase = (lane & (u32)(REP - 1)) << 4;                              // this lane's replica (table at LDS offset 0)
     const u32 rbase = (u32)(uintptr_t)(so.rings - smem) + trc_raddr(lane, 0);    // this lane's ring, as an LDS byte address
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
 
     QuadOut tout; tout.base = out + (u64)wc.c0 * chunk;        // output leaves through an in-register quad transpose
     AnsStreamIn si;
-    si.rings = wbase; si.sel = wbase + TRC_SRING_BYTES;
+    si.rings = wbase;
     si.gbase = payload; si.soff = off + 8; si.lim = trc_sub_sat(cl, 8u);   // words follow the two states
     u32 sa = 0, sb = 0;
     if (coded) { sa = trc_ld32_a2(payload + off); sb = trc_ld32_a2(payload + off + 4); }   // sa = enc state 1, sb = enc state 0
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec2_kernel(
 
     QuadOut tout; tout.base = out + (u64)wc.c0 * chunk;
     AnsStreamIn si;
-    si.rings = wbase; si.sel = wbase + TRC_SRING_BYTES;
+    si.rings = wbase;
     si.gbase = payload; si.soff = off + 8; si.lim = trc_sub_sat(cl, 8u);   // words follow the two states
     u32 st = 0;
     if (coded) st = trc_ld32_a2(payload + off + (b ? 0u : 4u));             // [enc state 1][enc state 0]: the even lane runs state 0

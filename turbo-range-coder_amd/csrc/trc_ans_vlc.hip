@@ -20,7 +20,7 @@
 #include "trc_vlc.h"
 #include "trc_launch.h"
 
-#define VLA_CODE_LDS (TRC_TILE_BYTES + TRC_SRING_BYTES + TRC_SEL_BYTES)
+#define VLA_CODE_LDS (TRC_TILE_BYTES + TRC_SRING_BYTES)
 
 // record space of one wave's chunks: 8 bytes per element
 template <int ES>
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(64) void trc_vla_code_kernel(
 
     TileIn tin; tin.tile = smem; tin.base = recs + (u64)wc.c0 * stride2;
     StreamOut<true> so;
-    so.rings = smem + TRC_TILE_BYTES; so.sel = smem + TRC_TILE_BYTES + TRC_SRING_BYTES;
+    so.rings = smem + TRC_TILE_BYTES;
     so.scratch = scratch; so.stride = stride; so.c0 = wc.c0; so.wpos = 0; so.nfl = 0;
     u32 st0 = TRC_ANS_LOW, st1 = TRC_ANS_LOW;
     bool ovf = false;

@@ -26,7 +26,6 @@
 #define TRC_SRING        128u     // stream ring bytes per lane
 #define TRC_SRING_STRIDE 132u
 #define TRC_SRING_BYTES  (64u * TRC_SRING_STRIDE)           // 8448 per wave
-#define TRC_SEL_BYTES    64u      // per-wave scratch for the rank -> lane table
 
 // Byte address, inside one wave's ring array, of ring offset `off` (0..127) of lane `lane`.
 //   default: lane-major rows of 132 bytes (33 dwords: conflict-free while lanes sit at equal offsets,
@@ -260,7 +259,6 @@ struct QuadOut {
 template <bool DOWN, bool PAIR = false>
 struct StreamOut {
     u8 *rings;           // this wave's ring array (LDS)
-    u8 *sel;             // this wave's rank->lane table (LDS)
     u8 *scratch;         // global scratch, region of chunk c is [c*stride, (c+1)*stride)
     u32 stride;
     u32 c0;
@@ -374,7 +372,6 @@ struct StreamInT {
         return IL ? ((off >> 2) << 8) + (lane << 2) + (off & 3u) : trc_raddr(lane, off);
     }
     u8 *rings;           // this wave's ring array (LDS)
-    u8 *sel;
     const u8 *gbase;     // payload base (kernel argument: keeps the loads in the global address space)
     u64 soff;            // this lane's stream start, bytes from gbase (2-byte aligned)
     u64 wbase;           // (set by prime) soff of the wave's first lane: wave-uniform

@@ -16,7 +16,7 @@
 #include "trc_rc.h"
 #include "trc_launch.h"
 
-#define RCS_WAVE_LDS(NS) ((NS) * TRC_SRING_BYTES + TRC_SEL_BYTES)     // chunk bytes travel through in-register quad transposes
+#define RCS_WAVE_LDS(NS) ((NS) * TRC_SRING_BYTES)     // chunk bytes travel through in-register quad transposes
 
 template <int GEO> struct RcGeo;
 template <> struct RcGeo<0> { typedef RcEncD Enc; typedef RcDec Dec; };
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(64) void trc_rcs_enc_kernel(
 
     QuadIn tin; tin.base = in + (u64)wc.c0 * chunk;
     StreamOut<false> so0, so1;
-    so0.rings = wbase; so0.sel = wbase + NS * TRC_SRING_BYTES;
+    so0.rings = wbase;
     so0.scratch = scrA; so0.stride = strideA; so0.c0 = wc.c0; so0.wpos = (NS == 2) ? 4u : 0u; so0.nfl = 0;
     so1 = so0;
     if (NS == 2) { so1.rings = so0.rings + TRC_SRING_BYTES; so1.scratch = scrB; so1.stride = strideB; so1.wpos = 0; }
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(896) void trc_rcs_dec_kernel(
 
     QuadOut tout; tout.base = out + (u64)wc.c0 * chunk;
     StreamIn s0, s1;
-    s0.rings = wbase; s0.sel = wbase + NS * TRC_SRING_BYTES;
+    s0.rings = wbase;
     const u32 len0 = (NS == 2 && coded) ? trc_min(trc_ld32_a2(payload + off), trc_sub_sat(cl, 4u)) : 0u;   // a corrupt header cannot point outside the chunk's payload
     s0.gbase = payload; s0.soff = off + (NS == 2 ? 4u : 0u); s0.lim = NS == 2 ? len0 : cl;
     s1 = s0;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(128) void trc_rcs2p_enc_kernel(
 
         QuadIn tin; tin.base = in + (u64)wc.c0 * chunk;
         StreamOut<false, true> so;
-        so.rings = wbase; so.sel = wbase + TRC_SRING_BYTES;
+        so.rings = wbase;
         so.scratch = scrA; so.stride = strideA; so.scratch_b = scrB; so.stride_b = strideB; so.c0 = wc.c0;
         so.wpos = b ? 0u : 4u; so.nfl = 0;
         RcEncD e; e.start();
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(896) void trc_rcs2p_dec_kernel(
 
     QuadOut tout; tout.base = out + (u64)wc.c0 * chunk;
     StreamIn si;
-    si.rings = wbase; si.sel = wbase + TRC_SRING_BYTES;
+    si.rings = wbase;
     const u32 len0 = coded ? trc_min(trc_ld32_a2(payload + off), trc_sub_sat(cl, 4u)) : 0u;   // a corrupt header cannot point outside the chunk's payload
     si.gbase = payload;
     si.soff = off + 4u + (b ? len0 : 0u);
