@@ -13,14 +13,16 @@ pytestmark = pytest.mark.gpu
 KINDS = ["zipf", "text", "runs", "uniform", "nibble", "binary", "const"]
 
 
-# TRC_FUZZ_SEEDS=N widens the sweep for a soak run (default 6 seeds x 20 configurations)
+# TRC_FUZZ_SEEDS=N widens the sweep for a soak run (default 6 seeds x 20 configurations); TRC_FUZZ_CODECS="1,3,12" restricts it to
+# those codec ids (soaks of the kernels a round has touched)
+_ONLY = [int(x) for x in os.environ.get("TRC_FUZZ_CODECS", "").split(",") if x.strip()]
 @pytest.mark.parametrize("seed", range(int(os.environ.get("TRC_FUZZ_SEEDS", "6"))))
 def test_random_configurations(seed):
     import torch
     assert torch.cuda.is_available()
     rng = np.random.default_rng(1000 + seed)
     for _it in range(20):
-        codec = int(rng.choice(trc.AVAILABLE))
+        codec = int(rng.choice(_ONLY or trc.AVAILABLE))
         chunk = int(rng.choice([256, 320, 512, 1024, 1984, 4096, 16384, 65536]))
         if codec == trc.ANSB:
             chunk = min(chunk, 8192)                         # one reference block per chunk

@@ -59,6 +59,14 @@ def lib():
         if not os.path.exists(LIB):
             raise RuntimeError("libturborc_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                                "there is no CPU fallback")
+        # The process must end up with ONE HIP runtime.  PyTorch's wheel brings its own libamdhip64; if this library is
+        # loaded first it pulls in /opt/rocm's copy, torch then loads its own, and device pointers of one runtime reach
+        # launches of the other ("no ROCm-capable device is detected" on the first call).  With torch imported first the
+        # library's dependency resolves to the runtime that is already there.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         l = C.CDLL(LIB)
         l.trc_last_error.restype = C.c_char_p
         l.trc_device_count.restype = C.c_int
