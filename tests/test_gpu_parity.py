@@ -259,6 +259,36 @@ def test_static_rans_decoder_both_forms(torch_cuda):
         assert r.returncode == 0 and "ok" in r.stdout, (form, r.stdout[-2000:] + r.stderr[-3000:])
 
 
+def test_bitwise_rc_encoder_both_forms(torch_cuda):
+    """the bitwise range coder's encoder exists with the deepest tree level in LDS and with it in global memory (a 256-byte row
+    per lane in the workspace, filled by the wave itself); the launch picks by wave count.  Each form is forced in a process of
+    its own (TRC_RCB_L7G is read once): per-chunk parity with the oracle and round trip, ragged tails and a short last wave
+    (dead lanes have rows of their own) included."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np, torch
+        sys.path[:0] = [%r, %r]
+        import trc, trc_testlib as T
+        from golden.make_golden import gen
+        for kind, n, chunk in (("text", 300001, 512), ("zipf", 64 * 1024 * 2 + 5, 1024), ("uniform", 40000, 256), ("runs", 70001, 4096), ("text", 700, 256)):
+            d = gen(kind, n, 6)
+            dc = trc.DeviceCoder(trc.RCB, n, chunk, "cuda:0")
+            d_in = torch.from_numpy(np.concatenate([d, np.zeros(512, np.uint8)])).to("cuda:0")
+            for rep in range(2):                                   # twice: the second call finds the rows of the first in the workspace
+                dc.encode(d_in, n)
+                clen, payload = dc.result(n)
+                ep, ec, _ = T.orc_chunked_enc(trc.RCB, d, chunk, None, 0)
+                assert np.array_equal(clen, ec) and np.array_equal(payload, ep), (kind, n, chunk, rep)
+            out = torch.full((n + 512,), 0xA5, dtype=torch.uint8, device="cuda:0")
+            dc.decode(out, n); torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy()[:n], d), (kind, n, chunk)
+        print("ok")
+    """) % (os.path.dirname(os.path.abspath(trc.__file__)), os.path.dirname(os.path.abspath(__file__)))
+    for form in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, TRC_RCB_L7G=form))
+        assert r.returncode == 0 and "ok" in r.stdout, (form, r.stdout[-2000:] + r.stderr[-3000:])
+
+
 def test_bounded_host_decoder(torch_cuda):
     """trc_decode_host: the decoder that is told how long its input really is.  A valid container round-trips; a truncated
     buffer, a header that claims more payload than the buffer holds and a directory that does not add up are REJECTED

@@ -97,7 +97,15 @@ static inline size_t scratch2_stride(int codec, uint32_t chunk)
 {
     if (codec >= TRC_VLAU16 && codec <= TRC_VLAVZ32)            // record stack (8 B per element) + room for the mantissa bytes at the slot's end
         return 8 * (size_t)(chunk / (codec >= TRC_VLAV32 ? 4 : 2)) + chunk + 64;
+    if (codec == TRC_RCB) return 256;                            // the bitwise encoder's deepest tree level (128 nodes x u16 per chunk, trc_rc_bit.hip)
     return two_streams(codec) ? chunk + 128 : (codec == TRC_ANSA || codec == TRC_ANSO1) ? 8 * (size_t)chunk : codec == TRC_ANSB ? 16 * (size_t)chunk : codec == TRC_ANSA4 ? 4 * (size_t)chunk : 0;
+}
+
+// bytes of the second scratch array (the bitwise coder's rows are indexed by LANE, dead lanes of the last wave included)
+static inline size_t scratch2_bytes(int codec, size_t nchunks, uint32_t chunk)
+{
+    const size_t rows = codec == TRC_RCB ? ((nchunks + 63) & ~(size_t)63) : nchunks;
+    return up256(rows * scratch2_stride(codec, chunk) + 256);
 }
 
 static uint32_t scratch_stride(int codec, uint32_t chunk)
@@ -112,7 +120,7 @@ extern "C" size_t trc_work_bytes(int codec, size_t n, uint32_t chunk)
     if (!chunk_ok(chunk)) return 0;
     const size_t nchunks = (n + chunk - 1) / chunk, ngroups = (nchunks + 63) / 64;
     return up256(TRC_TAB_BYTES) + up256(4 * ngroups) + up256(8 * (ngroups + 1)) +
-           up256(nchunks * (size_t)scratch_stride(codec, chunk)) + up256(nchunks * scratch2_stride(codec, chunk) + 256) +
+           up256(nchunks * (size_t)scratch_stride(codec, chunk)) + scratch2_bytes(codec, nchunks, chunk) +
            (codec == TRC_ANSO1 ? up256(nchunks * (size_t)TRC_O1_MODEL_BYTES) : 0) +
            ((codec >= TRC_VLCU16 && codec <= TRC_VLAVZ32) ? up256(nchunks * 8) : 0) + 4096;
 }
@@ -132,7 +140,7 @@ static int carve(int codec, size_t n, uint32_t chunk, void *d_work, size_t work_
     w.stride = scratch_stride(codec, chunk);
     w.stride2 = (uint32_t)scratch2_stride(codec, chunk);
     w.scratch2 = p + up256(nchunks * (size_t)w.stride);
-    w.model = w.scratch2 + up256(nchunks * scratch2_stride(codec, chunk) + 256);
+    w.model = w.scratch2 + scratch2_bytes(codec, nchunks, chunk);
     w.aux = (uint32_t *)(w.model + (codec == TRC_ANSO1 ? up256(nchunks * (size_t)TRC_O1_MODEL_BYTES) : 0));
     w.nchunks = (uint32_t)nchunks; w.ngroups = (uint32_t)ngroups;
     return TRC_OK;

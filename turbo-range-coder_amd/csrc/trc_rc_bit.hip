@@ -19,6 +19,13 @@
 //            the eight coding steps run on registers (state on 32-bit halves, mask selects, one emit per byte);
 //   decoder  the path depends on the decoded bits; both children of the current node are requested before the bit is
 //            resolved, the bit is the borrow of code - cut and everything that depends on it a select under its mask.
+// Round 3, ENCODER only: the deepest tree level (nodes 128..255: half of the model) lives in global memory, one 256-byte row per
+// lane, filled by the wave itself at its start -- 16 KiB of model per wave in LDS instead of 32: nine waves per CU where five fit,
+// i.e. more than two per SIMD, which is what fills the issue gaps of a one-wave-per-SIMD kernel (round 2's half-model ablation:
+// 1.4x).  The encoder knows a byte's level-7 node when it has the byte, so the 2-byte load is issued with the LDS reads and is
+// back long before the last bit is coded; the decoder learns that node only from the seventh bit it has just decoded, a memory
+// round trip on its critical path per byte, and keeps the whole model in LDS.  Measured: it buys residency, not throughput (the launch code says when it is used).
+#include <stdlib.h>
 #include "trc_rc.h"
 #include "trc_nibmodel.h"
 #include "trc_lane_io.h"
@@ -34,6 +41,7 @@
 #define RCB_AMASK 0x7fffu
 #endif
 #define RCB_WAVE_LDS    RCB_MODEL_BYTES
+#define RCB_ENC_WAVE_LDS(L7G) ((L7G) ? RCB_MODEL_BYTES / 2u : RCB_MODEL_BYTES)
 
 // (a & m) | (b & ~m) as the one instruction it is (from the C form the compiler builds and / and-or pairs, or compares and selects)
 __device__ __forceinline__ u32 rcb_bfi(u32 m, u32 a, u32 b)
@@ -44,14 +52,29 @@ __device__ __forceinline__ u32 rcb_bfi(u32 m, u32 a, u32 b)
 }
 __device__ __forceinline__ u32 rcb_adapt(u32 p, u32 bit) { return (p - (((p - (bit << TRC_PROB_BITS)) >> 5) + bit)) & 0xffffu; }
 
+template <bool L7G>
 __global__ __launch_bounds__(64) void trc_rcb_enc_kernel(
     const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks,
-    u8 *__restrict__ scratch, u32 stride, u32 *__restrict__ clen, u32 *__restrict__ gsum)
+    u8 *__restrict__ scratch, u32 stride, u8 *__restrict__ level7, u32 *__restrict__ clen, u32 *__restrict__ gsum)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const u32 lane = threadIdx.x;
     u16 *mb = (u16 *)smem + lane;                              // mb[ctx * 64]
-    for (u32 i = 0; i < RCB_MODEL_BYTES / 128u; i++) mb[i * 64] = (u16)(TRC_PROB_ONE >> 1);
+    for (u32 i = 0; i < RCB_ENC_WAVE_LDS(L7G) / 128u; i++) mb[i * 64] = (u16)(TRC_PROB_ONE >> 1);
+    u16 *l7 = nullptr;
+    if constexpr (L7G) {
+    // this wave's level-7 rows: 64 lanes x 256 B, contiguous -- filled with coalesced 16-byte stores (lane l: bytes 16 l + 1024 i),
+    // then every lane works on its own row.  The loads below see these stores: same wave, the stores are waited for.
+    u8 *l7w = level7 + (u64)blockIdx.x * (64u * 256u);
+    {
+        const u32 h = (TRC_PROB_ONE >> 1) | (TRC_PROB_ONE >> 1) << 16;
+#pragma unroll
+        for (u32 i = 0; i < 16u; i++) *(uint4 *)(l7w + lane * 16u + i * 1024u) = make_uint4(h, h, h, h);
+        __builtin_amdgcn_s_waitcnt(0x0f70);                    // vmcnt(0) (the compiler does not order the plain stores against the u16 loads of other lanes' bytes)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    }
+    l7 = (u16 *)(l7w + lane * 256u);                           // l7[node - 128]
+    }
 
     WaveChunks wc;
     wc.c0 = blockIdx.x * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
@@ -100,8 +123,10 @@ __global__ __launch_bounds__(64) void trc_rcb_enc_kernel(
 #pragma unroll
         for (int k = 1; k < 8; k++) ad[k] = (((t >> (8 - k)) << 7) & RCB_AMASK) + mcol;
         u32 pr[8];
+        u16 *g7 = l7 + ((t >> 1) & 127u);                      // (L7G) the byte's level-7 node
+        if constexpr (L7G) pr[7] = *g7; else pr[7] = trc_ldsr16(ad[7]);
 #pragma unroll
-        for (int k = 0; k < 8; k++) pr[k] = trc_ldsr16(ad[k]);
+        for (int k = 0; k < 7; k++) pr[k] = trc_ldsr16(ad[k]);
         u32 P[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -110,7 +135,8 @@ __global__ __launch_bounds__(64) void trc_rcb_enc_kernel(
             const trc_s2 pv = trc_as_s2(P[j]), bv = trc_as_s2(B);
             const trc_s2 np = pv - (((pv - trc_as_s2(B << 15)) >> (trc_s2)5) + bv);
             const u32 NP = trc_as_u32(np);
-            trc_ldsw16(ad[2 * j], NP); trc_ldsw16(ad[2 * j + 1], NP >> 16);
+            trc_ldsw16(ad[2 * j], NP);
+            if (L7G && j == 3) *g7 = (u16)(NP >> 16); else trc_ldsw16(ad[2 * j + 1], NP >> 16);
         }
         bool rnj[4], cyj[4];
         u32 pwj[4];
@@ -320,9 +346,21 @@ __global__ __launch_bounds__(64) void trc_rcb_dec_kernel(
 
 void trc_launch_rcb_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
 {
-    TRC_RAISE_LDS_ONCE(trc_rcb_enc_kernel, RCB_WAVE_LDS);
-    TRC_LAUNCH_TIMED(trc_rcb_enc_kernel, dim3(w.ngroups), dim3(64), RCB_WAVE_LDS, s,
-                       d_in, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
+    // Level 7 in global memory buys residency (9 waves per CU instead of 5), not throughput: its two scattered 2-byte accesses
+    // per byte and lane keep the texture-address unit as busy as the second wave per SIMD keeps the ALUs fed (100 MB, chunk 512:
+    // 1.68 -> 1.86-2.0 ms).  It pays where it saves a residency ROUND: more waves than 5 per CU hold, no more than 9 per CU
+    // hold (100 MB at chunk 1024: 1526 waves, 2.12 -> 1.30 ms).  TRC_RCB_L7G=0 / 1 force a form.
+    static const int env = getenv("TRC_RCB_L7G") ? atoi(getenv("TRC_RCB_L7G")) : -1;
+    const bool l7g = env >= 0 ? env != 0 : (w.ngroups > 5u * 256u && w.ngroups <= 9u * 256u);
+    if (l7g) {
+        TRC_RAISE_LDS_ONCE(trc_rcb_enc_kernel<true>, RCB_ENC_WAVE_LDS(true));
+        TRC_LAUNCH_TIMED(trc_rcb_enc_kernel<true>, dim3(w.ngroups), dim3(64), RCB_ENC_WAVE_LDS(true), s,
+                           d_in, (u64)n, chunk, w.nchunks, w.scratch, w.stride, w.scratch2, d_clen, w.gsum);
+    } else {
+        TRC_RAISE_LDS_ONCE(trc_rcb_enc_kernel<false>, RCB_ENC_WAVE_LDS(false));
+        TRC_LAUNCH_TIMED(trc_rcb_enc_kernel<false>, dim3(w.ngroups), dim3(64), RCB_ENC_WAVE_LDS(false), s,
+                           d_in, (u64)n, chunk, w.nchunks, w.scratch, w.stride, w.scratch2, d_clen, w.gsum);
+    }
 }
 void trc_launch_rcb_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                         const TrcWork &w, uint8_t *d_out, hipStream_t s)
