@@ -88,10 +88,14 @@ CODEC_INFO = {
 }
 
 
-# chunk size with the best throughput at 100 MB per GPU where it is not 512 (one residency round of the waves:
-# rccdfs2 runs one lane per stream: chunk 1024 gives it the lanes chunk 512 gives the one-stream coder; the order-1 coder needs room for its context statistics;
-# rcs at chunk 768 is one residency round for the encoder with its deepest tree level in global memory: 35.7 GB/s against 33.5 at 512, and 69.3 % instead of 70.9 %)
-BEST_CHUNK = {"rccdfs2": 1024, "anscdf1": 4096, "rcs": 768}
+# chunk size with the best throughput at 100 MB per GPU where it is not 512: ONE residency round of the coder's waves.
+# A launch's time is (rounds of resident waves) x (one wave's time, ~ chunk bytes), so the chunk that makes the input exactly
+# one round costs the fewest per-round starts and codes best.  Static coders hold 12 waves per CU: 512 (3052 waves).
+# rccdfs2 runs one lane per stream: chunk 1024 gives it the lanes chunk 512 gives the one-stream coder.  The coders with a
+# model per lane in LDS (byte-adaptive, bitwise) hold 4 waves per CU = 1024 waves: chunk 1536 (1018 waves) -- rccdf 51.7 -> 66.6,
+# anscdf 45.6 -> 56.2, ansb 26.6 -> 33.5, rcs 35.7 (at 768) -> 38.9 GB/s; 1280 (1221 waves, two rounds) is the worst point of
+# the sweep at 35 GB/s (profiles/r03_notes.md section 7).  The order-1 coder needs room for its context statistics.
+BEST_CHUNK = {"rccdfs2": 1024, "anscdf1": 4096, "rcs": 1536, "rccdf": 1536, "rccdfi": 1536, "anscdf": 1536, "ansb": 1536}
 
 
 def make_input(n, rank, kind="text"):

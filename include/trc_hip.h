@@ -94,12 +94,16 @@ const char *trc_last_error(void);
 int trc_device_count(void);
 
 /* chunk size of the host-pointer (reference-signature) calls, process-wide.  0 = automatic (the default): every call
- * takes trc_auto_chunk(its input length) -- the largest of 4096 / 2048 / 1024 / 512 that still fills the chip (one
- * residency round of 196 608 chunks: >= 805 / 403 / 201 MB), 512 below.  trc_set_chunk(c) or TRC_CHUNK=c in the
- * environment fix it; trc_set_chunk(0) returns to automatic.  Decoders take the size from the container. */
+ * takes trc_auto_chunk_codec(its coder, its input length).  Static coders (trc_auto_chunk): the largest of 4096 / 2048 /
+ * 1024 / 512 that still fills the chip (one residency round of 196 608 chunks: >= 805 / 403 / 201 MB), 512 below.
+ * Coders with a model per lane in LDS hold 4 waves per CU (a round is 65 536 chunks, which is also the slice their
+ * host-pointer calls pipeline by): the larger chunk only when 16 such slices remain (>= 4.3 / 2.1 / 1 GB); order-1 rANS
+ * always 4096.  trc_set_chunk(c) or TRC_CHUNK=c in the environment fix it; trc_set_chunk(0) returns to automatic.
+ * Decoders take the size from the container. */
 int      trc_set_chunk(uint32_t chunk);
 uint32_t trc_get_chunk(void);
 uint32_t trc_auto_chunk(size_t n);
+uint32_t trc_auto_chunk_codec(int codec, size_t n);
 
 /* ---- device-resident layer --------------------------------------------------------------------
  * All d_* pointers are device pointers on the current HIP device, 16-byte aligned, with TRC_PAD

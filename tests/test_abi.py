@@ -62,6 +62,13 @@ def test_config_calls_work_without_gpu(lib):
     lib.trc_auto_chunk.restype = ctypes.c_uint32
     lib.trc_auto_chunk.argtypes = [ctypes.c_size_t]
     assert [lib.trc_auto_chunk(n) for n in (1, 100 * 10**6, 201326591, 201326592, 402653184, 805306368, 8 * 10**9)] == [512, 512, 512, 1024, 2048, 4096, 4096]
+    # ... and its coder: the model-per-lane coders fill the chip with 65 536 chunks, and go up only with 16 slices of that left
+    lib.trc_auto_chunk_codec.restype = ctypes.c_uint32
+    lib.trc_auto_chunk_codec.argtypes = [ctypes.c_int, ctypes.c_size_t]
+    GB = 1 << 30
+    assert [lib.trc_auto_chunk_codec(1, n) for n in (1, 100 * 10**6, 201326592, 8 * 10**9)] == [512, 512, 1024, 4096]        # static rANS
+    assert [lib.trc_auto_chunk_codec(4, n) for n in (1, 100 * 10**6, GB - 1, GB, 2 * GB, 4 * GB)] == [512, 512, 512, 1024, 2048, 4096]
+    assert [lib.trc_auto_chunk_codec(12, n) for n in (1, 100 * 10**6, 8 * GB)] == [4096, 4096, 4096]                          # order-1 rANS
     if "TRC_CHUNK" not in os.environ:
         assert lib.trc_get_chunk() == 0                                   # automatic by default
     assert lib.trc_set_chunk(2048) == 0 and lib.trc_get_chunk() == 2048

@@ -52,12 +52,24 @@ extern "C" int trc_device_count(void)
 // every chunk costs 8 bytes of coder state and 4 bytes of directory.  Unless the caller fixes the size (trc_set_chunk,
 // TRC_CHUNK), a host-pointer call picks it from its input length: the largest of 4096 / 2048 / 1024 / 512 that still
 // gives one full residency round (>= 805 / 403 / 201 MB), 512 below that.
+// The coders that keep a MODEL per lane in LDS (adaptive, bitwise, order-1) hold 4 waves per CU, not 12: one residency
+// round is 65 536 chunks, and that is also the slice of their host-pointer calls (slice_plan).  They take the larger
+// chunk only when the call still has 16 such slices to pipeline (>= 1 / 2.1 / 4.3 GB).
+#define TRC_MODEL_ROUND_CHUNKS 65536u                         // 256 CUs x 4 waves x 64 lanes
 static uint32_t g_chunk = 0;                                  // 0: not read yet;  ~0u: automatic
 static bool chunk_ok(uint32_t c) { return c >= TRC_CHUNK_MIN && c <= TRC_CHUNK_MAX && (c % 64u) == 0; }
 extern "C" uint32_t trc_auto_chunk(size_t n)
 {
     for (uint32_t c = 4096u; c > TRC_CHUNK_AUTO_MIN; c >>= 1)
         if (n / c >= 196608u) return c;
+    return TRC_CHUNK_AUTO_MIN;
+}
+extern "C" uint32_t trc_auto_chunk_codec(int codec, size_t n)
+{
+    if (codec == TRC_ANS4S || codec == TRC_RCS1 || codec == TRC_RCS2 || codec == TRC_RCSM) return trc_auto_chunk(n);
+    if (codec == TRC_ANSO1) return 4096u;                     // 256 x 17 tables per chunk: nothing to learn from in fewer bytes (and 136 KiB of workspace each)
+    for (uint32_t c = 4096u; c > TRC_CHUNK_AUTO_MIN; c >>= 1)
+        if (n / c / TRC_MODEL_ROUND_CHUNKS >= 16u) return codec == TRC_ANSB && c > TRC_ANSB_CHUNK_MAX ? TRC_ANSB_CHUNK_MAX : c;
     return TRC_CHUNK_AUTO_MIN;
 }
 extern "C" uint32_t trc_get_chunk(void)
@@ -584,16 +596,22 @@ int host_cdfnum(const cdf_t *cdf)
     }
     return -1;
 }
-// Slice plan of a host-pointer call: whole groups of 64 chunks, ~16 MB of input per slice in the middle of the call
-// (TRC_HOST_SLICE overrides the byte target; 8-32 MB measure alike on the MI355X box, 4 MB throughout is 30 % slower: per-slice
-// synchronisation), ramping up from 1/8 of that at the start and down to 1/8 at the end: the first H2D copy and the last
-// D2H copy + unstaging are the part of the pipeline nothing overlaps with, so they are kept short.
+// Slice plan of a host-pointer call: whole groups of 64 chunks.  Static coders: ~16 MB of input per slice in the middle of
+// the call (8-32 MB measure alike on the MI355X box, 4 MB throughout is 30 % slower: per-slice synchronisation) -- their
+// kernels are far faster than the link, so the slice is sized for the copies.  Model-per-lane coders: one residency round of
+// 65 536 chunks (32 MB at chunk 512), because a launch with fewer waves than the chip holds still takes one wave's full time:
+// with 16 MB slices the kernels, not the link, set the pace (page-locked 100 MB, GB/s: rccdf 33 -> 41, rcs 18 -> 38,
+// ansb 16 -> 29, rccdf8 22 -> 38, order-1 1.7 -> 9 with its whole input in one slice; profiles/r03_notes.md section 7).
+// TRC_HOST_SLICE overrides the byte target for every coder.  The plan ramps up from 1/8 of the slice at the start and down
+// to 1/8 at the end: the first H2D copy and the last D2H copy + unstaging are the part of the pipeline nothing overlaps
+// with, so they are kept short.
 // first[i] = first chunk of slice i, first[nsl] = nchunks; returns the largest slice in chunks.
-size_t slice_plan(uint32_t chunk, size_t nchunks, std::vector<size_t> &first)
+size_t slice_plan(int codec, uint32_t chunk, size_t nchunks, std::vector<size_t> &first)
 {
-    static const size_t target = getenv("TRC_HOST_SLICE") ? (size_t)strtoull(getenv("TRC_HOST_SLICE"), 0, 10) : (size_t)16 << 20;
+    static const size_t forced = getenv("TRC_HOST_SLICE") ? (size_t)strtoull(getenv("TRC_HOST_SLICE"), 0, 10) : 0;
     static const bool ramp = !getenv("TRC_HOST_NO_RAMP");
-    size_t groups = target / ((size_t)chunk * 64);
+    const size_t target = forced ? forced : (size_t)16 << 20;
+    size_t groups = forced || is_static(codec) ? target / ((size_t)chunk * 64) : TRC_MODEL_ROUND_CHUNKS / 64;
     if (groups < 1) groups = 1;
     size_t per = groups * 64;
     while ((nchunks + per - 1) / per > 2000) per *= 2;                    // the totals area holds 2048 slices
@@ -634,10 +652,10 @@ static size_t host_encode(int codec, const unsigned char *in, size_t inlen, unsi
     if (ctx_init(c, dev)) return 0;
     HostDrain guard(c);
     uint32_t chunk = chunk_override ? chunk_override : trc_get_chunk();
-    if (!chunk) chunk = trc_auto_chunk(inlen);
+    if (!chunk) chunk = trc_auto_chunk_codec(codec, inlen);
     if (!chunk_ok(chunk)) { fail(TRC_E_ARG, "chunk %u: must be a multiple of 64 in [%u,%u]", chunk, TRC_CHUNK_MIN, TRC_CHUNK_MAX); return 0; }
     if (codec == TRC_ANSB && chunk > TRC_ANSB_CHUNK_MAX) chunk = TRC_ANSB_CHUNK_MAX;
-    if (codec == TRC_ANSO1 && chunk < 4096u && !chunk_override) chunk = 4096u;    // 256 x 17 tables per chunk: nothing to learn from in fewer bytes (and 136 KiB of workspace each)
+    if (codec == TRC_ANSO1 && chunk < 4096u && !chunk_override) chunk = 4096u;    // also under TRC_CHUNK / trc_set_chunk: see trc_auto_chunk_codec
     const size_t nchunks = (inlen + chunk - 1) / chunk, dir = 4 * nchunks, hdrsz = sizeof(trc_container_hdr);
     if (outcap && outcap < hdrsz + dir + inlen) { fail(TRC_E_ARG, "encode_host: out holds %zu bytes, the container may need %zu", outcap, hdrsz + dir + inlen); return 0; }
     if (is_static(codec)) {
@@ -645,7 +663,7 @@ static size_t host_encode(int codec, const unsigned char *in, size_t inlen, unsi
         if (cdfnum <= 0 || cdfnum > 256) { fail(TRC_E_CDF, "bad CDF (need cdf[0]=0 < ... < cdf[cdfnum]=32768)"); return 0; }
     } else cdfnum = 0;
     std::vector<size_t> sc;
-    const size_t per = slice_plan(chunk, nchunks, sc), nsl = sc.size() - 1;
+    const size_t per = slice_plan(codec, chunk, nchunks, sc), nsl = sc.size() - 1;
     const size_t slice_bytes = per * (size_t)chunk;
     const size_t wb = trc_work_bytes(codec, slice_bytes < inlen ? slice_bytes : inlen, chunk);
     // page-locked caller buffers are read / written by DMA directly (no staging copy on that side)
@@ -771,7 +789,7 @@ static size_t host_decode(int codec, const unsigned char *in, size_t outlen, uns
         if (cdfnum <= 0 || cdfnum > 256) { fail(TRC_E_CDF, "bad CDF"); return 0; }
     } else cdfnum = 0;
     std::vector<size_t> sc;
-    const size_t per = slice_plan(chunk, nchunks, sc), nsl = sc.size() - 1;
+    const size_t per = slice_plan(codec, chunk, nchunks, sc), nsl = sc.size() - 1;
     const size_t slice_bytes = per * (size_t)chunk;
     const size_t wb = trc_work_bytes(codec, slice_bytes < outlen ? slice_bytes : outlen, chunk);
     // page-locked caller buffers are read / written by DMA directly (no staging copy on that side)
