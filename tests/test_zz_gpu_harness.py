@@ -187,6 +187,11 @@ def test_c_harness_links_and_roundtrips(torch_cuda):
     assert r.returncode == 0 and "MISMATCH" not in r.stdout and "failed" not in r.stdout and "page-locked" in r.stdout, r.stdout + r.stderr
     r = subprocess.run([exe, "-I", "1", "--pin", "-e", "42,65", "--uniform", "3000001"], capture_output=True, text=True, timeout=300)   # raw return through pinned `out`
     assert r.returncode == 0 and "MISMATCH" not in r.stdout and "failed" not in r.stdout, r.stdout + r.stderr
+    # adaptive / bitwise coders are sliced by one residency round (65 536 chunks = 32 MB at the automatic chunk 512): 150 MB is five
+    # slices with the ramps at both ends, pageable (staged) and page-locked (direct)
+    for pin in ([], ["--pin"]):
+        r = subprocess.run([exe, "-I", "1", "-e", "1,46,66"] + pin + ["--text", "150000001"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "MISMATCH" not in r.stdout and "failed" not in r.stdout and r.stdout.count(":") >= 4, r.stdout + r.stderr
     for args in (["--int16", "2000000"], ["--int32", "4000000"]):        # integer series: the Turbo-VLC coders
         r = subprocess.run([exe, "-I", "1", "-e", "50,52,53,60,61,62,63"] + args, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "MISMATCH" not in r.stdout and "failed" not in r.stdout, r.stdout + r.stderr

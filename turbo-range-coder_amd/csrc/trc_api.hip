@@ -558,6 +558,8 @@ int grow_pins(HostCtx &c, size_t need)
 {
     need = up256(need + TRC_PAD);
     if (c.cap_pin >= need) return TRC_OK;
+    const size_t twice = 2 * c.cap_pin < ((size_t)40 << 20) ? 2 * c.cap_pin : (size_t)40 << 20;    // calls of growing length re-pin a few times, not every time
+    if (need < twice) need = twice;
     for (int i = 0; i < TRC_NSLOT; i++) {
         if (c.pin_in[i]) HIPCHK(hipHostFree(c.pin_in[i]));
         if (c.pin_out[i]) HIPCHK(hipHostFree(c.pin_out[i]));
@@ -612,6 +614,7 @@ size_t slice_plan(int codec, uint32_t chunk, size_t nchunks, std::vector<size_t>
     static const bool ramp = !getenv("TRC_HOST_NO_RAMP");
     const size_t target = forced ? forced : (size_t)16 << 20;
     size_t groups = forced || is_static(codec) ? target / ((size_t)chunk * 64) : TRC_MODEL_ROUND_CHUNKS / 64;
+    if (!forced && groups * 64 * (size_t)chunk > ((size_t)256 << 20)) groups = ((size_t)256 << 20) / ((size_t)chunk * 64);   // caller-fixed chunks above 4096: the staging slots stay <= 256 MB
     if (groups < 1) groups = 1;
     size_t per = groups * 64;
     while ((nchunks + per - 1) / per > 2000) per *= 2;                    // the totals area holds 2048 slices
@@ -631,7 +634,8 @@ size_t slice_plan(int codec, uint32_t chunk, size_t nchunks, std::vector<size_t>
     c += left;
     for (size_t k = tail.size(); k-- > 0;) { first.push_back(c); c += tail[k]; }      // largest first: per/2, per/4, per/8
     first.push_back(nchunks);
-    return per;
+    const size_t all = (nchunks + 63) / 64 * 64;                            // a short call sizes its staging slots and workspace by what it has
+    return per < all ? per : all;
 }
 }  // namespace
 
