@@ -351,6 +351,11 @@ BENCH_CONFIGS = [
     dict(name="anscdf-bwt100m-512", codec=ANSA, kind="bwt", seed=3, n=100 * 1000 * 1000, chunk=512),           # config 3, `-e56`
     dict(name="rcs-text100m-512", codec=RCB, kind="text", seed=7, n=100 * 1000 * 1000, chunk=512),             # config 4, `-e1`
     dict(name="anscdf4s-text100m-4096", codec=ANS4S, kind="text", seed=7, n=100 * 1000 * 1000, chunk=4096),    # the chunk size of the large-input regime
+    # the chunks bench.py runs these coders at since round 3 (one residency round of their waves at 100 MB)
+    dict(name="rccdfs2-text100m-1024", codec=RCS2, kind="text", seed=7, n=100 * 1000 * 1000, chunk=1024),
+    dict(name="rccdf-bwt100m-1536", codec=RCA, kind="bwt", seed=3, n=100 * 1000 * 1000, chunk=1536),
+    dict(name="anscdf-bwt100m-1536", codec=ANSA, kind="bwt", seed=3, n=100 * 1000 * 1000, chunk=1536),
+    dict(name="rcs-text100m-1536", codec=RCB, kind="text", seed=7, n=100 * 1000 * 1000, chunk=1536),
 ]
 
 
