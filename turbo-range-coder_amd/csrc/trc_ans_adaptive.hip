@@ -26,6 +26,9 @@
 #include "trc_nibmodel.h"
 #include "trc_launch.h"
 
+#ifndef ANSA_BATCH
+#define ANSA_BATCH 4                                           // bytes per record_bytes call of the model pass (divides 8)
+#endif
 #define ANSA_MODEL_LDS(NIB) ((NIB) ? TRC_NIB1_BYTES : TRC_NIB_BYTES)
 #define ANSA_CODE_LDS       (TRC_TILE_BYTES + TRC_SRING_BYTES)
 
@@ -58,6 +61,7 @@ __global__ __launch_bounds__(64) void trc_ansa_model_kernel(
 
     QuadIn qin; qin.base = in + (u64)wc.c0 * chunk;
     QuadOut qout; qout.base = recs + (u64)wc.c0 * wr.chunk;
+    NibTable T0 = m.load(m.table(0));                          // the hi table (the only table of the nibble coder): registers, see record_bytes
 
     const u32 S = chunk / TRC_SEG;
     qin.issue(wc, 0);
@@ -76,20 +80,27 @@ __global__ __launch_bounds__(64) void trc_ansa_model_kernel(
                 for (int h = 0; h < 2; h++) {                  // 8 input bytes -> 16 records = one 64-byte record segment
                     u32 r[16];
 #pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        u32 x = (w[2 * h + (i >> 2)] >> (8 * (i & 3))) & 255u;
-                        if (p0 + 8u * (u32)h + (u32)i >= len) x = 0;      // the coded dummy of an odd tail (and unused padding)
-                        r[2 * i] = m.record(m.table(0), x >> 4);
-                        r[2 * i + 1] = m.record(m.table(1u + (x >> 4)), x & 15u);
+                    for (int q = 0; q < 8 / ANSA_BATCH; q++) {
+                        u32 x[ANSA_BATCH], rr[2 * ANSA_BATCH];
+#pragma unroll
+                        for (int i = 0; i < ANSA_BATCH; i++) {
+                            const int b = q * ANSA_BATCH + i;
+                            x[i] = (w[2 * h + (b >> 2)] >> (8 * (b & 3))) & 255u;
+                            if (p0 + 8u * (u32)h + (u32)b >= len) x[i] = 0;  // the coded dummy of an odd tail (and unused padding)
+                        }
+                        m.template record_bytes<ANSA_BATCH>(T0, x, rr);
+#pragma unroll
+                        for (int i = 0; i < 2 * ANSA_BATCH; i++) r[2 * q * ANSA_BATCH + i] = rr[i];
                     }
 #pragma unroll
                     for (int j = 0; j < 4; j++) qout.put((u32)j, make_uint4(r[4 * j], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]));
                     qout.flush(wr, (p0 + 8u * (u32)h) * 8u);
                 }
             } else {
-                u32 r[16];                                     // 16 input values -> 16 records
+                u32 r[16], x[16];                              // 16 input values -> 16 records
 #pragma unroll
-                for (int i = 0; i < 16; i++) r[i] = m.record(m.table(0), (w[i >> 2] >> (8 * (i & 3))) & 15u);
+                for (int i = 0; i < 16; i++) x[i] = (w[i >> 2] >> (8 * (i & 3))) & 15u;
+                m.template record_nibs<16>(T0, x, r);
 #pragma unroll
                 for (int j = 0; j < 4; j++) qout.put((u32)j, make_uint4(r[4 * j], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]));
                 qout.flush(wr, p0 * 4u);

@@ -85,9 +85,10 @@ struct NibModel {
         c1 = x == 15u ? TRC_PROB_ONE : n;
     }
     // cdf16upd for coded symbol x
-    __device__ __forceinline__ void adapt(NibTable &T, u32 x) const
+    __device__ __forceinline__ void adapt(NibTable &T, u32 x) const { adapt_k(T, load(kb + x * 32u)); }
+    // the same with the K row of the symbol already in registers
+    __device__ __forceinline__ void adapt_k(NibTable &T, const NibTable &K) const
     {
-        const NibTable K = load(kb + x * 32u);
         // three passes over the eight dwords, not eight three-step chains: on gfx950 a packed shift that reads the result of
         // the packed subtract right before it costs a wait state (the compiler fills it with an s_nop)
         trc_s2 d[8];
@@ -104,6 +105,62 @@ struct NibModel {
         u32 c0, c1; bounds(tb, x, c0, c1);
         NibTable T = load(tb); adapt(T, x); store(tb, T);
         return (c0 << TRC_PROB_BITS) | (c1 - c0);
+    }
+    // Encoder side, NB bytes at once (byte model).  An encoder knows its symbols, hence every table ADDRESS, before it
+    // walks them: with one wave per SIMD nothing hides an LDS round trip, and record() per nibble puts four dependent
+    // ones into every byte (table load -> adapt -> store -> the next load of the same table).  Here the K rows of all
+    // 2 NB nibbles and the lo tables of all NB bytes are requested first; the hi table T0 lives in registers for the
+    // whole chunk (its LDS copy is only written, for the bounds reads); a lo table that an EARLIER byte of the batch has
+    // already updated is taken from that byte's registers instead (hi nibbles equal: 8 v_cndmask), so the chain from
+    // byte to byte is VALU only.  LDS executes a wave's accesses in order: every bounds read sees the stores before it,
+    // and the bounds are USED only after the walk, so nothing waits inside it.
+    // r[2i] = hi record of byte i, r[2i + 1] = lo record.
+    template <int NB>
+    __device__ __forceinline__ void record_bytes(NibTable &T0, const u32 (&x)[NB], u32 (&r)[2 * NB]) const
+    {
+        NibTable Kh[NB], Kl[NB], L[NB], U[NB];
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            Kh[i] = load(kb + (x[i] >> 4) * 32u);
+            Kl[i] = load(kb + (x[i] & 15u) * 32u);
+            L[i] = load(table(1u + (x[i] >> 4)));
+        }
+        u32 c0[2 * NB], c1[2 * NB];
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const u32 h = x[i] >> 4, l = x[i] & 15u;
+            bounds(table(0), h, c0[2 * i], c1[2 * i]);
+            adapt_k(T0, Kh[i]); store(table(0), T0);
+            NibTable T = L[i];
+#pragma unroll
+            for (int j = 0; j < i; j++) {
+                const bool same = (x[j] >> 4) == h;
+#pragma unroll
+                for (int k = 0; k < 8; k++) T.d[k] = same ? U[j].d[k] : T.d[k];
+            }
+            u8 *tb = table(1u + h);
+            bounds(tb, l, c0[2 * i + 1], c1[2 * i + 1]);
+            adapt_k(T, Kl[i]); store(tb, T);
+            U[i] = T;
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * NB; i++) r[i] = (c0[i] << TRC_PROB_BITS) | (c1[i] - c0[i]);
+    }
+    // NN symbols through ONE table held in registers (nibble coders; T0's LDS copy serves the bounds reads)
+    template <int NN>
+    __device__ __forceinline__ void record_nibs(NibTable &T0, const u32 (&x)[NN], u32 (&r)[NN]) const
+    {
+        NibTable K[NN];
+#pragma unroll
+        for (int i = 0; i < NN; i++) K[i] = load(kb + x[i] * 32u);
+        u32 c0[NN], c1[NN];
+#pragma unroll
+        for (int i = 0; i < NN; i++) {
+            bounds(table(0), x[i], c0[i], c1[i]);
+            adapt_k(T0, K[i]); store(table(0), T0);
+        }
+#pragma unroll
+        for (int i = 0; i < NN; i++) r[i] = (c0[i] << TRC_PROB_BITS) | (c1[i] - c0[i]);
     }
     // the same where `on`; elsewhere the table stays as it is and the record is 0 (freq 0: never coded)
     __device__ __forceinline__ u32 record_if(bool on, u8 *tb, u32 x) const

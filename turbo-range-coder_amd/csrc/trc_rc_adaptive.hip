@@ -54,6 +54,7 @@ __global__ __launch_bounds__(64) void trc_rca_enc_kernel(
     o1.start(NS == 2 ? scratch2 + (u64)c * stride2 : scratch);
     RcEncD e0, e1; e0.start(); e1.start();
     bool ovf = alive && NS == 1 && lim <= 0;
+    NibTable T0 = m.load(m.table(0));                          // hi table / the nibble coders' table: registers (record_bytes, trc_nibmodel.h)
 
     const u32 S = chunk / TRC_SEG;
     qin.issue(wc, 0);
@@ -73,15 +74,14 @@ __global__ __launch_bounds__(64) void trc_rca_enc_kernel(
                 // ---- model: 4 bytes -> records (no coder state involved)
                 u32 rc[8];
                 if (!NIB) {
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const u32 x = (w >> (8 * i)) & 255u, h = x >> 4;
-                        rc[2 * i] = m.record(m.table(0), h);
-                        rc[2 * i + 1] = m.record(m.table(1u + h), x & 15u);
-                    }
+                    const u32 x[4] = { w & 255u, (w >> 8) & 255u, (w >> 16) & 255u, w >> 24 };
+                    m.template record_bytes<4>(T0, x, rc);
                 } else if (NS == 1) {
+                    const u32 x[4] = { w & 15u, (w >> 8) & 15u, (w >> 16) & 15u, (w >> 24) & 15u };
+                    u32 r4[4];
+                    m.template record_nibs<4>(T0, x, r4);
 #pragma unroll
-                    for (int i = 0; i < 4; i++) rc[i] = m.record(m.table(0), (w >> (8 * i)) & 15u);
+                    for (int i = 0; i < 4; i++) rc[i] = r4[i];
                 } else {
 #pragma unroll
                     for (int pr = 0; pr < 2; pr++) {           // both symbols against the table before the pair
