@@ -234,6 +234,18 @@ __global__ __launch_bounds__(64) void trc_ansa_dec_kernel(
         m.adapt(T, x); m.store(tb, T);
         return x;
     };
+    // Table 0 (the hi-nibble table of the byte model, the only table of the nibble coder) is used at every step: it lives in
+    // registers for the whole chunk and never travels to LDS -- two of the four dependent LDS round trips of a byte (one wave
+    // per SIMD: nothing else hides them), as in the range decoders (trc_rc_adaptive.hip)
+    NibTable T0 = m.load(m.table(0));
+    auto get_hi = [&](u32 &s, bool act) -> u32 {
+        const u32 slot = s & (TRC_PROB_ONE - 1);
+        u32 c0, c1;
+        const u32 x = trc_nib_find(T0, slot, c0, c1);
+        s = act ? __umul24(c1 - c0, s >> TRC_PROB_BITS) + slot - c0 : s;
+        m.adapt(T0, x);
+        return x;
+    };
     auto renorm = [&](u32 &s, bool act) {
         const u32 w = si.peek16();
         const bool rn = act && s < TRC_ANS_LOW;
@@ -260,8 +272,8 @@ __global__ __launch_bounds__(64) void trc_ansa_dec_kernel(
                         for (int j = 0; j < 2; j++) {          // mndec8x2: two bytes, then four renorms in order st0..st3
                             const bool act = coded && q0 + 2u * (u32)j < len;     // the second byte of an odd tail is the dummy
                             const uint4 pre = si.prefetch();   // (<= 8 stream bytes per group: trc_lane_io.h LaneInWide)
-                            const u32 h0 = get_nibble(st[0], m.table(0), act), l0 = get_nibble(st[1], m.table(1u + h0), act);
-                            const u32 h1 = get_nibble(st[2], m.table(0), act), l1 = get_nibble(st[3], m.table(1u + h1), act);
+                            const u32 h0 = get_hi(st[0], act), l0 = get_nibble(st[1], m.table(1u + h0), act);
+                            const u32 h1 = get_hi(st[2], act), l1 = get_nibble(st[3], m.table(1u + h1), act);
                             renorm(st[0], act); renorm(st[1], act); renorm(st[2], act); renorm(st[3], act);
                             si.end_step(pre);
                             w |= ((h0 << 4 | l0) | (h1 << 4 | l1) << 8) << (16 * j);
@@ -274,7 +286,7 @@ __global__ __launch_bounds__(64) void trc_ansa_dec_kernel(
                             const bool act = coded && pos < len;
                             const bool first = !(i & 1) && pos < body;
                             u32 cur = first ? st[0] : st[1];
-                            const u32 x = get_nibble(cur, m.table(0), act);
+                            const u32 x = get_hi(cur, act);
                             renorm(cur, act);
                             st[0] = first ? cur : st[0]; st[1] = first ? st[1] : cur;
                             w |= x << (8 * i);

@@ -56,6 +56,7 @@ __global__ __launch_bounds__(64) void trc_vla_model_kernel(
     LaneBitsDown bo; bo.start(recs + (u64)(c + 1u) * stride2);
     u32 prev = 0;
 
+    NibTable T0 = m.load(m.table(0)), T1 = T0;                 // both tables in registers (record_r, trc_nibmodel.h); all tables start alike
     auto elem_records = [&](u32 v, bool act, u32 &r0, u32 &r1) {
         u32 x = v;
         if (ZZ) { x = vlc_zigzag_enc(v - prev, ES == 4); prev = act ? v : prev; }
@@ -66,9 +67,9 @@ __global__ __launch_bounds__(64) void trc_vla_model_kernel(
         const u32 xs = big ? expo : x;
         const bool two = xs >= T;
         const u32 y0 = two ? ((xs - T) >> 4) + T : xs, y1 = (xs - T) & 15u;
-        r0 = m.record(m.table(0), y0 & 15u);
+        r0 = m.record_r(T0, m.table(0), y0 & 15u);
         r1 = 0;
-        if (act && two) r1 = m.record(m.table(1), y1);          // table 1 adapts only where its symbol is coded
+        if (act && two) r1 = m.record_r(T1, m.table(1), y1);    // table 1 adapts only where its symbol is coded
     };
 
     const u32 S = chunk / TRC_SEG;
@@ -223,9 +224,11 @@ __global__ __launch_bounds__(64) void trc_vla_dec_kernel(
     const u8 *bend = payload + off + cl;
     u32 bpos = 0, prev = 0;
 
-    auto get = [&](u32 &s, u8 *tb, bool act) -> u32 {          // mndec4: cdf16ansdec, then ecdnorm
+    // both tables live in registers for the whole chunk (a decoder's table loads and stores are dependent LDS round trips that
+    // one wave per SIMD cannot hide; LDS keeps only the K rows of the update)
+    NibTable T0 = m.load(m.table(0)), T1 = T0;                 // all tables start alike
+    auto get = [&](u32 &s, NibTable &Tb, bool act) -> u32 {    // mndec4: cdf16ansdec, then ecdnorm
         const u32 slot = s & (TRC_PROB_ONE - 1);
-        NibTable Tb = m.load(tb);
         u32 c0, c1;
         const u32 x = trc_nib_find(Tb, slot, c0, c1);
         u32 ns = __umul24(c1 - c0, s >> TRC_PROB_BITS) + slot - c0;
@@ -234,12 +237,12 @@ __global__ __launch_bounds__(64) void trc_vla_dec_kernel(
         ns = rn ? (ns << 16) | w : ns;
         si.skip_if(rn);
         s = act ? ns : s;
-        m.adapt(Tb, x); m.store(tb, Tb);
+        m.adapt(Tb, x);
         return x;
     };
     auto get_elem = [&](bool act) -> u32 {
-        u32 x = get(sa, m.table(0), act);
-        if (act && x >= T) { const u32 z = get(sb, m.table(1), true); x = ((x - T) << 4 | z) + T; }
+        u32 x = get(sa, T0, act);
+        if (act && x >= T) { const u32 z = get(sb, T1, true); x = ((x - T) << 4 | z) + T; }
         if (act && x >= FIRST) {
             u32 f = (x >> VN) - 1u;
             f = f > 30u ? 30u : f;                             // (corrupt input)

@@ -162,6 +162,20 @@ struct NibModel {
 #pragma unroll
         for (int i = 0; i < NN; i++) r[i] = (c0[i] << TRC_PROB_BITS) | (c1[i] - c0[i]);
     }
+    // record() for a table the encoder keeps in registers (T == the table at tb): the LDS copy is only written, for the
+    // bounds reads of later symbols -- the table's own load, the dependent half of the round trip, is gone
+    __device__ __forceinline__ u32 record_r(NibTable &T, u8 *tb, u32 x) const
+    {
+        u32 c0, c1; bounds(tb, x, c0, c1);
+        adapt(T, x); store(tb, T);
+        return (c0 << TRC_PROB_BITS) | (c1 - c0);
+    }
+    __device__ __forceinline__ u32 record_r_if(bool on, NibTable &T, u8 *tb, u32 x) const
+    {
+        u32 r = 0;
+        if (on) r = record_r(T, tb, x);
+        return r;
+    }
     // the same where `on`; elsewhere the table stays as it is and the record is 0 (freq 0: never coded)
     __device__ __forceinline__ u32 record_if(bool on, u8 *tb, u32 x) const
     {

@@ -51,6 +51,7 @@ __global__ __launch_bounds__(64) void trc_vlc_enc_kernel(
     bool ovf = false;
 
     // one element: mantissa bits, then one or two range-coder symbols
+    NibTable T0 = m.load(m.table(0)), T1 = T0;                 // both tables in registers (record_r, trc_nibmodel.h); all tables start alike
     auto put_elem = [&](u32 v, bool act) {
         u32 x = v;
         if (ZZ) { x = vlc_zigzag_enc(v - prev, ES == 4); prev = act ? v : prev; }
@@ -61,9 +62,9 @@ __global__ __launch_bounds__(64) void trc_vlc_enc_kernel(
         const u32 xs = big ? expo : x;
         const bool two = xs >= T;
         const u32 y0 = two ? ((xs - T) >> 4) + T : xs, y1 = (xs - T) & 15u;
-        const u32 r0 = m.record(m.table(0), y0 & 15u);
+        const u32 r0 = m.record_r(T0, m.table(0), y0 & 15u);
         u32 r1 = 1u;
-        if (act && two) r1 = m.record(m.table(1), y1);          // table 1 adapts only where its symbol is coded
+        if (act && two) r1 = m.record_r(T1, m.table(1), y1);    // table 1 adapts only where its symbol is coded
         e.sym_rec(act, r0 >> TRC_PROB_BITS, r0 & 0x7fffu);
         e.sym_rec(act && two, r1 >> TRC_PROB_BITS, r1 & 0x7fffu);
         e.flush(so);                                            // at most one word per two steps (trc_rc.h RcEncD)
@@ -139,17 +140,19 @@ __global__ __launch_bounds__(64) void trc_vlc_dec_kernel(
     const u8 *bend = payload + off + cl;                       // the bit string is read downward from here
     u32 bpos = 0, prev = 0;
 
-    auto get = [&](u8 *tb, bool act) -> u32 {
-        NibTable Tb = m.load(tb);
+    // both tables live in registers for the whole chunk (a decoder's table loads and stores are dependent LDS round trips that
+    // one wave per SIMD cannot hide; LDS keeps only the K rows of the update)
+    NibTable T0 = m.load(m.table(0)), T1 = T0;                 // all tables start alike
+    auto get = [&](NibTable &Tb, bool act) -> u32 {
         u32 c0, c1;
         const u32 x = trc_nib_search(Tb, dc.scaled(), c0, c1);
         dc.consume_if(si, act, c0, c1);
-        m.adapt(Tb, x); m.store(tb, Tb);
+        m.adapt(Tb, x);
         return x;
     };
     auto get_elem = [&](bool act) -> u32 {
-        u32 x = get(m.table(0), act);
-        if (act && x >= T) { const u32 z = get(m.table(1), true); x = ((x - T) << 4 | z) + T; }
+        u32 x = get(T0, act);
+        if (act && x >= T) { const u32 z = get(T1, true); x = ((x - T) << 4 | z) + T; }
         if (act && x >= FIRST) {
             u32 f = (x >> VN) - 1u;
             f = f > 30u ? 30u : f;                             // (corrupt input)

@@ -47,6 +47,7 @@ __global__ __launch_bounds__(64) void trc_rcv_enc_kernel(
     RcEncD e0, e1; e0.start(); e1.start();
     bool ovf = alive && NS == 1 && lim <= 0;
 
+    NibTable T0 = m.load(m.table(0)), T1 = T0, T2 = T0;        // the three tables in registers (record_r, trc_nibmodel.h); all tables start alike
     const u32 S = chunk / TRC_SEG;
     qin.issue(wc, 0);
     for (u32 s = 0; s < S; s++) {
@@ -70,9 +71,9 @@ __global__ __launch_bounds__(64) void trc_rcv_enc_kernel(
                     const bool two = x >= 13u, three = x >= 45u;
                     const u32 y = three ? x - 45u : x - 13u;            // (unused when x < 13)
                     const u32 a = three ? 15u : two ? 13u + (y >> 4) : x;
-                    ra[i] = m.record(m.table(0), a);
-                    rb[i] = m.record_if(two, m.table(1), three ? y >> 4 : y & 15u);
-                    rc[i] = m.record_if(three, m.table(2), y & 15u);
+                    ra[i] = m.record_r(T0, m.table(0), a);
+                    rb[i] = m.record_r_if(two, T1, m.table(1), three ? y >> 4 : y & 15u);
+                    rc[i] = m.record_r_if(three, T2, m.table(2), y & 15u);
                 }
                 // ---- range coder(s): predicated steps, in the reference's order m0, m1, m2
 #pragma unroll
