@@ -491,7 +491,7 @@ struct HostCtx {
     uint8_t *d_cont = nullptr; size_t cap_cont = 0;    // container: hdr | clen[] | payload
     uint8_t *d_work = nullptr; size_t cap_work = 0;
     uint8_t *d_small = nullptr;                        // cdf (1 KiB) | totals (8 B x 4096 slices at 2048) | status
-    uint8_t *pin_in[TRC_NSLOT] = {}, *pin_out[TRC_NSLOT] = {}; size_t cap_pin = 0;
+    uint8_t *pin_in[TRC_NSLOT] = {}, *pin_out[TRC_NSLOT] = {}; size_t cap_pin[TRC_NSLOT] = {};
     uint64_t *pin_tot = nullptr;                       // pinned: per-slice totals
     hipEvent_t ev_in[TRC_NSLOT] = {}, ev_k[TRC_NSLOT] = {}, ev_out[TRC_NSLOT] = {};
     CopyPool *pool_in = nullptr, *pool_out = nullptr;  // this context's copy threads (staging in / unstaging out)
@@ -554,23 +554,23 @@ int grow(uint8_t **p, size_t *cap, size_t need)
     *cap = want;
     return TRC_OK;
 }
-int grow_pins(HostCtx &c, size_t need)
+// staging slots of `need` bytes each for a call of `nslices` slices (slice i uses slot i % TRC_NSLOT: a one-slice call --
+// the order-1 coder's whole input, up to 256 MB -- pins one pair of buffers, not three)
+int grow_pins(HostCtx &c, size_t need, size_t nslices)
 {
     need = up256(need + TRC_PAD);
-    if (c.cap_pin >= need) return TRC_OK;
-    const size_t twice = 2 * c.cap_pin < ((size_t)40 << 20) ? 2 * c.cap_pin : (size_t)40 << 20;    // calls of growing length re-pin a few times, not every time
-    if (need < twice) need = twice;
-    for (int i = 0; i < TRC_NSLOT; i++) {
+    const int want = nslices < TRC_NSLOT ? (int)nslices : TRC_NSLOT;
+    for (int i = 0; i < want; i++) {
+        if (c.cap_pin[i] >= need) continue;
+        const size_t twice = 2 * c.cap_pin[i] < ((size_t)40 << 20) ? 2 * c.cap_pin[i] : (size_t)40 << 20;    // calls of growing length re-pin a few times, not every time
+        const size_t sz = need < twice ? twice : need;
         if (c.pin_in[i]) HIPCHK(hipHostFree(c.pin_in[i]));
         if (c.pin_out[i]) HIPCHK(hipHostFree(c.pin_out[i]));
-        c.pin_in[i] = c.pin_out[i] = nullptr;
+        c.pin_in[i] = c.pin_out[i] = nullptr; c.cap_pin[i] = 0;
+        HIPCHK(hipHostMalloc((void **)&c.pin_in[i], sz));
+        HIPCHK(hipHostMalloc((void **)&c.pin_out[i], sz));
+        c.cap_pin[i] = sz;
     }
-    c.cap_pin = 0;
-    for (int i = 0; i < TRC_NSLOT; i++) {
-        HIPCHK(hipHostMalloc((void **)&c.pin_in[i], need));
-        HIPCHK(hipHostMalloc((void **)&c.pin_out[i], need));
-    }
-    c.cap_pin = need;
     return TRC_OK;
 }
 // Is [p, p + len) page-locked host memory the GPU can address (hipHostMalloc, or registered with hipHostRegister /
@@ -673,7 +673,7 @@ static size_t host_encode(int codec, const unsigned char *in, size_t inlen, unsi
     // page-locked caller buffers are read / written by DMA directly (no staging copy on that side)
     const bool in_direct = host_is_pinned(in, inlen), out_direct = host_is_pinned(out, outcap ? outcap : inlen);
     if (grow(&c.d_in, &c.cap_in, inlen) || grow(&c.d_cont, &c.cap_cont, hdrsz + dir + inlen + 64) || grow(&c.d_work, &c.cap_work, wb) ||
-        ((!in_direct || !out_direct) && grow_pins(c, slice_bytes + 4 * per + 64))) return 0;
+        ((!in_direct || !out_direct) && grow_pins(c, slice_bytes + 4 * per + 64, nsl))) return 0;
     uint16_t *d_cdf = (uint16_t *)c.d_small;
     uint64_t *d_tot = (uint64_t *)(c.d_small + 2048);
     uint32_t *d_clen = (uint32_t *)(c.d_cont + hdrsz);
@@ -799,7 +799,7 @@ static size_t host_decode(int codec, const unsigned char *in, size_t outlen, uns
     // page-locked caller buffers are read / written by DMA directly (no staging copy on that side)
     const bool in_direct = host_is_pinned(in, hdrsz + dir + (size_t)h.payload), out_direct = host_is_pinned(out, outlen);
     if (grow(&c.d_in, &c.cap_in, outlen) || grow(&c.d_cont, &c.cap_cont, hdrsz + dir + outlen + 64 + 2 * nsl) || grow(&c.d_work, &c.cap_work, wb) ||
-        ((!in_direct || !out_direct) && grow_pins(c, slice_bytes + 4 * per + 64))) return 0;
+        ((!in_direct || !out_direct) && grow_pins(c, slice_bytes + 4 * per + 64, nsl))) return 0;
     uint16_t *d_cdf = (uint16_t *)c.d_small;
     uint32_t *d_clen = (uint32_t *)(c.d_cont + hdrsz);
     uint8_t *d_payload = c.d_cont + hdrsz + dir;
