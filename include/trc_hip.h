@@ -104,6 +104,10 @@ int      trc_set_chunk(uint32_t chunk);
 uint32_t trc_get_chunk(void);
 uint32_t trc_auto_chunk(size_t n);
 uint32_t trc_auto_chunk_codec(int codec, size_t n);
+/* the chunk for a DEVICE-RESIDENT call of n bytes (one launch over the whole input): the largest multiple of 64 <= 4096 that
+ * makes the input a whole number of residency rounds of the coder's lanes, barely (a launch lasts rounds x one wave's time:
+ * 100 MB of the model-per-lane coders at 1280 instead of 1536 is half the throughput).  What bench.py runs every coder at. */
+uint32_t trc_round_chunk(int codec, size_t n);
 
 /* ---- device-resident layer --------------------------------------------------------------------
  * All d_* pointers are device pointers on the current HIP device, 16-byte aligned, with TRC_PAD

@@ -36,16 +36,31 @@ def main():
     res, cache = [], {}
     path = os.path.join(HERE, "bench_configs.json")
     have = {e["name"]: e for e in json.load(open(path))} if os.path.exists(path) and "--all" not in sys.argv else {}
-    for cfg in T.BENCH_CONFIGS:
-        if cfg["name"] in have:                      # entries already committed are kept as they are (--all regenerates everything)
-            res.append(have[cfg["name"]]); continue
-        key = (cfg["kind"], cfg["n"], cfg["seed"])
+    whole = {}                                       # (codec, kind, n, seed) -> bytes the reference function returns for the WHOLE input
+    def load(key):
         if key not in cache:
             d = T.bench_input(*key)
             r, cdf, cdfnum = T.ref_cdfini(d, 256)
             assert r == d.size
             cache[key] = (d, cdf, cdfnum)
-        d, cdf, cdfnum = cache[key]
+        return cache[key]
+    def whole_buffer(cfg):
+        """round 4: what the chunking costs.  The reference semantics are ONE call over the whole input (rccdf.c:201-211,
+        anscdf.c:567-586 in 4 MiB blocks, anscdf.c:57-73, rc_.c:47-58); its size goes beside the per-chunk payload size."""
+        wk = (cfg["codec"], cfg["kind"], cfg["n"], cfg["seed"])
+        if wk not in whole:
+            d, cdf, cdfnum = load((cfg["kind"], cfg["n"], cfg["seed"]))
+            whole[wk] = int(T.ref_enc(cfg["codec"], d, cdf, cdfnum, "s" if cfg["codec"] == T.ANSA else "").size)
+        return whole[wk]
+    for cfg in T.BENCH_CONFIGS:
+        if cfg["name"] in have:                      # entries already committed are kept as they are (--all regenerates everything)
+            e = have[cfg["name"]]
+            if "whole_buffer_bytes" not in e:
+                e["whole_buffer_bytes"] = whole_buffer(cfg)
+                print(e["name"], "whole buffer", e["whole_buffer_bytes"])
+            res.append(e); continue
+        key = (cfg["kind"], cfg["n"], cfg["seed"])
+        d, cdf, cdfnum = load(key)
         n, chunk, codec = cfg["n"], cfg["chunk"], cfg["codec"]
         nch = (n + chunk - 1) // chunk
         nthr = min(64, os.cpu_count() or 1)
@@ -60,7 +75,8 @@ def main():
                    in_sha256=hashlib.sha256(d.tobytes()).hexdigest(), cdfnum=cdfnum,
                    cdf_sha256=hashlib.sha256(cdf[:cdfnum + 1].tobytes()).hexdigest(),
                    payload_bytes=int(payload.size), payload_sha256=hashlib.sha256(payload.tobytes()).hexdigest(),
-                   clen_sha256=hashlib.sha256(clen.astype("<u4").tobytes()).hexdigest(), raw_chunks=int((clen == np.minimum(chunk, n - np.arange(nch) * chunk)).sum()))
+                   clen_sha256=hashlib.sha256(clen.astype("<u4").tobytes()).hexdigest(), raw_chunks=int((clen == np.minimum(chunk, n - np.arange(nch) * chunk)).sum()),
+                   whole_buffer_bytes=whole_buffer(cfg))
         print(ent["name"], ent["payload_bytes"], ent["payload_sha256"][:16])
         res.append(ent)
     with open(path, "w") as f:

@@ -100,7 +100,7 @@ def _group_worker(rank, world, port, codec, n, chunk, nbatch, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,nbatch", [(2, 2), (3, 3), (3, 2), (3, 5), (2, 1)])
+@pytest.mark.parametrize("world,nbatch", [(2, 2), (3, 3), (3, 2), (3, 5), (2, 1), (8, 8), (8, 9)])
 def test_group_exchange_with_rotating_roots(world, nbatch):
     """`exchange_group`: batch j of a group is gathered onto rank j % world, all transfers in one grouped call; every
     assembled container must equal the single-process container of that batch (full groups, a partial group -- the
@@ -118,7 +118,7 @@ def test_group_exchange_with_rotating_roots(world, nbatch):
     assert res == [(j, True) for j in range(nbatch)]
 
 
-def _pipeline_worker(rank, world, port, group, steps, prealloc, q):
+def _pipeline_worker(rank, world, port, group, steps, prealloc, q, lag=1):
     """bench.py's N>1 schedule (shard.StepPipeline) with CPU tensors: the oracle stands in for the HIP coder"""
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -150,7 +150,7 @@ def _pipeline_worker(rank, world, port, group, steps, prealloc, q):
                 ref = shard.assemble_container(codec, n, chunk, cdfnum, [fc], [fp])
                 seen.append((first + j, bool(np.array_equal(cont, ref))))
 
-        pipe = shard.StepPipeline(dist, rank, world, group, banks, recv, nch, shard.HostRuntime(), rotate=rotate, on_gathered=on_gathered)
+        pipe = shard.StepPipeline(dist, rank, world, group, banks, recv, nch, shard.HostRuntime(), rotate=rotate, on_gathered=on_gathered, lag=lag)
         cur = {}
 
         def encode(result):
@@ -174,15 +174,18 @@ def _pipeline_worker(rank, world, port, group, steps, prealloc, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,group,steps,prealloc", [(2, 2, 5, True), (4, 4, 9, True), (4, 4, 4, False), (2, 1, 3, True), (3, 3, 7, False)])
-def test_step_pipeline_schedule(world, group, steps, prealloc):
+@pytest.mark.parametrize("world,group,steps,prealloc,lag", [(2, 2, 5, True, 1), (4, 4, 9, True, 1), (4, 4, 4, False, 4), (2, 1, 3, True, 1), (3, 3, 7, False, 2),
+                                                            (8, 8, 17, True, 1), (8, 8, 9, False, 4), (8, 8, 24, True, 8)])
+def test_step_pipeline_schedule(world, group, steps, prealloc, lag):
     """shard.StepPipeline -- the class bench.py --gpus N runs its steps through -- with CPU tensors over gloo: every step
     of two consecutive runs must arrive whole on its root (step j of a group on rank j; group 1: rank 0) and equal the
-    single-process container of that step's data, incl. the partial last group and bank reuse."""
+    single-process container of that step's data, incl. the partial last group and bank reuse.  World 8 (round 4) is the
+    shape of the first real 8-GPU run: full groups, a group of one (9 steps), three full groups, exchanges issued 1, 4 and
+    8 steps late."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, group, steps, prealloc, q)) for r in range(world)]
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, group, steps, prealloc, q, lag)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

@@ -21,6 +21,7 @@
 // The decoders read the stream through a 16-byte register window per lane (trc_lane_io.h).  ANSA4's decoder takes
 // the n%4 tail from the state the ENCODER used (the reference decoder's tail reads the other state and does not
 // round-trip: see oracle/trc_oracle.c orc_anscdf4dec).
+#include <stdlib.h>
 #include "trc_io.h"
 #include "trc_lane_io.h"
 #include "trc_nibmodel.h"
@@ -42,17 +43,26 @@ __device__ __forceinline__ WaveChunks ansa_record_space(const WaveChunks &wc)
     return wr;
 }
 
+// PLANAR record space (round 4, the two-wave model pass of ANSA): per block of 16 input bytes 64 B of hi records, then 64 B of lo
+// records -- each wave of the model pass writes whole 64-byte segments of its own plane
+__device__ __forceinline__ WaveChunks ansa_record_space_planar(const WaveChunks &wc)
+{
+    WaveChunks wr = wc;
+    wr.chunk = 8u * wc.chunk;
+    wr.lastlen = 128u * ((wc.lastlen + 15u) / 16u);
+    return wr;
+}
+
 // ------------------------------------------------------------------------------ encode, pass 1 ---
 template <bool NIB>
-__global__ __launch_bounds__(64) void trc_ansa_model_kernel(
+__global__ __launch_bounds__(64 * TRC_WPG) void trc_ansa_model_kernel(
     const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ recs)
 {
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    const u32 lane = threadIdx.x;
+    TRC_QUAD_PROLOGUE(ANSA_MODEL_LDS(NIB));
     NibModel<NIB ? 1 : 17> m; m.init(smem);
 
     WaveChunks wc;
-    wc.c0 = blockIdx.x * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
+    wc.c0 = grp_ * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
     wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
     wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
     const WaveChunks wr = ansa_record_space<NIB>(wc);
@@ -109,6 +119,69 @@ __global__ __launch_bounds__(64) void trc_ansa_model_kernel(
     }
 }
 
+// Pass 1 of ANSA as TWO WAVES per 64 chunks (round 4).  The hi record of a byte depends on the hi table alone, the lo record on
+// the lo tables alone (the lo table is SELECTED by the hi nibble, which is input, not model state): wave 0 walks the hi nibbles,
+// wave 1 the lo nibbles of the same bytes, on disjoint parts of the same LDS rows, with nothing to tell each other -- no barrier.
+// Two waves per SIMD on the LDS footprint of one: each wave's issue gaps (a lone wave issues every ~1.5 quad-cycles) are the
+// other's slots.  The record space is PLANAR (above) so that both write whole segments.
+__global__ __launch_bounds__(128 * TRC_WPG) void trc_ansa_model2_kernel(
+    const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ recs)
+{
+    // a workgroup = 4 hi waves (0-3) + 4 lo waves (4-7): pair k = waves k and k + 4 on SIMD k (trc_dev.h, TRC_WPG)
+    extern __shared__ __attribute__((aligned(16))) u8 smem_wg_[];
+    const u32 wv_ = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool lo_wave = wv_ >= TRC_WPG;
+    const u32 grp_ = blockIdx.x * TRC_WPG + (wv_ & (TRC_WPG - 1u));
+    if (grp_ >= (nchunks + 63u) / 64u) return;
+    u8 *const smem = smem_wg_ + (wv_ & (TRC_WPG - 1u)) * ANSA_MODEL_LDS(false);
+    const u32 lane = trc_lane();
+    NibModel<17> m;
+    if (lo_wave) m.init_part(smem, 1u, 16u); else m.init_part(smem, 0u, 1u);       // each wave its own tables (and the same K)
+
+    WaveChunks wc;
+    wc.c0 = grp_ * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
+    wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
+    wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
+    const WaveChunks wr = ansa_record_space_planar(wc);
+    const bool alive = lane < wc.rows;
+    const u32 len = alive ? wc.len_of(lane) : 0u;
+
+    QuadIn qin; qin.base = in + (u64)wc.c0 * chunk;
+    QuadOut qout; qout.base = recs + (u64)wc.c0 * wr.chunk;
+    NibTable T0 = m.load(m.table(0));                          // (hi wave)
+
+    const u32 S = chunk / TRC_SEG;
+    qin.issue(wc, 0);
+    for (u32 s = 0; s < S; s++) {
+        qin.commit();
+        if (s + 1 < S) qin.issue(wc, (s + 1) * TRC_SEG);
+        uint4 pc0 = qin.read(0), pc1 = qin.read(1), pc2 = qin.read(2), pc3 = qin.read(3);
+#pragma nounroll
+        for (u32 k = 0; k < 4; k++) {
+            const uint4 v = pc0; pc0 = pc1; pc1 = pc2; pc2 = pc3;
+            const u32 p0 = s * TRC_SEG + k * 16u;
+            if (!__ballot(alive && p0 < len)) continue;
+            const u32 w[4] = { v.x, v.y, v.z, v.w };
+            u32 r[16];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {                      // 16 input bytes -> 16 records of this wave's plane
+                u32 x[4], rr[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    x[i] = (w[q] >> (8 * i)) & 255u;
+                    if (p0 + 4u * (u32)q + (u32)i >= len) x[i] = 0;       // the coded dummy of an odd tail (and unused padding)
+                }
+                if (lo_wave) m.template record_lo<4>(x, rr); else m.template record_hi<4>(T0, x, rr);
+#pragma unroll
+                for (int i = 0; i < 4; i++) r[4 * q + i] = rr[i];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) qout.put((u32)j, make_uint4(r[4 * j], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]));
+            qout.flush(wr, p0 * 8u + (lo_wave ? 64u : 0u));
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------ encode, pass 2 ---
 // one step where `act`, nothing where not (no branch: with 64 lanes some lane is always at a different point of its chunk)
 __device__ __forceinline__ void ansa_put(u32 &st, u32 rec, StreamOut<true> &so, bool act = true)
@@ -127,14 +200,13 @@ __device__ __forceinline__ void ansa_put(u32 &st, u32 rec, StreamOut<true> &so, 
 }
 
 template <bool NIB>
-__global__ __launch_bounds__(64) void trc_ansa_code_kernel(
+__global__ __launch_bounds__(64 * TRC_WPG) void trc_ansa_code_kernel(
     const u8 *__restrict__ recs, u64 n, u32 chunk, u32 nchunks,
     u8 *__restrict__ scratch, u32 stride, u32 *__restrict__ clen, u32 *__restrict__ gsum)
 {
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    const u32 lane = threadIdx.x;
+    TRC_QUAD_PROLOGUE(ANSA_CODE_LDS);
     WaveChunks wc;
-    wc.c0 = blockIdx.x * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
+    wc.c0 = grp_ * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
     wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
     wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
     const WaveChunks wr = ansa_record_space<NIB>(wc);
@@ -196,18 +268,84 @@ __global__ __launch_bounds__(64) void trc_ansa_code_kernel(
     if (lane == 0) gsum[wc.c0 >> 6] = gs;
 }
 
+// Pass 2 over the PLANAR record space (ANSA behind trc_ansa_model2_kernel): a block of 16 input bytes is two segments, hi records
+// and lo records; record 2j of the block is hi[j], record 2j + 1 is lo[j].  Everything else as above.
+#define ANSA_CODE_PLANAR_LDS (2u * TRC_TILE_BYTES + TRC_SRING_BYTES)
+__global__ __launch_bounds__(64 * TRC_WPG) void trc_ansa_code_planar_kernel(
+    const u8 *__restrict__ recs, u64 n, u32 chunk, u32 nchunks,
+    u8 *__restrict__ scratch, u32 stride, u32 *__restrict__ clen, u32 *__restrict__ gsum)
+{
+    TRC_QUAD_PROLOGUE(ANSA_CODE_PLANAR_LDS);
+    WaveChunks wc;
+    wc.c0 = grp_ * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
+    wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
+    wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
+    const WaveChunks wr = ansa_record_space_planar(wc);
+    const bool alive = lane < wc.rows;
+    const u32 c = wc.c0 + lane;
+    const u32 len = alive ? wc.len_of(lane) : 0u;
+    const u32 nrec = 2u * (len + (len & 1u));                  // 4 per byte pair
+    const u32 room = 2u + 4u * 4u;                             // mnflush: ep <= op + sizeof(io_t) + states * 4  ->  raw
+
+    TileIn th, tl;
+    th.tile = smem; th.base = recs + (u64)wc.c0 * wr.chunk;
+    tl.tile = smem + TRC_TILE_BYTES; tl.base = th.base;
+    StreamOut<true> so;
+    so.rings = smem + 2u * TRC_TILE_BYTES;
+    so.scratch = scratch; so.stride = stride; so.c0 = wc.c0; so.wpos = 0; so.nfl = 0;
+    u32 st[4] = { TRC_ANS_LOW, TRC_ANS_LOW, TRC_ANS_LOW, TRC_ANS_LOW };
+    bool ovf = false;
+
+    const u32 T = wr.chunk / 128u;                             // blocks (32 records each) in a full chunk
+    const u32 top = alive && nrec ? (nrec - 1u) / 32u : 0u;
+    th.issue(wr, (T - 1u) * 128u); tl.issue(wr, (T - 1u) * 128u + 64u);
+    for (u32 t = T - 1u;; t--) {
+        th.commit(); tl.commit();
+        if (t) { th.issue(wr, (t - 1u) * 128u); tl.issue(wr, (t - 1u) * 128u + 64u); }
+        const bool act = alive && nrec != 0u && t <= top && !ovf;
+#pragma unroll
+        for (int half = 1; half >= 0; half--) {                // records 31..16, then 15..0 of the block
+            if (act) {
+                const uint4 qh[2] = { th.read(2u * (u32)half), th.read(2u * (u32)half + 1u) };
+                const uint4 ql[2] = { tl.read(2u * (u32)half), tl.read(2u * (u32)half + 1u) };
+                const u32 *hh = (const u32 *)qh, *ll = (const u32 *)ql;
+#pragma unroll
+                for (int i = 15; i >= 0; i--) {
+                    const bool can = 32u * t + 16u * (u32)half + (u32)i < nrec && !ovf;
+                    ovf = ovf || (can && so.wpos + room >= len);
+                    const bool go = can && !ovf;
+                    ansa_put(st[3 - (i & 3)], (i & 1) ? ll[i >> 1] : hh[i >> 1], so, go);
+                }
+            }
+            so.drain(false, alive);                            // <= 32 new bytes (16 records) per lane
+        }
+        if (t == 0) break;
+    }
+    u32 out_len = 0;
+    if (alive) {
+        if (!ovf) {
+            for (int k = 0; k < 4; k++) { so.put16(st[k] >> 16); so.put16(st[k]); }
+            if (so.wpos >= len) ovf = true;
+        }
+        out_len = ovf ? len : so.wpos;
+    }
+    so.drain(true, alive && !ovf);
+    if (alive) clen[c] = out_len;
+    const u32 gs = trc_wave_sum(out_len);
+    if (lane == 0) gsum[wc.c0 >> 6] = gs;
+}
+
 // ------------------------------------------------------------------------------------- decode ---
 template <bool NIB>
-__global__ __launch_bounds__(64) void trc_ansa_dec_kernel(
+__global__ __launch_bounds__(64 * TRC_WPG) void trc_ansa_dec_kernel(
     const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
     u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ out)
 {
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    const u32 lane = threadIdx.x;
+    TRC_QUAD_PROLOGUE(ANSA_MODEL_LDS(NIB));
     NibModel<NIB ? 1 : 17> m; m.init(smem);
 
     WaveChunks wc;
-    wc.c0 = blockIdx.x * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
+    wc.c0 = grp_ * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
     wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
     wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
     const bool alive = lane < wc.rows;
@@ -309,28 +447,44 @@ __global__ __launch_bounds__(64) void trc_ansa_dec_kernel(
 }
 
 // ------------------------------------------------------------------------------------- launch ---
+// TRC_ANSA_MC=0 selects the one-wave model pass of rounds 1-3 (A/B measurements, tests of both forms)
+static bool ansa_mc_enabled()
+{
+    static const int env = getenv("TRC_ANSA_MC") ? atoi(getenv("TRC_ANSA_MC")) : 1;
+    return env != 0;
+}
 template <bool NIB>
 static void launch_ansa_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
 {
-    TRC_LAUNCH_TIMED((trc_ansa_model_kernel<NIB>), dim3(w.ngroups), dim3(64), ANSA_MODEL_LDS(NIB), s, d_in, (u64)n, chunk, w.nchunks, w.scratch2);
-    TRC_LAUNCH_TIMED((trc_ansa_code_kernel<NIB>), dim3(w.ngroups), dim3(64), ANSA_CODE_LDS, s,
+    if (!NIB && ansa_mc_enabled()) {
+        TRC_RAISE_LDS_ONCE(trc_ansa_model2_kernel, TRC_WPG * ANSA_MODEL_LDS(false));
+        TRC_RAISE_LDS_ONCE(trc_ansa_code_planar_kernel, TRC_WPG * ANSA_CODE_PLANAR_LDS);
+        TRC_LAUNCH_TIMED(trc_ansa_model2_kernel, TRC_QUAD_GRID(w.ngroups), dim3(128 * TRC_WPG), TRC_WPG * ANSA_MODEL_LDS(false), s, d_in, (u64)n, chunk, w.nchunks, w.scratch2);
+        TRC_LAUNCH_TIMED(trc_ansa_code_planar_kernel, TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (ANSA_CODE_PLANAR_LDS), s,
+                           (const u8 *)w.scratch2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
+        return;
+    }
+    TRC_RAISE_LDS_ONCE((trc_ansa_model_kernel<NIB>), TRC_WPG * ANSA_MODEL_LDS(NIB));
+    TRC_LAUNCH_TIMED((trc_ansa_model_kernel<NIB>), TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (ANSA_MODEL_LDS(NIB)), s, d_in, (u64)n, chunk, w.nchunks, w.scratch2);
+    TRC_LAUNCH_TIMED((trc_ansa_code_kernel<NIB>), TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (ANSA_CODE_LDS), s,
                        (const u8 *)w.scratch2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
 }
 template <bool NIB>
 static void launch_ansa_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                             const TrcWork &w, uint8_t *d_out, hipStream_t s)
 {
-    TRC_LAUNCH_TIMED((trc_ansa_dec_kernel<NIB>), dim3(w.ngroups), dim3(64), ANSA_MODEL_LDS(NIB), s,
+    TRC_RAISE_LDS_ONCE((trc_ansa_dec_kernel<NIB>), TRC_WPG * ANSA_MODEL_LDS(NIB));
+    TRC_LAUNCH_TIMED((trc_ansa_dec_kernel<NIB>), TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (ANSA_MODEL_LDS(NIB)), s,
                        d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, d_out);
 }
 // pass 2 alone (the order-1 coder of trc_ans_o1.hip produces the same record stack with its own pass 1)
 void trc_launch_ansa_code(int nibble, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
 {
     if (nibble)
-        TRC_LAUNCH_TIMED((trc_ansa_code_kernel<true>), dim3(w.ngroups), dim3(64), ANSA_CODE_LDS, s,
+        TRC_LAUNCH_TIMED((trc_ansa_code_kernel<true>), TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (ANSA_CODE_LDS), s,
                            (const u8 *)w.scratch2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
     else
-        TRC_LAUNCH_TIMED((trc_ansa_code_kernel<false>), dim3(w.ngroups), dim3(64), ANSA_CODE_LDS, s,
+        TRC_LAUNCH_TIMED((trc_ansa_code_kernel<false>), TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (ANSA_CODE_LDS), s,
                            (const u8 *)w.scratch2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
 }
 void trc_launch_ansa_enc(int nibble, const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)

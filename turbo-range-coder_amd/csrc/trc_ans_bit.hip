@@ -29,16 +29,15 @@ __device__ __forceinline__ u32 ansb_adapt(u32 p, u32 bit)
 }
 
 // ------------------------------------------------------------------------------ encode, pass 1 ---
-__global__ __launch_bounds__(64) void trc_ansb_model_kernel(
+__global__ __launch_bounds__(64 * TRC_WPG) void trc_ansb_model_kernel(
     const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ recs)
 {
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    const u32 lane = threadIdx.x;
+    TRC_QUAD_PROLOGUE(ANSB_MODEL_BYTES);
     u16 *mb = (u16 *)smem + lane;                              // mb[ctx * 64]
     for (u32 i = 0; i < 256; i++) mb[i * 64] = (u16)(TRC_PROB_ONE >> 1);
 
     WaveChunks wc;
-    wc.c0 = blockIdx.x * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
+    wc.c0 = grp_ * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
     wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
     wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
     WaveChunks wr = wc;                                        // the same chunks in record space (16 B per byte)
@@ -101,14 +100,13 @@ __device__ __forceinline__ void ansb_put(u32 &st, u32 rec, StreamOut<true> &so)
     st = st + __umul24(q, TRC_PROB_ONE - ls) + (bit ? 0u : p0);
 }
 
-__global__ __launch_bounds__(64) void trc_ansb_code_kernel(
+__global__ __launch_bounds__(64 * TRC_WPG) void trc_ansb_code_kernel(
     const u8 *__restrict__ recs, u64 n, u32 chunk, u32 nchunks,
     u8 *__restrict__ scratch, u32 stride, u32 *__restrict__ clen, u32 *__restrict__ gsum)
 {
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    const u32 lane = threadIdx.x;
+    TRC_QUAD_PROLOGUE(ANSB_CODE_LDS);
     WaveChunks wc;
-    wc.c0 = blockIdx.x * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
+    wc.c0 = grp_ * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
     wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
     wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
     WaveChunks wr = wc; wr.chunk = 16u * chunk; wr.lastlen = 16u * wc.lastlen;
@@ -162,17 +160,16 @@ __global__ __launch_bounds__(64) void trc_ansb_code_kernel(
 }
 
 // ------------------------------------------------------------------------------------- decode ---
-__global__ __launch_bounds__(64) void trc_ansb_dec_kernel(
+__global__ __launch_bounds__(64 * TRC_WPG) void trc_ansb_dec_kernel(
     const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
     u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ out)
 {
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    const u32 lane = threadIdx.x;
+    TRC_QUAD_PROLOGUE(ANSB_MODEL_BYTES);
     u16 *mb = (u16 *)smem + lane;
     for (u32 i = 0; i < 256; i++) mb[i * 64] = (u16)(TRC_PROB_ONE >> 1);
 
     WaveChunks wc;
-    wc.c0 = blockIdx.x * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
+    wc.c0 = grp_ * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
     wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
     wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
     const bool alive = lane < wc.rows;
@@ -250,13 +247,15 @@ __global__ __launch_bounds__(64) void trc_ansb_dec_kernel(
 // ------------------------------------------------------------------------------------- launch ---
 void trc_launch_ansb_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
 {
-    TRC_LAUNCH_TIMED(trc_ansb_model_kernel, dim3(w.ngroups), dim3(64), ANSB_MODEL_BYTES, s, d_in, (u64)n, chunk, w.nchunks, w.scratch2);
-    TRC_LAUNCH_TIMED(trc_ansb_code_kernel, dim3(w.ngroups), dim3(64), ANSB_CODE_LDS, s,
+    TRC_RAISE_LDS_ONCE(trc_ansb_model_kernel, TRC_WPG * ANSB_MODEL_BYTES);
+    TRC_LAUNCH_TIMED(trc_ansb_model_kernel, TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (ANSB_MODEL_BYTES), s, d_in, (u64)n, chunk, w.nchunks, w.scratch2);
+    TRC_LAUNCH_TIMED(trc_ansb_code_kernel, TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (ANSB_CODE_LDS), s,
                        (const u8 *)w.scratch2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
 }
 void trc_launch_ansb_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                          const TrcWork &w, uint8_t *d_out, hipStream_t s)
 {
-    TRC_LAUNCH_TIMED(trc_ansb_dec_kernel, dim3(w.ngroups), dim3(64), ANSB_MODEL_BYTES, s,
+    TRC_RAISE_LDS_ONCE(trc_ansb_dec_kernel, TRC_WPG * ANSB_MODEL_BYTES);
+    TRC_LAUNCH_TIMED(trc_ansb_dec_kernel, TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (ANSB_MODEL_BYTES), s,
                      d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, d_out);
 }

@@ -72,6 +72,31 @@ extern "C" uint32_t trc_auto_chunk_codec(int codec, size_t n)
         if (n / c / TRC_MODEL_ROUND_CHUNKS >= 16u) return codec == TRC_ANSB && c > TRC_ANSB_CHUNK_MAX ? TRC_ANSB_CHUNK_MAX : c;
     return TRC_CHUNK_AUTO_MIN;
 }
+// The chunk for a DEVICE-RESIDENT call of n bytes (one launch over the whole input: trc_encode_dev, bench.py).  A launch lasts
+// (residency rounds) x (one wave's time, proportional to its chunk), so the input should be a whole number of rounds of the
+// coder's resident lanes, barely: the LARGEST chunk (multiple of 64, at most 4096: the ratio has nothing left to gain above)
+// with ceil(n / chunk) <= k rounds for the smallest k that allows it.  Lanes per round: static coders 12 waves per CU
+// (196 608 chunks; the two-lanes-per-chunk `-e45` coder 98 304), a model per lane in LDS 4 waves per CU (65 536), the
+// small-model coders (nibble, vnibble, Turbo-VLC) ~20 (327 680).  100 MB: 512 / 1024 / 1536 / 512 as measured best in round 3
+// (profiles/r03_notes.md section 7: 1280 instead of 1536 is a factor 1.9); 70 / 120 / 150 / 333 MB: tests/test_gpu_chunk_policy.py.
+static inline bool is_static(int codec);
+static size_t round_chunks(int codec)
+{
+    if (codec == TRC_RCS2) return 98304u;
+    if (is_static(codec)) return 196608u;
+    if (codec == TRC_RCA || codec == TRC_RCAI || codec == TRC_ANSA || codec == TRC_RCB || codec == TRC_ANSB) return TRC_MODEL_ROUND_CHUNKS;
+    return 327680u;
+}
+extern "C" uint32_t trc_round_chunk(int codec, size_t n)
+{
+    if (codec == TRC_ANSO1) return 4096u;                     // (see trc_auto_chunk_codec)
+    const size_t rc = round_chunks(codec);
+    for (size_t k = 1;; k++) {
+        size_t c = (n + rc * k - 1) / (rc * k);               // ceil(n / c) <= rc * k
+        c = (c + 63u) & ~(size_t)63u;
+        if (c <= 4096u) return c < TRC_CHUNK_AUTO_MIN ? TRC_CHUNK_AUTO_MIN : (uint32_t)c;
+    }
+}
 extern "C" uint32_t trc_get_chunk(void)
 {
     if (!g_chunk) {

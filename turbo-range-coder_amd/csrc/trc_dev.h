@@ -70,6 +70,18 @@ __device__ __forceinline__ u32 trc_lds_addr(const void *p) { return (u32)(uintpt
 __device__ __forceinline__ u32 trc_ldsr16(u32 a) { return *(const trc_lds_u16 *)(uintptr_t)a; }
 __device__ __forceinline__ void trc_ldsw16(u32 a, u32 v) { *(trc_lds_u16 *)(uintptr_t)a = (u16)v; }
 
+typedef __attribute__((address_space(3))) trc_v4u trc_lds_v4u;
+__device__ __forceinline__ uint4 trc_ldsr128(u32 a) { const trc_v4u v = *(const trc_lds_v4u *)(uintptr_t)a; return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void trc_ldsw128(u32 a, uint4 q) { const trc_v4u v = { q.x, q.y, q.z, q.w }; *(trc_lds_v4u *)(uintptr_t)a = v; }
+
+// LDS-only workgroup barrier (the two-wave encoders: a model wave feeding a coder wave through an LDS queue).
+// __syncthreads() also waits for vmcnt(0), i.e. for the coder wave's word stores and the model wave's input loads in
+// flight -- a memory round trip per period that nothing there needs.
+__device__ __forceinline__ void trc_lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // (a & m) | (b & ~m) as the one instruction it is.  From the C form the compiler builds and / and-or pairs, compares and selects
 // or -- for a group of selects on one condition -- a divergent if / else; in the one-wave-per-SIMD kernels every one of those is slower.
 __device__ __forceinline__ u32 trc_bfi(u32 m, u32 a, u32 b)
@@ -83,6 +95,35 @@ __device__ __forceinline__ u32 trc_sub_sat(u32 a, u32 b) { return a > b ? a - b 
 
 // ---- wave64 helpers -----------------------------------------------------------------------------
 __device__ __forceinline__ u32 trc_lane() { return threadIdx.x & 63u; }
+
+// ---- workgroup shape of the one-wave-per-64-chunks kernels (round 4) -------------------------------------------------
+// These kernels hold ONE wave per SIMD (the model fills the LDS) and a launch of ~1000 waves is one residency round, so a
+// launch lasts as long as its SLOWEST wave -- and a wave that shares its SIMD with another runs ~1.4x longer.  Which SIMD a
+// wave lands on is the dispatcher's business: with one-wave workgroups it deals them round-robin from wherever the launch
+// before left off, and scripts/probe/residency.hip found a fresh launch of 1018 such workgroups with 105 SIMDs holding two
+// waves and 111 holding none (all 1018 on their own SIMD only right behind a launch of the same shape).  A workgroup's
+// OWN waves, however, are dealt over consecutive SIMDs: a workgroup of FOUR waves puts one on every SIMD of its CU, one of
+// eight puts two, whatever came before (measured: 1012 of 1024 SIMDs at exactly two waves, 12 at one).  So these kernels
+// run as workgroups of TRC_WPG = 4 independent waves (no barrier between them; each has its own slice of the dynamic LDS),
+// one workgroup per CU; the two-wave encoders as workgroups of 8 (waves 0-3 model, 4-7 coder: SIMD k gets pair k).
+#define TRC_WPG 4u
+#define TRC_QUAD_GRID(ngroups) dim3(((ngroups) + TRC_WPG - 1u) / TRC_WPG)
+// kernel prologue: this wave's 64-chunk group `grp_`, its LDS slice `smem`, `lane`; waves without a group leave at once
+#define TRC_QUAD_PROLOGUE(WAVE_LDS_BYTES)                                                               \
+    extern __shared__ __attribute__((aligned(16))) u8 smem_wg_[];                                      \
+    const u32 wv_ = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));                      \
+    const u32 grp_ = blockIdx.x * TRC_WPG + wv_;                                                        \
+    if (grp_ >= (nchunks + 63u) / 64u) return;                                                          \
+    u8 *const smem = smem_wg_ + wv_ * (u32)(WAVE_LDS_BYTES);                                            \
+    const u32 lane = trc_lane()
+// orders a wave's own LDS stores before its later loads of what OTHER lanes stored (the hardware executes a wave's LDS
+// instructions in order; this keeps the compiler from moving them)
+__device__ __forceinline__ void trc_wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // inclusive prefix sum over the 64 lanes of a wave (all lanes must call)
 __device__ __forceinline__ u32 trc_wave_incl_scan(u32 v)

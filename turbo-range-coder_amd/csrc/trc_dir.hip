@@ -246,23 +246,35 @@ __global__ __launch_bounds__(256) void trc_hist_kernel(const u8 *__restrict__ in
     tot[tid] = 0;
     const u64 nvec = n >> 4, stride = (u64)gridDim.x * 256;
     const uint4 *v = (const uint4 *)in;
-    auto count = [&](u32 w) {                                       // four bytes -> four ds_add_u32 on this lane's column
+    // four bytes -> four ds_add_u32 on this lane's column: per byte v_bfe (row) + v_lshl_add (address), v_bfe (parity) + v_mad_u32_u24
+    // (increment 1 or 0x10000) -- with one wave per SIMD the kernel's time is its instruction count plus whatever memory latency is
+    // left exposed
+    auto count = [&](u32 w) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const u32 b = (w >> (8 * k)) & 255u;
-            __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)(col + (b >> 1) * 256u), (b & 1u) ? 0x10000u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            const u32 a = (__builtin_amdgcn_ubfe(w, 8 * k + 1, 7) << 8) + col;
+            const u32 inc = __umul24(__builtin_amdgcn_ubfe(w, 8 * k, 1), 0xffffu) + 1u;
+            __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)a, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
     };
+    auto count4 = [&](const uint4 q) { count(q.x); count(q.y); count(q.z); count(q.w); };
     for (u64 r0 = 0; r0 == 0 || r0 < nvec; r0 += stride * TRC_HIST_ROUND_VECS) {      // (r0 is uniform: every wave runs every round)
         for (u32 r = lane; r < 128u * 64u; r += 64u) mine[r] = 0;  // own wave's counters (row-major: lanes write consecutive dwords)
         u64 i = r0 + (u64)blockIdx.x * 256 + tid;
         u32 left = TRC_HIST_ROUND_VECS;
-        for (; left >= 4u && i + 3 * stride < nvec; left -= 4u, i += 4 * stride) {      // four loads in flight per lane
-            const uint4 q0 = v[i], q1 = v[i + stride], q2 = v[i + 2 * stride], q3 = v[i + 3 * stride];
-            count(q0.x); count(q0.y); count(q0.z); count(q0.w); count(q1.x); count(q1.y); count(q1.z); count(q1.w);
-            count(q2.x); count(q2.y); count(q2.z); count(q2.w); count(q3.x); count(q3.y); count(q3.z); count(q3.w);
+        // Round 4: the NEXT four vectors are requested before the current four are counted (round 3 requested four and counted them
+        // at once: a memory round trip in front of every 64 bytes, ~24 of them per lane at 100 MB).
+        if (left >= 4u && i + 3 * stride < nvec) {
+            uint4 q0 = v[i], q1 = v[i + stride], q2 = v[i + 2 * stride], q3 = v[i + 3 * stride];
+            left -= 4u; i += 4 * stride;
+            for (; left >= 4u && i + 3 * stride < nvec; left -= 4u, i += 4 * stride) {
+                const uint4 n0 = v[i], n1 = v[i + stride], n2 = v[i + 2 * stride], n3 = v[i + 3 * stride];
+                count4(q0); count4(q1); count4(q2); count4(q3);
+                q0 = n0; q1 = n1; q2 = n2; q3 = n3;
+            }
+            count4(q0); count4(q1); count4(q2); count4(q3);
         }
-        for (; left && i < nvec; left--, i += stride) { const uint4 q = v[i]; count(q.x); count(q.y); count(q.z); count(q.w); }
+        for (; left && i < nvec; left--, i += stride) count4(v[i]);
         if (r0 == 0 && blockIdx.x == 0 && wv == 0)                  // the input's last n % 16 bytes, once
             for (u64 t = (nvec << 4) + lane; t < n; t += 64) { const u32 b = in[t]; mine[(b >> 1) * 64u + lane] += (b & 1u) ? 0x10000u : 1u; }
         // reduce this wave's columns: lane l sums rows l and l + 64, walking the columns rotated by l (bank = column mod 32)
@@ -314,8 +326,7 @@ void trc_launch_hist(const uint8_t *d_in, size_t n, uint64_t *d_hist, hipStream_
     if (blocks < 1) blocks = 1;
     if (blocks > 256) blocks = 256;                             // one workgroup (4 x 32 KiB of counters) per CU
     const size_t sm = 4u * TRC_HIST_WAVE_LDS + 256u * sizeof(u64);
-    static bool raised = false;
-    if (!raised) { (void)hipFuncSetAttribute((const void *)trc_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); raised = true; }
+    TRC_RAISE_LDS_ONCE(trc_hist_kernel, sm);                    // per DEVICE (a process-wide flag left a second GPU at the 64 KiB default)
     hipLaunchKernelGGL(trc_hist_kernel, dim3((u32)blocks), dim3(256), sm, s, d_in, (u64)n, d_hist);
 }
 void trc_launch_cdf_build(const uint64_t *d_hist, size_t n_total, uint16_t *d_cdf, unsigned cdfnum, int32_t *d_status, hipStream_t s)

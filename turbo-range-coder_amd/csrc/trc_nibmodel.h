@@ -61,7 +61,25 @@ struct NibModel {
         for (u32 t = 0; t < (u32)NT; t++)
 #pragma unroll
             for (u32 k = 0; k < 8; k++) ((u32 *)(row + t * 32u))[k] = trc_pk((2 * k) << 11, (2 * k + 1) << 11);
-        __syncthreads();                          // one wave per workgroup: orders the K writes before other lanes' reads
+        trc_wave_lds_fence();                     // the K writes of this wave before its lanes' reads (the model belongs to ONE wave)
+    }
+    // the same for a wave that owns only tables [first, first + count) of the rows (the two-wave model pass: a hi wave and a lo
+    // wave share the rows; each initialises its own tables, both write the same K)
+    __device__ __forceinline__ void init_part(u8 *smem, u32 first, u32 count)
+    {
+        const u32 lane = trc_lane();
+        kb = smem;
+        row = smem + TRC_NIBK_BYTES + lane * ROW;
+#pragma unroll
+        for (u32 j = 0; j < 2; j++) {
+            const u32 idx = lane * 2u + j, x = idx >> 3, k = idx & 7u;
+            const u32 e0 = 2u * k, e1 = 2u * k + 1u;
+            ((u32 *)kb)[idx] = trc_pk(10u * e0 + (e0 > x ? 32736u : 0u), 10u * e1 + (e1 > x ? 32736u : 0u));
+        }
+        for (u32 t = first; t < first + count; t++)
+#pragma unroll
+            for (u32 k = 0; k < 8; k++) ((u32 *)(row + t * 32u))[k] = trc_pk((2 * k) << 11, (2 * k + 1) << 11);
+        trc_wave_lds_fence();
     }
     __device__ __forceinline__ u8 *table(u32 t) const { return row + t * 32u; }      // t = 0: hi, 1 + h: lo[h]
     __device__ __forceinline__ NibTable load(const u8 *tb) const
@@ -145,6 +163,52 @@ struct NibModel {
         }
 #pragma unroll
         for (int i = 0; i < 2 * NB; i++) r[i] = (c0[i] << TRC_PROB_BITS) | (c1[i] - c0[i]);
+    }
+    // record_bytes split in two for the two-wave model pass of the adaptive rANS (trc_ans_adaptive.hip, round 4): the hi records of
+    // NB bytes need the hi table only (registers; its LDS copy serves the bounds reads), the lo records the sixteen lo tables only
+    // -- disjoint LDS, no data between the two, so a "hi" wave and a "lo" wave walk the same bytes independently.
+    template <int NB>
+    __device__ __forceinline__ void record_hi(NibTable &T0, const u32 (&x)[NB], u32 (&r)[NB]) const
+    {
+        NibTable Kh[NB];
+#pragma unroll
+        for (int i = 0; i < NB; i++) Kh[i] = load(kb + (x[i] >> 4) * 32u);
+        u32 c0[NB], c1[NB];
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            bounds(table(0), x[i] >> 4, c0[i], c1[i]);
+            adapt_k(T0, Kh[i]); store(table(0), T0);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; i++) r[i] = (c0[i] << TRC_PROB_BITS) | (c1[i] - c0[i]);
+    }
+    template <int NB>
+    __device__ __forceinline__ void record_lo(const u32 (&x)[NB], u32 (&r)[NB]) const
+    {
+        NibTable Kl[NB], L[NB], U[NB];
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            Kl[i] = load(kb + (x[i] & 15u) * 32u);
+            L[i] = load(table(1u + (x[i] >> 4)));
+        }
+        u32 c0[NB], c1[NB];
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const u32 h = x[i] >> 4, l = x[i] & 15u;
+            NibTable T = L[i];
+#pragma unroll
+            for (int j = 0; j < i; j++) {
+                const bool same = (x[j] >> 4) == h;
+#pragma unroll
+                for (int k = 0; k < 8; k++) T.d[k] = same ? U[j].d[k] : T.d[k];
+            }
+            u8 *tb = table(1u + h);
+            bounds(tb, l, c0[i], c1[i]);
+            adapt_k(T, Kl[i]); store(tb, T);
+            U[i] = T;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; i++) r[i] = (c0[i] << TRC_PROB_BITS) | (c1[i] - c0[i]);
     }
     // NN symbols through ONE table held in registers (nibble coders; T0's LDS copy serves the bounds reads)
     template <int NN>

@@ -21,6 +21,7 @@
 // register windows (trc_lane_io.h) -- which lets four waves (one per SIMD) share a CU.  A period is 4 input bytes:
 // first the model walks them and leaves {cdf_lo, freq} records in registers (pure packed-16 VALU + LDS, no
 // dependence on the coder state), then the range coder consumes the records with predicated, branch-free steps.
+#include <stdlib.h>
 #include "trc_rc.h"
 #include "trc_lane_io.h"
 #include "trc_nibmodel.h"
@@ -29,17 +30,16 @@
 #define RCA_WAVE_LDS(NIB) ((NIB) ? TRC_NIB1_BYTES : TRC_NIB_BYTES)
 
 template <int NS, bool NIB>
-__global__ __launch_bounds__(64) void trc_rca_enc_kernel(
+__global__ __launch_bounds__(64 * TRC_WPG) void trc_rca_enc_kernel(
     const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks,
     u8 *__restrict__ scratch, u32 stride, u8 *__restrict__ scratch2, u32 stride2,
     u32 *__restrict__ clen, u32 *__restrict__ gsum)
 {
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    const u32 lane = threadIdx.x;
+    TRC_QUAD_PROLOGUE(RCA_WAVE_LDS(NIB));
     NibModel<NIB ? 1 : 17> m; m.init(smem);
 
     WaveChunks wc;
-    wc.c0 = blockIdx.x * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
+    wc.c0 = grp_ * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
     wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
     wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
     const bool alive = lane < wc.rows;
@@ -146,17 +146,144 @@ __global__ __launch_bounds__(64) void trc_rca_enc_kernel(
     if (lane == 0) gsum[wc.c0 >> 6] = gs;
 }
 
+// ---- the byte coders' encoder as TWO WAVES per 64 chunks (round 4) -------------------------------------------------
+// The encoder above already runs in two phases per period of 4 bytes: the model walks the bytes and leaves records, the
+// range coder consumes them.  Nothing of the first phase depends on the coder's state.  With the model filling the LDS
+// a CU holds four such waves, one per SIMD, and a lone wave issues an instruction every ~1.5 quad-cycles
+// (profiles/r02_notes.md): 40 % of the VALU slots.  Here the two phases are two WAVES of one workgroup: wave 0 owns the
+// model (LDS rows, K table, the input bytes) and pushes the 8 records of a period into a double-buffered LDS queue
+// (2 x 32 B per lane), wave 1 owns the range coder (state, carry logic, output) and pops them one period later; one
+// s_barrier per period keeps them a period apart.  Same LDS per 64 chunks + 4 KiB, twice the waves per SIMD: each wave's
+// issue gaps are the other's slots.  Payloads are bit-identical by construction (same records, same coder).
+#define RCA_MC_QUEUE   (2u * 2u * 64u * 16u)                   // [buffer][half][lane][16 B]
+#define RCA_MC_LDS     (TRC_NIB_BYTES + RCA_MC_QUEUE)
+
+template <int NS>
+__global__ __launch_bounds__(128 * TRC_WPG) void trc_rca_enc_mc_kernel(
+    const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks,
+    u8 *__restrict__ scratch, u32 stride, u8 *__restrict__ scratch2, u32 stride2,
+    u32 *__restrict__ clen, u32 *__restrict__ gsum)
+{
+    // a workgroup = 4 model waves (0-3) + 4 coder waves (4-7): pair k = waves k and k + 4 = group 4 blockIdx + k; the dispatcher
+    // deals a workgroup's waves over consecutive SIMDs, so SIMD k of the CU holds pair k (trc_dev.h, TRC_WPG)
+    extern __shared__ __attribute__((aligned(16))) u8 smem_wg_[];
+    const u32 wv_ = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool coder = wv_ >= TRC_WPG;
+    const u32 grp_ = blockIdx.x * TRC_WPG + (wv_ & (TRC_WPG - 1u));
+    if (grp_ >= (nchunks + 63u) / 64u) return;                 // (both waves of the pair: a finished wave no longer counts at s_barrier)
+    u8 *const smem = smem_wg_ + (wv_ & (TRC_WPG - 1u)) * RCA_MC_LDS;
+    const u32 lane = trc_lane();
+    NibModel<17> m;
+    if (!coder) m.init(smem);                                  // the model belongs to the model wave alone
+    const u32 qa = trc_lds_addr(smem) + TRC_NIB_BYTES + lane * 16u;
+
+    WaveChunks wc;
+    wc.c0 = grp_ * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
+    wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
+    wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
+    const u32 S = chunk / TRC_SEG;
+
+    if (!coder) {
+        // ---- wave 0: the model.  Walks every period of the chunk (a lane past the end of a short last chunk, or one whose
+        // chunk the coder has given up on, leaves records nobody codes).
+        QuadIn qin; qin.base = in + (u64)wc.c0 * chunk;
+        NibTable T0 = m.load(m.table(0));
+        u32 buf = 0;
+        qin.issue(wc, 0);
+        for (u32 s = 0; s < S; s++) {
+            qin.commit();
+            if (s + 1 < S) qin.issue(wc, (s + 1) * TRC_SEG);
+            uint4 pc0 = qin.read(0), pc1 = qin.read(1), pc2 = qin.read(2), pc3 = qin.read(3);
+#pragma nounroll
+            for (u32 k = 0; k < 4; k++) {
+                uint4 v = pc0; pc0 = pc1; pc1 = pc2; pc2 = pc3;
+#pragma nounroll
+                for (u32 d = 0; d < 4; d++) {
+                    const u32 w = v.x; v.x = v.y; v.y = v.z; v.z = v.w;
+                    const u32 x[4] = { w & 255u, (w >> 8) & 255u, (w >> 16) & 255u, w >> 24 };
+                    u32 rc[8];
+                    m.template record_bytes<4>(T0, x, rc);
+                    const u32 a = qa + buf * 2048u;
+                    trc_ldsw128(a, make_uint4(rc[0], rc[1], rc[2], rc[3]));
+                    trc_ldsw128(a + 1024u, make_uint4(rc[4], rc[5], rc[6], rc[7]));
+                    trc_lds_barrier();
+                    buf ^= 1u;
+                }
+            }
+        }
+        return;
+    }
+
+    // ---- wave 1: the range coder, one period behind
+    const bool alive = lane < wc.rows;
+    const u32 c = wc.c0 + lane;
+    const u32 len = alive ? wc.len_of(lane) : 0u;
+    const int lim = trc_rc_limit(len);
+    const u32 off1 = 4u + len / 2u;                            // stream-1 base inside `out` (rccdf.c:215)
+    LaneOutDirect o0, o1;
+    o0.start(scratch + (u64)c * stride + (NS == 2 ? 4u : 0u));
+    o1.start(NS == 2 ? scratch2 + (u64)c * stride2 : scratch);
+    RcEncD e0, e1; e0.start(); e1.start();
+    bool ovf = alive && NS == 1 && lim <= 0;
+
+    auto code_period = [&](u32 q0, u32 buf) __attribute__((always_inline)) {
+        if (!__ballot(alive && !ovf && q0 < len)) return;
+        const u32 a = qa + buf * 2048u;
+        const uint4 ra = trc_ldsr128(a), rb = trc_ldsr128(a + 1024u);
+        const u32 rc[8] = { ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w };
+        const bool run = alive && !ovf;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool act = run && q0 + (u32)i < len;
+            e0.sym_rec(act, rc[2 * i] >> TRC_PROB_BITS, rc[2 * i] & 0x7fffu);
+            if (NS == 1) { e0.sym_rec(act, rc[2 * i + 1] >> TRC_PROB_BITS, rc[2 * i + 1] & 0x7fffu); e0.flush(o0); }
+            else {
+                e1.sym_rec(act, rc[2 * i + 1] >> TRC_PROB_BITS, rc[2 * i + 1] & 0x7fffu);
+                if (i & 1) { e0.flush(o0); e1.flush(o1); }
+            }
+        }
+        if (NS == 1) ovf = ovf || (run && q0 < len && (int)(4u * e0.cw.nwords) >= lim);
+        else ovf = ovf || (run && q0 + 4u <= len &&
+                           ((int)(off1 + 4u * e1.cw.nwords) >= lim || 4u + 4u * e0.cw.nwords >= off1));
+    };
+    {
+        const u32 P = S * 16u;                                 // periods of a full chunk = barriers of the model wave
+        u32 buf = 0;
+#pragma nounroll
+        for (u32 p = 0; p <= P; p++) {                         // (one call site: the coder's body exists once)
+            if (p) code_period((p - 1u) * 4u, buf ^ 1u);
+            if (p < P) trc_lds_barrier();
+            buf ^= 1u;
+        }
+    }
+    u32 out_len = 0;
+    if (alive) {
+        if (!ovf) {
+            e0.finish(o0);
+            if (NS == 2) {
+                e1.finish(o1);
+                out_len = 4u + o0.wpos + o1.wpos;
+                if ((int)out_len >= lim) ovf = true;
+            } else out_len = o0.wpos;
+        }
+        if (ovf) out_len = len;
+    }
+    if (NS == 2 && alive && !ovf) *(u32 *)(scratch + (u64)c * stride) = o0.wpos;          // header: len0
+    if (alive) clen[c] = out_len;
+    const u32 gs = trc_wave_sum(out_len);
+    if (lane == 0) gsum[wc.c0 >> 6] = gs;
+}
+
 template <int NS, bool NIB>
-__global__ __launch_bounds__(64) void trc_rca_dec_kernel(
+__global__ __launch_bounds__(64 * TRC_WPG) void trc_rca_dec_kernel(
     const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
     u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ out)
 {
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    const u32 lane = threadIdx.x;
+    TRC_QUAD_PROLOGUE(RCA_WAVE_LDS(NIB));
     NibModel<NIB ? 1 : 17> m; m.init(smem);
 
     WaveChunks wc;
-    wc.c0 = blockIdx.x * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
+    wc.c0 = grp_ * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
     wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
     wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
     const bool alive = lane < wc.rows;
@@ -276,18 +403,37 @@ __global__ __launch_bounds__(64) void trc_rca_dec_kernel(
 template <int NS, bool NIB>
 static void launch_rca_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
 {
-    TRC_LAUNCH_TIMED((trc_rca_enc_kernel<NS, NIB>), dim3(w.ngroups), dim3(64), RCA_WAVE_LDS(NIB), s,
+    TRC_RAISE_LDS_ONCE((trc_rca_enc_kernel<NS, NIB>), TRC_WPG * RCA_WAVE_LDS(NIB));
+    TRC_LAUNCH_TIMED((trc_rca_enc_kernel<NS, NIB>), TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (RCA_WAVE_LDS(NIB)), s,
                        d_in, (u64)n, chunk, w.nchunks, w.scratch, w.stride, w.scratch2, w.stride2, d_clen, w.gsum);
 }
 template <int NS, bool NIB>
 static void launch_rca_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                            const TrcWork &w, uint8_t *d_out, hipStream_t s)
 {
-    TRC_LAUNCH_TIMED((trc_rca_dec_kernel<NS, NIB>), dim3(w.ngroups), dim3(64), RCA_WAVE_LDS(NIB), s,
+    TRC_RAISE_LDS_ONCE((trc_rca_dec_kernel<NS, NIB>), TRC_WPG * RCA_WAVE_LDS(NIB));
+    TRC_LAUNCH_TIMED((trc_rca_dec_kernel<NS, NIB>), TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (RCA_WAVE_LDS(NIB)), s,
                        d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, d_out);
+}
+// TRC_RCA_MC=0 selects the one-wave encoder of rounds 1-3 for the byte coders (A/B measurements, tests of both forms)
+static bool rca_mc_enabled()
+{
+    static const int env = getenv("TRC_RCA_MC") ? atoi(getenv("TRC_RCA_MC")) : 1;
+    return env != 0;
+}
+template <int NS>
+static void launch_rca_enc_mc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
+{
+    TRC_RAISE_LDS_ONCE(trc_rca_enc_mc_kernel<NS>, TRC_WPG * RCA_MC_LDS);
+    TRC_LAUNCH_TIMED((trc_rca_enc_mc_kernel<NS>), TRC_QUAD_GRID(w.ngroups), dim3(128 * TRC_WPG), TRC_WPG * RCA_MC_LDS, s,
+                       d_in, (u64)n, chunk, w.nchunks, w.scratch, w.stride, w.scratch2, w.stride2, d_clen, w.gsum);
 }
 void trc_launch_rca_enc(int nstreams, int nibble, const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
 {
+    if (!nibble && rca_mc_enabled()) {
+        if (nstreams == 2) launch_rca_enc_mc<2>(d_in, n, chunk, w, d_clen, s); else launch_rca_enc_mc<1>(d_in, n, chunk, w, d_clen, s);
+        return;
+    }
     if (nibble) { if (nstreams == 2) launch_rca_enc<2, true>(d_in, n, chunk, w, d_clen, s); else launch_rca_enc<1, true>(d_in, n, chunk, w, d_clen, s); }
     else        { if (nstreams == 2) launch_rca_enc<2, false>(d_in, n, chunk, w, d_clen, s); else launch_rca_enc<1, false>(d_in, n, chunk, w, d_clen, s); }
 }

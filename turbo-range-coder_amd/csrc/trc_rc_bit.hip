@@ -53,19 +53,18 @@ __device__ __forceinline__ u32 rcb_bfi(u32 m, u32 a, u32 b)
 __device__ __forceinline__ u32 rcb_adapt(u32 p, u32 bit) { return (p - (((p - (bit << TRC_PROB_BITS)) >> 5) + bit)) & 0xffffu; }
 
 template <bool L7G>
-__global__ __launch_bounds__(64) void trc_rcb_enc_kernel(
+__global__ __launch_bounds__(64 * TRC_WPG) void trc_rcb_enc_kernel(
     const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks,
     u8 *__restrict__ scratch, u32 stride, u8 *__restrict__ level7, u32 *__restrict__ clen, u32 *__restrict__ gsum)
 {
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    const u32 lane = threadIdx.x;
+    TRC_QUAD_PROLOGUE(RCB_ENC_WAVE_LDS(L7G));
     u16 *mb = (u16 *)smem + lane;                              // mb[ctx * 64]
     for (u32 i = 0; i < RCB_ENC_WAVE_LDS(L7G) / 128u; i++) mb[i * 64] = (u16)(TRC_PROB_ONE >> 1);
     u16 *l7 = nullptr;
     if constexpr (L7G) {
     // this wave's level-7 rows: 64 lanes x 256 B, contiguous -- filled with coalesced 16-byte stores (lane l: bytes 16 l + 1024 i),
     // then every lane works on its own row.  The loads below see these stores: same wave, the stores are waited for.
-    u8 *l7w = level7 + (u64)blockIdx.x * (64u * 256u);
+    u8 *l7w = level7 + (u64)grp_ * (64u * 256u);
     {
         const u32 h = (TRC_PROB_ONE >> 1) | (TRC_PROB_ONE >> 1) << 16;
 #pragma unroll
@@ -77,7 +76,7 @@ __global__ __launch_bounds__(64) void trc_rcb_enc_kernel(
     }
 
     WaveChunks wc;
-    wc.c0 = blockIdx.x * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
+    wc.c0 = grp_ * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
     wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
     wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
     const bool alive = lane < wc.rows;
@@ -229,17 +228,198 @@ __global__ __launch_bounds__(64) void trc_rcb_enc_kernel(
     if (lane == 0) gsum[wc.c0 >> 6] = gs;
 }
 
-__global__ __launch_bounds__(64) void trc_rcb_dec_kernel(
+// ---- the encoder as TWO WAVES per 64 chunks (round 4; the scheme of trc_rca_enc_mc_kernel, trc_rc_adaptive.hip) --------
+// Nothing of the model side of a byte depends on the coder: the eight nodes are a function of the byte, their
+// probabilities a function of the bytes before it.  Wave 0 owns the model (32 KiB of LDS, the input bytes): per byte it
+// reads the eight probabilities, adapts them, and pushes four RECORDS {p | bit << 15} x 2 (one per half of a dword: a
+// probability has 15 bits) into a double-buffered LDS queue, two bytes = 32 B per lane and period.  Wave 1 owns the range
+// coder (state on 32-bit halves, carry logic, output) and pops them one period later; the bits ride in the records, so
+// it never sees the input.  One LDS-only s_barrier per period.  36 KiB per workgroup: four per CU, two waves per SIMD.
+#define RCB_MC_QUEUE   (2u * 2u * 64u * 16u)                   // [buffer][byte of the period][lane][16 B]
+#define RCB_MC_LDS     (RCB_MODEL_BYTES + RCB_MC_QUEUE)
+
+__global__ __launch_bounds__(128 * TRC_WPG) void trc_rcb_enc_mc_kernel(
+    const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks,
+    u8 *__restrict__ scratch, u32 stride, u32 *__restrict__ clen, u32 *__restrict__ gsum)
+{
+    // a workgroup = 4 model waves (0-3) + 4 coder waves (4-7): pair k = waves k and k + 4 on SIMD k (trc_dev.h, TRC_WPG)
+    extern __shared__ __attribute__((aligned(16))) u8 smem_wg_[];
+    const u32 wv_ = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool coder = wv_ >= TRC_WPG;
+    const u32 grp_ = blockIdx.x * TRC_WPG + (wv_ & (TRC_WPG - 1u));
+    if (grp_ >= (nchunks + 63u) / 64u) return;                 // (both waves of the pair: a finished wave no longer counts at s_barrier)
+    u8 *const smem = smem_wg_ + (wv_ & (TRC_WPG - 1u)) * RCB_MC_LDS;
+    const u32 lane = trc_lane();
+    const u32 qa = trc_lds_addr(smem) + RCB_MODEL_BYTES + lane * 16u;
+
+    WaveChunks wc;
+    wc.c0 = grp_ * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
+    wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
+    wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
+    const u32 S = chunk / TRC_SEG;
+
+    if (!coder) {
+        // ---- wave 0: the model
+        u16 *mb = (u16 *)smem + lane;                          // mb[ctx * 64]
+        for (u32 i = 0; i < RCB_MODEL_BYTES / 128u; i++) mb[i * 64] = (u16)(TRC_PROB_ONE >> 1);
+        const u32 mcol = trc_lds_addr(smem) + lane * 2u;
+        // the records of one byte: R[j] = {p(node of bit 7-2j) | bit << 15, p(node of bit 6-2j) | bit << 15} before adaptation
+        auto model_byte = [&](u32 x, u32 qaddr) __attribute__((always_inline)) {
+            const u32 t = 0x100u | x;
+            u32 ad[8];
+            ad[0] = mcol + 128u;
+#pragma unroll
+            for (int k = 1; k < 8; k++) ad[k] = (((t >> (8 - k)) << 7) & RCB_AMASK) + mcol;
+            u32 pr[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) pr[k] = trc_ldsr16(ad[k]);
+            u32 R[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const u32 P = pr[2 * j] | pr[2 * j + 1] << 16;
+                const u32 B = __builtin_amdgcn_ubfe(x, 7 - 2 * j, 1) | __builtin_amdgcn_ubfe(x, 6 - 2 * j, 1) << 16;
+                const trc_s2 pv = trc_as_s2(P), bv = trc_as_s2(B);
+                const trc_s2 np = pv - (((pv - trc_as_s2(B << 15)) >> (trc_s2)5) + bv);
+                const u32 NP = trc_as_u32(np);
+                trc_ldsw16(ad[2 * j], NP);
+                trc_ldsw16(ad[2 * j + 1], NP >> 16);
+                R[j] = P | B << 15;
+            }
+            trc_ldsw128(qaddr, make_uint4(R[0], R[1], R[2], R[3]));
+        };
+        QuadIn qin; qin.base = in + (u64)wc.c0 * chunk;
+        u32 buf = 0;
+        qin.issue(wc, 0);
+        for (u32 s = 0; s < S; s++) {
+            qin.commit();
+            if (s + 1 < S) qin.issue(wc, (s + 1) * TRC_SEG);
+            uint4 pc0 = qin.read(0), pc1 = qin.read(1), pc2 = qin.read(2), pc3 = qin.read(3);
+#pragma nounroll
+            for (u32 k = 0; k < 4; k++) {
+                uint4 v = pc0; pc0 = pc1; pc1 = pc2; pc2 = pc3;
+#pragma nounroll
+                for (u32 d = 0; d < 4; d++) {
+                    const u32 w = v.x; v.x = v.y; v.y = v.z; v.z = v.w;
+#pragma unroll
+                    for (u32 h = 0; h < 2; h++) {
+                        const u32 a = qa + buf * 2048u;
+                        model_byte((w >> (16 * h)) & 255u, a);
+                        model_byte((w >> (16 * h + 8)) & 255u, a + 1024u);
+                        trc_lds_barrier();
+                        buf ^= 1u;
+                    }
+                }
+            }
+        }
+        return;
+    }
+
+    // ---- wave 1: the range coder (the state and the emit logic of trc_rcb_enc_kernel), one period behind
+    const bool alive = lane < wc.rows;
+    const u32 c = wc.c0 + lane;
+    const u32 len = alive ? wc.len_of(lane) : 0u;
+    const int lim = trc_rc_limit(len);
+    LaneOutDirect so; so.start(scratch + (u64)c * stride);
+    u32 rlo = ~0u, rhi = ~0u, llo = 0, lhi = 0;
+    bool cy = false;
+    TrcCarry cw; cw.start();
+    bool ovf = alive && lim <= 0;
+    bool live = alive && !ovf;
+    u32 out_len = alive ? len : 0u;
+
+    auto put_byte = [&](const uint4 rec) __attribute__((always_inline)) {
+        const u32 R[4] = { rec.x, rec.y, rec.z, rec.w };
+        bool rnj[4], cyj[4];
+        u32 pwj[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            {
+                const bool rn = rhi == 0u;
+                rnj[j] = rn; cyj[j] = rn && cy; pwj[j] = lhi;
+                cy = cy && !rn;
+                lhi = rn ? llo : lhi; llo = rn ? 0u : llo;
+                rhi = rn ? rlo : rhi; rlo = rn ? 0u : rlo;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const u32 prob = h ? __builtin_amdgcn_ubfe(R[j], 16, 15) : R[j] & 0x7fffu;
+                const u32 m = h ? (u32)((int)R[j] >> 31) : (u32)__builtin_amdgcn_sbfe((int)R[j], 15, 1);   // bit 1: all ones
+                const u32 slo = __builtin_amdgcn_alignbit(rhi, rlo, TRC_PROB_BITS), shi = rhi >> TRC_PROB_BITS;
+                const u64 c64 = (u64)slo * prob;
+                const u32 clo = (u32)c64, chi = __umul24(shi, prob) + (u32)(c64 >> 32);
+                u32 k1, k2;
+                llo = __builtin_addc(llo, rcb_bfi(m, 0u, clo), 0u, &k1);
+                lhi = __builtin_addc(lhi, rcb_bfi(m, 0u, chi), k1, &k2);
+                cy = cy || (k2 != 0u);
+                u32 b1, b2;
+                const u32 tlo = __builtin_subc(rlo, clo, 0u, &b1), thi = __builtin_subc(rhi, chi, b1, &b2);
+                rlo = rcb_bfi(m, clo, tlo); rhi = rcb_bfi(m, chi, thi);
+            }
+        }
+        const bool two = (rnj[0] && (rnj[1] || rnj[2] || rnj[3])) || (rnj[1] && (rnj[2] || rnj[3])) || (rnj[2] && rnj[3]);
+        if (__ballot(two && live)) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) cw.emit_if(so, rnj[j] && live, cyj[j], pwj[j]);
+        } else {
+            const bool pend = rnj[0] || rnj[1] || rnj[2] || rnj[3];
+            const bool pcy = cyj[0] || cyj[1] || cyj[2] || cyj[3];
+            const u32 pw = rnj[3] ? pwj[3] : rnj[2] ? pwj[2] : rnj[1] ? pwj[1] : pwj[0];
+            cw.emit_if(so, pend && live, pcy, pw);
+        }
+    };
+    auto finish = [&]() __attribute__((always_inline)) {                                      // rceflush (turborc_.h:118-128), then everything still held back
+        u64 low = ((u64)lhi << 32) | llo;
+        u64 rg = ((u64)rhi << 32) | rlo;
+        bool c0 = cy;
+        if (rg < TRC_TOP32) { cw.emit(so, c0, (u32)(low >> 32)); low <<= 32; rg <<= 32; c0 = false; }
+        if (rg > ((u64)1 << 33)) {
+            const u64 nl = low + TRC_TOP32;
+            cw.emit(so, c0 || nl < low, (u32)(nl >> 32));
+        } else {
+            const u64 nl = low + 1;
+            cw.emit(so, c0 || nl < low, (u32)(nl >> 32));
+            cw.emit(so, false, (u32)nl);
+        }
+        cw.release(so);
+    };
+    auto code_period = [&](u32 q0, u32 buf) __attribute__((always_inline)) {
+        if (!__ballot(live)) return;
+        const u32 a = qa + buf * 2048u;
+        const uint4 r0 = trc_ldsr128(a), r1 = trc_ldsr128(a + 1024u);
+        const bool ends = __ballot(live && len - q0 < 2u) != 0;        // a short last chunk ends inside this period (once per grid)
+        if (ends && live && q0 == len) { if ((int)(4u * cw.nwords) < lim) { finish(); out_len = so.wpos; } live = false; }
+        put_byte(r0);
+        if (ends && live && q0 + 1u == len) { if ((int)(4u * cw.nwords) < lim) { finish(); out_len = so.wpos; } live = false; }
+        put_byte(r1);
+        ovf = ovf || (live && (int)(4u * cw.nwords) >= lim);           // OVERFLOW, monotone
+        live = live && !ovf;
+    };
+    {
+        const u32 P = S * 32u;                                 // periods of a full chunk = barriers of the model wave
+        u32 buf = 0;
+#pragma nounroll
+        for (u32 p = 0; p <= P; p++) {                         // (one call site: the coder's body exists once)
+            if (p) code_period((p - 1u) * 2u, buf ^ 1u);
+            if (p < P) trc_lds_barrier();
+            buf ^= 1u;
+        }
+    }
+    if (live) { finish(); out_len = so.wpos; }
+    if (alive) clen[c] = out_len;
+    const u32 gs = trc_wave_sum(out_len);
+    if (lane == 0) gsum[wc.c0 >> 6] = gs;
+}
+
+__global__ __launch_bounds__(64 * TRC_WPG) void trc_rcb_dec_kernel(
     const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
     u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ out)
 {
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    const u32 lane = threadIdx.x;
+    TRC_QUAD_PROLOGUE(RCB_WAVE_LDS);
     u16 *mb = (u16 *)smem + lane;
     for (u32 i = 0; i < RCB_MODEL_BYTES / 128u; i++) mb[i * 64] = (u16)(TRC_PROB_ONE >> 1);
 
     WaveChunks wc;
-    wc.c0 = blockIdx.x * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
+    wc.c0 = grp_ * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
     wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
     wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
     const bool alive = lane < wc.rows;
@@ -351,21 +531,30 @@ void trc_launch_rcb_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const Trc
     // 1.68 -> 1.86-2.0 ms).  It pays where it saves a residency ROUND: more waves than 5 per CU hold, no more than 9 per CU
     // hold (100 MB at chunk 1024: 1526 waves, 2.12 -> 1.30 ms).  TRC_RCB_L7G=0 / 1 force a form.
     static const int env = getenv("TRC_RCB_L7G") ? atoi(getenv("TRC_RCB_L7G")) : -1;
+    static const int env_mc = getenv("TRC_RCB_MC") ? atoi(getenv("TRC_RCB_MC")) : -1;
     const bool l7g = env >= 0 ? env != 0 : (w.ngroups > 5u * 256u && w.ngroups <= 9u * 256u);
+    // the two-wave form (model wave + coder wave): four workgroups per CU
+    const bool mc = env_mc >= 0 ? env_mc != 0 : (env < 0);
+    if (mc) {
+        TRC_RAISE_LDS_ONCE(trc_rcb_enc_mc_kernel, TRC_WPG * RCB_MC_LDS);
+        TRC_LAUNCH_TIMED(trc_rcb_enc_mc_kernel, TRC_QUAD_GRID(w.ngroups), dim3(128 * TRC_WPG), TRC_WPG * RCB_MC_LDS, s,
+                           d_in, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
+        return;
+    }
     if (l7g) {
-        TRC_RAISE_LDS_ONCE(trc_rcb_enc_kernel<true>, RCB_ENC_WAVE_LDS(true));
-        TRC_LAUNCH_TIMED(trc_rcb_enc_kernel<true>, dim3(w.ngroups), dim3(64), RCB_ENC_WAVE_LDS(true), s,
+        TRC_RAISE_LDS_ONCE(trc_rcb_enc_kernel<true>, TRC_WPG * RCB_ENC_WAVE_LDS(true));
+        TRC_LAUNCH_TIMED(trc_rcb_enc_kernel<true>, TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (RCB_ENC_WAVE_LDS(true)), s,
                            d_in, (u64)n, chunk, w.nchunks, w.scratch, w.stride, w.scratch2, d_clen, w.gsum);
     } else {
-        TRC_RAISE_LDS_ONCE(trc_rcb_enc_kernel<false>, RCB_ENC_WAVE_LDS(false));
-        TRC_LAUNCH_TIMED(trc_rcb_enc_kernel<false>, dim3(w.ngroups), dim3(64), RCB_ENC_WAVE_LDS(false), s,
+        TRC_RAISE_LDS_ONCE(trc_rcb_enc_kernel<false>, TRC_WPG * RCB_ENC_WAVE_LDS(false));
+        TRC_LAUNCH_TIMED(trc_rcb_enc_kernel<false>, TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (RCB_ENC_WAVE_LDS(false)), s,
                            d_in, (u64)n, chunk, w.nchunks, w.scratch, w.stride, w.scratch2, d_clen, w.gsum);
     }
 }
 void trc_launch_rcb_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                         const TrcWork &w, uint8_t *d_out, hipStream_t s)
 {
-    TRC_RAISE_LDS_ONCE(trc_rcb_dec_kernel, RCB_WAVE_LDS);
-    TRC_LAUNCH_TIMED(trc_rcb_dec_kernel, dim3(w.ngroups), dim3(64), RCB_WAVE_LDS, s,
+    TRC_RAISE_LDS_ONCE(trc_rcb_dec_kernel, TRC_WPG * RCB_WAVE_LDS);
+    TRC_LAUNCH_TIMED(trc_rcb_dec_kernel, TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (RCB_WAVE_LDS), s,
                        d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, d_out);
 }

@@ -208,12 +208,16 @@ class StepPipeline:
     on_gathered(first_step_of_group, sizes, got)  optional hook, called on every rank after its part of a group's
                exchange has been issued (tests assert every step's container there)
     """
-    def __init__(self, dist, rank, world, group, banks, recv, nch, rt, rotate=True, on_gathered=None):
+    def __init__(self, dist, rank, world, group, banks, recv, nch, rt, rotate=True, on_gathered=None, lag=1):
         self.dist, self.rank, self.world, self.group = dist, rank, world, group
         self.banks, self.recv, self.nch, self.rt, self.rotate = banks, recv, nch, rt, rotate
         self.on_gathered = on_gathered
         self.done = [None, None]
         self.pending = []
+        # `lag`: how many steps after a group's last step its exchange is issued (the host reads the sizes then and waits for
+        # that group's last encode: the more steps are queued behind it, the less the GPU can run dry meanwhile; the later the
+        # transfers start).  1 = rounds 2-3.  At most `group`: the bank is coded into again `group` steps later.
+        self.lag = max(1, min(int(lag), max(1, group)))
 
     def reset(self):
         """between independent runs (set-up / warmup / timed): forget finished exchanges"""
@@ -231,9 +235,10 @@ class StepPipeline:
         if self.on_gathered:
             self.on_gathered(first, sizes, got)
 
-    def _run_pending(self):
-        while self.pending:
-            bank, ns, coded, first = self.pending.pop(0)
+    def _run_pending(self, upto=None):
+        """issue the exchanges that are due (all of them with upto=None)"""
+        while self.pending and (upto is None or self.pending[0][4] <= upto):
+            bank, ns, coded, first, _ = self.pending.pop(0)
             self.rt.side_wait(coded)                           # the exchange may start once the group's last encode is done
             with self.rt.on_side():
                 self._exchange(bank, ns, first)
@@ -244,14 +249,16 @@ class StepPipeline:
         decodes them again (both only enqueue work on the main stream)"""
         j, bank, ns = group_plan(k, self.group, last)
         if j == 0:
+            if any(p[0] == bank for p in self.pending):        # (lag == group: the exchange out of this bank must be issued before it is waited for)
+                self._run_pending()
             self.rt.main_wait(self.done[bank])                 # the previous exchange out of this bank is done
         result = self.banks[bank][j]
         encode(result)
         coded = self.rt.record_main() if ns else None
         decode(result)
-        self._run_pending()                                    # one step late: the GPU has this step's kernels queued meanwhile
+        self._run_pending(k)                                   # `lag` steps late: the GPU has those steps' kernels queued meanwhile
         if ns:
-            self.pending.append((bank, ns, coded, k - j))
+            self.pending.append((bank, ns, coded, k - j, k + self.lag))
         if last:
             self._run_pending()
 

@@ -72,6 +72,8 @@ def lib():
         l.trc_device_count.restype = C.c_int
         l.trc_set_chunk.restype = C.c_int; l.trc_set_chunk.argtypes = [C.c_uint32]
         l.trc_get_chunk.restype = C.c_uint32
+        l.trc_round_chunk.restype = C.c_uint32; l.trc_round_chunk.argtypes = [C.c_int, _sz]
+        l.trc_auto_chunk_codec.restype = C.c_uint32; l.trc_auto_chunk_codec.argtypes = [C.c_int, _sz]
         l.trc_work_bytes.restype = _sz; l.trc_work_bytes.argtypes = [C.c_int, _sz, C.c_uint32]
         l.trc_cdfini_dev.restype = C.c_int
         l.trc_cdfini_dev.argtypes = [_vp, _sz, _vp, C.c_uint, _vp, _vp, _vp]
