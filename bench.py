@@ -238,11 +238,31 @@ def launch_command(ngpus, argv, env=None):
     return cmd, add
 
 
+def memory_budget(codec_name, n, chunk, world, group):
+    """HBM bytes one rank of `bench.py --gpus world` allocates (needs the library, not a GPU): what the first real 8-GPU
+    run of BASELINE config 5 (1 GB shards) has to fit.  input + decoded output; the coder's workspace, directory and
+    payload (trc.DeviceCoder); two banks of `group` result sets (clen, payload, total) for the exchange; on a root, two
+    banks of world - 1 receive sets."""
+    sys.path[:0] = [os.path.join(ROOT, "turbo-range-coder_amd")]
+    import trc
+    codec = {v: k for k, v in trc.CODEC_NAMES.items()}[codec_name]
+    chunk = chunk or int(trc.lib().trc_round_chunk(codec, n))
+    nch = (n + chunk - 1) // chunk
+    result = 4 * (max(nch, 1) + 64) + (n + trc.PAD + 64) + 16
+    b = {"input": n + 512, "output": n + 512, "workspace": int(trc.lib().trc_work_bytes(codec, n, chunk)) + trc.PAD,
+         "result_banks": (2 * group if world > 1 else 1) * result,
+         "receive_banks": 2 * (world - 1) * (4 * nch + n + 1024) if world > 1 else 0, "small": 4096}
+    b["total"] = sum(b.values())
+    b["chunk"] = chunk
+    return b
+
+
 def self_launch(args):
     import subprocess
     cmd, add = launch_command(args.gpus, sys.argv[1:])
     if args.dry_launch:
-        print(json.dumps({"launch": cmd, "env": add}))
+        n = args.size or (1000 * 1000 * 1000 if args.workload == "zipf1g" else 100 * 1000 * 1000)
+        print(json.dumps({"launch": cmd, "env": add, "hbm_bytes_per_rank": memory_budget(args.codec, n, args.chunk, args.gpus, args.group or args.gpus)}))
         return 0
     env = dict(os.environ); env.update(add)
     # the ranks inherit stdout: rank 0 prints the one JSON line; torch.distributed.run ends non-zero if any rank dies
@@ -267,6 +287,9 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cold", action="store_true", help="skip the value_cold pass (flags off)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the exchange code even with 1 rank (self-test)")
+    ap.add_argument("--group", type=int, default=0, help="steps per exchange group (default: the world size with rotating roots; with --force-dist on one rank, "
+                    "--group 8 runs the 8-GPU schedule -- banks of 8 steps, one size all-gather + one grouped send/receive per 8 steps -- with nothing to send: the schedule's own cost)")
+    ap.add_argument("--lag", type=int, default=1, help="steps after a group's last step before its exchange is issued (shard.StepPipeline)")
     ap.add_argument("--clock-warmup-ms", type=float, default=400.0,
                     help="untimed preamble: the same step repeated for about this long before the W warm-up steps, so that the K "
                          "timed steps run at the GPU's steady-state clocks (0 = none; the JSON also carries the cold-clock line)")
@@ -344,7 +367,7 @@ def main():
     # same class with CPU tensors.  TRC_BENCH_EXCHANGE=root0 selects the plain per-step gather to rank 0.
     nch = trc.nchunks(n, chunk)
     rotate = use_dist and os.environ.get("TRC_BENCH_EXCHANGE", "rotate") != "root0"
-    G = world if rotate else 1                                 # steps per exchange group
+    G = (args.group if args.group > 0 and use_dist else world) if rotate else 1     # steps per exchange group
     DIRR = os.environ.get('TRC_NO_DIRR') is None               # ablation knob: TRC_NO_DIRR=1 re-derives the group sums in every decode
 
     def encode(result):
@@ -376,7 +399,7 @@ def main():
         if world > 1 and (rotate or rank == 0):                # this rank is the root of one step per group
             recv = [([torch.empty(nch, dtype=torch.int32, device=dev) for _ in range(world - 1)],
                      [torch.empty(n + 1024, dtype=torch.uint8, device=dev) for _ in range(world - 1)]) for _ in range(2)]
-        pipe = shard.StepPipeline(dist, rank, world, G, banks, recv, nch, shard.CudaRuntime(torch, dev), rotate=rotate)
+        pipe = shard.StepPipeline(dist, rank, world, G, banks, recv, nch, shard.CudaRuntime(torch, dev), rotate=rotate, lag=args.lag)
 
     def step(k, last):
         if pipe is None:
@@ -548,7 +571,8 @@ def main():
                        # what the chunking costs (round 4): the container as stored (32 B header + 4 B of directory per chunk + payloads)
                        # next to ONE call of the reference function over the whole input (filled in below from the committed fixture)
                        "ratio_container": round((32 + 4 * ((n + chunk - 1) // chunk) + total_c) / n, 5), "ratio_reference_whole_buffer": None,
-                       "steps_in_flight": inflight, "exchange": ("none" if world == 1 else "rccl gather of every step's payloads, root rotating over the ranks, %d steps per grouped exchange" % G if rotate else "rccl gather of payloads to rank 0")},
+                       "steps_in_flight": inflight, "exchange_group_steps": G if use_dist else None, "exchange_lag_steps": (pipe.lag if pipe is not None else None),
+                       "exchange": ("none" if world == 1 else "rccl gather of every step's payloads, root rotating over the ranks, %d steps per grouped exchange" % G if rotate else "rccl gather of payloads to rank 0")},
             "flags": ["TABLES_READY", "DIR_READY"] if (codec in trc.STATIC and DIRR) else (["DIR_READY"] if DIRR else (["TABLES_READY"] if codec in trc.STATIC else [])),
             "value_cold": round(cold[0], 1) if cold else None,
             "ms_per_step_cold": round(cold[1], 4) if cold else None,

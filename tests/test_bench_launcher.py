@@ -28,6 +28,11 @@ def test_dry_launch_command_and_environment():
     i = cmd.index(BENCH)
     assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5", "--workload", "zipf1g"]      # flags pass through, --dry-launch does not
     assert j["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # BASELINE config 5 on 8 GPUs: what one rank allocates (1 GB shard; two banks of 8 result sets, two banks of 7 receive
+    # sets, the coder's scratch) must fit a 288 GB GPU with a wide margin
+    b = j["hbm_bytes_per_rank"]
+    assert b["chunk"] == 2560 and b["receive_banks"] == 2 * 7 * (4 * 390625 + 10**9 + 1024)
+    assert 30e9 < b["total"] < 40e9, b
 
 
 def test_dry_launch_honours_master_port():

@@ -1,0 +1,64 @@
+"""The chunk the library picks for a device-resident call (trc_round_chunk, include/trc_hip.h) against its neighbours.
+
+A launch of the one-lane-per-chunk coders lasts (residency rounds) x (one wave's time ~ chunk bytes): in round 3 100 MB of
+`rccdf` at chunk 1280 ran at half the rate of chunk 1536, and bench.py side-stepped the cliff with a hand-picked table
+for exactly 100 MB.  trc_round_chunk computes the chunk from (coder, n) so that the input is a whole number of rounds,
+barely; this test sweeps input sizes that are NOT 100 MB and asserts that the pick is never more than 15 % slower than
+the best chunk of its +-256-byte neighbourhood (encode + decode, device-resident, whole step)."""
+import pytest
+
+import trc
+import trc_testlib as T
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU (and must not silently fall back)"
+    return torch
+
+MB = 10**6
+
+
+def _step_ms(torch, dc, d_in, d_out, n, reps=4):
+    for _ in range(2):
+        dc.encode(d_in, n); dc.decode(d_out, n)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 1e9
+    for _ in range(reps):
+        a.record()
+        dc.encode(d_in, n); dc.decode(d_out, n)
+        b.record(); torch.cuda.synchronize()
+        best = min(best, a.elapsed_time(b))
+    return best
+
+
+@pytest.mark.parametrize("name", ["anscdf4s", "rccdf", "rcs"])
+def test_round_chunk_is_no_cliff(torch_cuda, name):
+    torch = torch_cuda
+    codec = {v: k for k, v in trc.CODEC_NAMES.items()}[name]
+    dev = torch.device("cuda:0")
+    nmax = 333 * MB
+    d_in = torch.zeros(nmax + 512, dtype=torch.uint8, device=dev)
+    T.table_bytes_device(torch, dev, nmax, T.text_weights(), 7, out=d_in)       # any prefix of it is the same kind of data
+    d_out = torch.zeros(nmax + 512, dtype=torch.uint8, device=dev)
+    report = []
+    for n in (70 * MB, 100 * MB, 120 * MB, 150 * MB, 333 * MB):
+        pick = int(trc.lib().trc_round_chunk(codec, n))
+        times = {}
+        for c in range(max(256, pick - 256), min(4096, pick + 256) + 1, 64):
+            dc = trc.DeviceCoder(codec, n, c, dev)
+            if codec in trc.STATIC:
+                dc.cdfini(d_in, n, 256)
+            times[c] = _step_ms(torch, dc, d_in, d_out, n)
+            if c == pick:
+                assert torch.equal(d_out[:n], d_in[:n]), "round trip failed"
+            del dc
+        best = min(times, key=times.get)
+        report.append("%s n=%d MB: pick %d %.3f ms, best %d %.3f ms, worst %d %.3f ms" %
+                      (name, n // MB, pick, times[pick], best, times[best], max(times, key=times.get), max(times.values())))
+        assert times[pick] <= 1.15 * times[best], report[-1] + "  all: %s" % {k: round(v, 3) for k, v in times.items()}
+    print("\n".join(report))

@@ -142,6 +142,10 @@ def zipf_bytes(n, alpha=1.1, nsym=256, seed=1):
 
 def text_bytes(n, seed=7):
     """'enwik8 stand-in' (SURVEY 8d cfg 2): i.i.d. bytes, English-like order-0 table, ~5.1 bit/B."""
+    return table_bytes(n, text_weights(), seed)
+
+
+def text_weights():
     w = np.full(256, 2e-5)
     common = b" etaoinshrdlcumwfgypbvkjxqz"
     freq = [17.0, 9.6, 7.0, 6.2, 5.9, 5.5, 5.3, 5.0, 4.5, 4.4, 3.3, 3.1, 2.4, 2.2, 2.1, 1.9, 1.8, 1.6, 1.5, 1.3,
@@ -154,7 +158,7 @@ def text_bytes(n, seed=7):
         w[ch] = 0.45
     for ch, f in zip(b"[]|=<>/&;:.,'\"\n-()", [1.2, 1.2, 0.7, 0.6, 0.9, 0.9, 0.6, 0.5, 0.5, 0.4, 0.9, 1.0, 0.5, 0.5, 1.3, 0.4, 0.2, 0.2]):
         w[ch] = f
-    return table_bytes(n, w, seed)
+    return w
 
 
 def runs_bytes(n, seed=3, mean_run=6.0, alpha=1.2):

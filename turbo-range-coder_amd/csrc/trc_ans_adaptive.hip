@@ -335,6 +335,112 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_ansa_code_planar_kernel(
     if (lane == 0) gsum[wc.c0 >> 6] = gs;
 }
 
+// Pass 2 with FOUR LANES PER CHUNK (round 4).  The four rANS states of anscdfenc are independent chains that share only the
+// order of their 16-bit words (anscdf_.h:106-138: record i steps state 3 - (i & 3), words go out in record order, downward), and
+// pass 2 has no model: nothing but the chunk count (65 104 at 100 MB / 1536) kept it at one wave per SIMD, where a wave issues
+// every ~1.5 quad-cycles and the chip's other 7/8 lanes idle.  Here lanes 4i .. 4i + 3 take chunk i of the wave, lane s state s:
+// a step is four consecutive records (32t + 4u + 3 - s goes to lane s: descending record order = ascending lane order), the
+// emit flags of a quad come from one __ballot, a lane's word goes to the shared stream position + 2 x (emits of the lanes
+// before it), the overflow rule (before EVERY record: words so far + 18 >= len -> raw; monotone) is evaluated by every lane with
+// its own "words so far" and ORed over the quad -- the same decisions as the one-lane walk.  Four times the waves, a quarter
+// of the chain each.  A workgroup = 4 waves = one group of 64 chunks (gsum keeps its meaning).
+#define ANSQ_ROW        144u                                   // tile row: one block (64 B hi + 64 B lo records) + 16 B (bank spread)
+#define ANSQ_TILE       (16u * ANSQ_ROW)
+#define ANSQ_WAVE_LDS   (ANSQ_TILE + 16u * TRC_SRING_STRIDE)   // + 16 rings
+#define ANSQ_LDS        (4u * ANSQ_WAVE_LDS + 16u)
+__global__ __launch_bounds__(256) void trc_ansa_codeq_kernel(
+    const u8 *__restrict__ recs, u64 n, u32 chunk, u32 nchunks,
+    u8 *__restrict__ scratch, u32 stride, u32 *__restrict__ clen, u32 *__restrict__ gsum)
+{
+    typedef __attribute__((address_space(3))) u32 lds_u32;
+    extern __shared__ __attribute__((aligned(16))) u8 smem_wg_[];
+    const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const u32 lane = trc_lane(), s = lane & 3u, ci = lane >> 2;
+    u8 *const smem = smem_wg_ + wv * ANSQ_WAVE_LDS;
+    u32 *const wsum = (u32 *)(smem_wg_ + 4u * ANSQ_WAVE_LDS);
+    const u32 cw0 = blockIdx.x * 64u + wv * 16u;               // this wave's first chunk
+    const u32 c = cw0 + ci;
+    const bool alive = c < nchunks;
+    const u32 lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
+    const u32 len = alive ? (c == nchunks - 1u ? lastlen : chunk) : 0u;
+    const u32 nrec = 2u * (len + (len & 1u));                  // 4 per byte pair: a multiple of 4
+    const u32 room = 2u + 4u * 4u;                             // mnflush: ep <= op + sizeof(io_t) + states * 4  ->  raw
+    const u8 *rbase = recs + (u64)(alive ? c : 0u) * (8u * (u64)chunk);
+
+    StreamOut<true, false, true> so;
+    so.rings = smem + ANSQ_TILE;
+    so.scratch = scratch; so.stride = stride; so.c0 = cw0; so.wpos = 0; so.nfl = 0;
+    u32 st = TRC_ANS_LOW;
+    bool ovf = false;
+    const u32 sh = lane & ~3u, below = (1u << s) - 1u;
+    const u32 tw = trc_lds_addr(smem) + ci * ANSQ_ROW + 16u * s;                      // where this lane's two pieces of a block land
+    const u32 tr = trc_lds_addr(smem) + ci * ANSQ_ROW + ((s & 1u) ? 0u : 64u) + (s < 2u ? 4u : 0u);   // its records: plane, then every other dword
+
+    const u32 T = chunk / 16u;                                 // blocks (32 records each) of a full chunk
+    const u32 top = nrec ? (nrec - 1u) / 32u : 0u;
+    // a lane that has nothing to store this step stores into its own dummy slot (the row's 16 pad bytes): no exec-mask branch
+    const u32 ringw = trc_lds_addr(so.rings) + ci * TRC_SRING_STRIDE;
+    const u32 dummy = trc_lds_addr(smem) + ci * ANSQ_ROW + 128u + 4u * s;
+    uint4 nh = make_uint4(0, 0, 0, 0), nl = nh;
+    if (alive && nrec && T - 1u <= top) { nh = trc_ld16_nt(rbase + (T - 1u) * 128u + 16u * s); nl = trc_ld16_nt(rbase + (T - 1u) * 128u + 64u + 16u * s); }
+    for (u32 t = T - 1u;; t--) {
+        trc_ldsw128(tw, nh); trc_ldsw128(tw + 64u, nl);
+        if (t && alive && nrec && t - 1u <= top) { nh = trc_ld16_nt(rbase + (t - 1u) * 128u + 16u * s); nl = trc_ld16_nt(rbase + (t - 1u) * 128u + 64u + 16u * s); }
+        const bool act = alive && nrec != 0u && t <= top;
+        const u32 left = act ? nrec - 32u * t : 0u;            // records of this chunk from this block's first one on (>= 32: the whole block)
+        u32 r[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) r[u] = *(const lds_u32 *)(uintptr_t)(tr + 8u * (u32)u);
+#pragma unroll
+        for (int half = 1; half >= 0; half--) {
+            // The reference tests "words so far + 18 >= len -> raw" before EVERY record; the test is monotone in the words, so it
+            // fires somewhere iff it fires before the LAST record (record 0: block 0, lane 3's last step).  Tested here exactly there,
+            // and -- only to stop a hopeless chunk from running out of its region -- before every 16 records with the quad's common
+            // count (also the reference's test, before that half's first record).
+            ovf = ovf || (act && 16u * (u32)half < left && so.wpos + room >= len);
+#pragma unroll
+            for (int uu = 3; uu >= 0; uu--) {
+                const int u = 4 * half + uu;
+                const bool go = 4u * (u32)u < left && !ovf;    // (records exist in fours: the same for the four lanes)
+                const u32 f = r[u] & 0x7fffu, c0 = r[u] >> 15;
+                const bool emit = go && st >= (f << 16);
+                const u32 q4 = (u32)(__ballot(emit) >> sh) & 15u;
+                const u32 pre = (u32)__builtin_popcount(q4 & below), tot = (u32)__builtin_popcount(q4);
+                if (t == 0 && half == 0 && uu == 0)            // before the last record (lane 3's; the others' counts are smaller)
+                    ovf = ovf || (((u32)(__ballot(go && so.wpos + 2u * pre + room >= len) >> sh) & 15u) != 0u);
+                const u32 at = ringw + ((0u - (so.wpos + 2u * pre + 2u)) & (TRC_SRING - 1u));
+                trc_lds_write16(emit ? at : dummy, st);
+                so.wpos += 2u * tot;
+                const u32 s1 = emit ? st >> 16 : st;
+                u32 q = (u32)((float)s1 * __builtin_amdgcn_rcpf((float)f));           // st/f within +-1 (garbage where !go: f may be 0)
+                u32 rm = s1 - __umul24(q, f);
+                const u32 dn = (u32)((int)rm >> 31);                                  // all ones: one too many
+                q += dn; rm += dn & f;
+                const bool up = rm >= f;
+                q += up ? 1u : 0u; rm -= up ? f : 0u;
+                st = go ? (q << TRC_PROB_BITS) + rm + c0 : st;
+            }
+            so.drain(false, alive);                            // <= 32 new bytes (16 records) per chunk
+        }
+        if (t == 0) break;
+    }
+    u32 out_len = 0;
+    if (alive) {
+        if (!ovf) {                                            // mnflush: states 0..3, high half first, each below the one before
+            so.put16_at(true, so.wpos + 4u * s, st >> 16); so.put16_at(true, so.wpos + 4u * s + 2u, st);
+            so.wpos += 16u;
+            if (so.wpos >= len) ovf = true;
+        }
+        out_len = ovf ? len : so.wpos;
+    }
+    so.drain(true, alive && !ovf);
+    if (alive && s == 0u) clen[c] = out_len;
+    const u32 ws = trc_wave_sum(s == 0u ? out_len : 0u);
+    if (lane == 0) wsum[wv] = ws;
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x * 64u < nchunks) gsum[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
 // ------------------------------------------------------------------------------------- decode ---
 template <bool NIB>
 __global__ __launch_bounds__(64 * TRC_WPG) void trc_ansa_dec_kernel(
@@ -446,6 +552,138 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_ansa_dec_kernel(
     trc_wave_copy_raw(__ballot(alive && cl == len && len != 0), off, len, out + (u64)wc.c0 * chunk, chunk, payload);
 }
 
+// ---- ANSA's decoder as two waves per 64 chunks (round 4; the scheme of trc_rca_dec_mc_kernel, trc_rc_adaptive.hip) -------
+// Wave D owns the four rANS states and the stream and READS tables; wave M owns the tables and adapts them.  Per byte:
+//     phase A   D: hi table -> slot search, state update, h -> mailbox      M: the byte before's lo table adapts by its l
+//     phase B   D: lo table (h) -> search, state update, l -> mailbox       M: hi table adapts by h; lo table (h) loaded
+// one LDS-only barrier behind each phase; the four renormalisations of a byte pair (their order is the word order) stay
+// with wave D behind the pair.
+#define ANSA_DMC_MBOX   512u
+#define ANSA_DMC_LDS    (TRC_NIB_BYTES + ANSA_DMC_MBOX)
+__global__ __launch_bounds__(128 * TRC_WPG) void trc_ansa_dec_mc_kernel(
+    const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
+    u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ out)
+{
+    typedef __attribute__((address_space(3))) u32 lds_u32;
+    extern __shared__ __attribute__((aligned(16))) u8 smem_wg_[];
+    const u32 wv_ = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool model = wv_ >= TRC_WPG;
+    const u32 grp_ = blockIdx.x * TRC_WPG + (wv_ & (TRC_WPG - 1u));
+    if (grp_ >= (nchunks + 63u) / 64u) return;                 // (both waves of the pair)
+    u8 *const smem = smem_wg_ + (wv_ & (TRC_WPG - 1u)) * ANSA_DMC_LDS;
+    const u32 lane = trc_lane();
+    NibModel<17> m;
+    if (model) m.init(smem); else m.attach(smem);
+    const u32 mb = trc_lds_addr(smem) + TRC_NIB_BYTES + lane * 4u;     // mailbox: h at +0, l at +256
+
+    WaveChunks wc;
+    wc.c0 = grp_ * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
+    wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
+    wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
+    const bool alive = lane < wc.rows;
+    const u32 c = wc.c0 + lane;
+    const u32 len = alive ? wc.len_of(lane) : 0u;
+    const u32 cl = alive ? trc_min(clen[c], len) : 0u;        // a directory entry above the chunk length (corrupt input) reads as raw
+    const bool coded = alive && cl != len;
+    const u32 S = chunk / TRC_SEG;
+    trc_lds_barrier();                                         // the model's initial tables are in place
+
+    if (model) {
+        NibTable T0 = m.load(m.table(0)), TL = T0;
+        u32 hp = 0;
+        bool have = false;
+        for (u32 s = 0; s < S; s++) {
+#pragma nounroll
+            for (u32 k = 0; k < 4; k++) {
+                const u32 p0 = s * TRC_SEG + k * 16u;
+                if (!__ballot(coded && p0 < len)) continue;
+#pragma nounroll
+                for (u32 b = 0; b < 16u; b++) {
+                    if (have) {                                // phase A: the byte before's lo table
+                        const u32 l = *(const lds_u32 *)(uintptr_t)(mb + 256u);
+                        m.adapt(TL, l & 15u); m.store(m.table(1u + hp), TL);
+                    }
+                    have = true;
+                    trc_lds_barrier();
+                    const u32 h = *(const lds_u32 *)(uintptr_t)mb & 15u;         // phase B
+                    m.adapt(T0, h); m.store(m.table(0), T0);
+                    TL = m.load(m.table(1u + h)); hp = h;
+                    trc_lds_barrier();
+                }
+            }
+        }
+        return;
+    }
+
+    const u32 ex = trc_wave_incl_scan(cl) - cl;
+    const u64 off = trc_group_base(goff, gsum, wc.c0 >> 6) + ex;
+    u32 st[4] = { TRC_ANS_LOW, TRC_ANS_LOW, TRC_ANS_LOW, TRC_ANS_LOW };
+    if (coded) for (u32 k = 0; k < 4u; k++) st[k] = trc_ld32_a2(payload + off + 4u * k);   // decoder st[i] = encoder st[3-i] (mnfill)
+    LaneInWide si; si.prime(payload + off + 16u, coded, trc_sub_sat(cl, 16u));             // words follow the states
+
+    // cdf16ansdec without its model half: search + state update against the table at `tb` as wave M left it
+    auto get = [&](u32 &sx, const u8 *tb, bool act) __attribute__((always_inline)) -> u32 {
+        const u32 slot = sx & (TRC_PROB_ONE - 1);
+        const NibTable T = m.load(tb);
+        u32 c0, c1;
+        const u32 x = trc_nib_find(T, slot, c0, c1);
+        sx = act ? __umul24(c1 - c0, sx >> TRC_PROB_BITS) + slot - c0 : sx;
+        return x;
+    };
+    auto get_byte = [&](u32 &sh, u32 &sl, bool act) __attribute__((always_inline)) -> u32 {
+        const u32 h = get(sh, m.table(0), act);
+        *(lds_u32 *)(uintptr_t)mb = h;
+        trc_lds_barrier();
+        const u32 l = get(sl, m.table(1u + h), act);
+        *(lds_u32 *)(uintptr_t)(mb + 256u) = l;
+        trc_lds_barrier();
+        return h << 4 | l;
+    };
+    auto renorm = [&](u32 &sx, bool act) __attribute__((always_inline)) {
+        const u32 w = si.peek16();
+        const bool rn = act && sx < TRC_ANS_LOW;
+        sx = rn ? (sx << 16) | w : sx;
+        si.skip_if(rn);
+    };
+
+    QuadOut qout; qout.base = out + (u64)wc.c0 * chunk;
+    u8 *dst = out + (u64)c * chunk;
+    for (u32 s = 0; s < S; s++) {
+        uint4 pc0 = make_uint4(0, 0, 0, 0), pc1 = pc0, pc2 = pc0, pc3 = pc0;
+#pragma nounroll
+        for (u32 k = 0; k < 4; k++) {
+            const u32 p0 = s * TRC_SEG + k * 16u;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (__ballot(coded && p0 < len)) {
+#pragma nounroll
+                for (u32 d = 0; d < 4; d++) {
+                    const u32 q0 = p0 + d * 4u;
+                    u32 w = 0;
+#pragma nounroll
+                    for (u32 j = 0; j < 2; j++) {              // mndec8x2: two bytes, then four renorms in order st0..st3
+                        const bool act = coded && q0 + 2u * j < len;          // the second byte of an odd tail is the dummy
+                        const uint4 pre = si.prefetch();       // (<= 8 stream bytes per group: trc_lane_io.h LaneInWide)
+                        const u32 x0 = get_byte(st[0], st[1], act);
+                        const u32 x1 = get_byte(st[2], st[3], act);
+                        renorm(st[0], act); renorm(st[1], act); renorm(st[2], act); renorm(st[3], act);
+                        si.end_step(pre);
+                        w |= (x0 | x1 << 8) << (16u * j);
+                    }
+                    v.x = v.y; v.y = v.z; v.z = v.w; v.w = w;
+                }
+                if (coded && p0 < len && p0 + 16u > len) {      // ragged end of the last chunk: byte stores
+                    const u32 ww[4] = { v.x, v.y, v.z, v.w };
+                    for (u32 pos = p0; pos < len; pos++) dst[pos] = (u8)(ww[(pos - p0) >> 2] >> (8 * ((pos - p0) & 3u)));
+                }
+            }
+            pc0 = pc1; pc1 = pc2; pc2 = pc3; pc3 = v;
+        }
+        qout.put(0, pc0); qout.put(1, pc1); qout.put(2, pc2); qout.put(3, pc3);
+        qout.flush(wc, s * TRC_SEG);
+    }
+    trc_wave_copy_raw(__ballot(alive && cl == len && len != 0), off, len, out + (u64)wc.c0 * chunk, chunk, payload);
+}
+
 // ------------------------------------------------------------------------------------- launch ---
 // TRC_ANSA_MC=0 selects the one-wave model pass of rounds 1-3 (A/B measurements, tests of both forms)
 static bool ansa_mc_enabled()
@@ -460,8 +698,13 @@ static void launch_ansa_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const
         TRC_RAISE_LDS_ONCE(trc_ansa_model2_kernel, TRC_WPG * ANSA_MODEL_LDS(false));
         TRC_RAISE_LDS_ONCE(trc_ansa_code_planar_kernel, TRC_WPG * ANSA_CODE_PLANAR_LDS);
         TRC_LAUNCH_TIMED(trc_ansa_model2_kernel, TRC_QUAD_GRID(w.ngroups), dim3(128 * TRC_WPG), TRC_WPG * ANSA_MODEL_LDS(false), s, d_in, (u64)n, chunk, w.nchunks, w.scratch2);
-        TRC_LAUNCH_TIMED(trc_ansa_code_planar_kernel, TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (ANSA_CODE_PLANAR_LDS), s,
-                           (const u8 *)w.scratch2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
+        static const int codeq = getenv("TRC_ANSA_CODEQ") ? atoi(getenv("TRC_ANSA_CODEQ")) : 1;     // 0: one lane per chunk (rounds 1-3)
+        if (codeq)
+            TRC_LAUNCH_TIMED(trc_ansa_codeq_kernel, dim3(w.ngroups), dim3(256), ANSQ_LDS, s,
+                               (const u8 *)w.scratch2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
+        else
+            TRC_LAUNCH_TIMED(trc_ansa_code_planar_kernel, TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (ANSA_CODE_PLANAR_LDS), s,
+                               (const u8 *)w.scratch2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
         return;
     }
     TRC_RAISE_LDS_ONCE((trc_ansa_model_kernel<NIB>), TRC_WPG * ANSA_MODEL_LDS(NIB));
@@ -469,10 +712,22 @@ static void launch_ansa_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const
     TRC_LAUNCH_TIMED((trc_ansa_code_kernel<NIB>), TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (ANSA_CODE_LDS), s,
                        (const u8 *)w.scratch2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
 }
+// TRC_ANSA_DMC=1 selects the two-wave decoder.  MEASURED AND NOT USED (profiles/r04_notes.md): bit-exact, 0.93 ms against 0.68.
+static bool ansa_dmc_enabled()
+{
+    static const int env = getenv("TRC_ANSA_DMC") ? atoi(getenv("TRC_ANSA_DMC")) : 0;
+    return env != 0;
+}
 template <bool NIB>
 static void launch_ansa_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                             const TrcWork &w, uint8_t *d_out, hipStream_t s)
 {
+    if (!NIB && ansa_dmc_enabled()) {
+        TRC_RAISE_LDS_ONCE(trc_ansa_dec_mc_kernel, TRC_WPG * ANSA_DMC_LDS);
+        TRC_LAUNCH_TIMED(trc_ansa_dec_mc_kernel, TRC_QUAD_GRID(w.ngroups), dim3(128 * TRC_WPG), TRC_WPG * ANSA_DMC_LDS, s,
+                           d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, d_out);
+        return;
+    }
     TRC_RAISE_LDS_ONCE((trc_ansa_dec_kernel<NIB>), TRC_WPG * ANSA_MODEL_LDS(NIB));
     TRC_LAUNCH_TIMED((trc_ansa_dec_kernel<NIB>), TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (ANSA_MODEL_LDS(NIB)), s,
                        d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, d_out);

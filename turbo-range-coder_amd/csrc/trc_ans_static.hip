@@ -334,6 +334,7 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
     const u8 *__restrict__ lut_g, const u32 *__restrict__ dtab_g, u8 *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    if (trc_lds_addr(smem) != 0u) __builtin_trap();            // the decoders address LUT / dtab / rings by ABSOLUTE LDS offsets (DEC_LDS_*): a static __shared__ object in front of the dynamic segment must fail loudly, not decode from the wrong tables
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, BLOCK = blockDim.x;
     u8 *wbase = smem + DEC_LDS_WAVES + wv * DEC_WAVE_LDS;
     WaveChunks wc;
@@ -479,6 +480,7 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec2_kernel(
     const u8 *__restrict__ lut_g, const u32 *__restrict__ dtab_g, u8 *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    if (trc_lds_addr(smem) != 0u) __builtin_trap();            // the decoders address LUT / dtab / rings by ABSOLUTE LDS offsets (DEC_LDS_*): a static __shared__ object in front of the dynamic segment must fail loudly, not decode from the wrong tables
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, BLOCK = blockDim.x;
     u8 *wbase = smem + DEC_LDS_WAVES + wv * DEC_WAVE_LDS;
     {

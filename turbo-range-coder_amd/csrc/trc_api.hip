@@ -172,6 +172,7 @@ static int carve(int codec, size_t n, uint32_t chunk, void *d_work, size_t work_
     w.tables = p;               p += up256(TRC_TAB_BYTES);
     w.gsum = (uint32_t *)p;     p += up256(4 * ngroups);
     static const uint32_t scan_max = getenv("TRC_SCAN_MAX") ? (uint32_t)atoi(getenv("TRC_SCAN_MAX")) : TRC_INKERNEL_SCAN_MAX;   // tuning aid
+    w.goff_area = (uint64_t *)p;
     w.goff = ngroups > scan_max ? (uint64_t *)p : nullptr;     p += up256(8 * (ngroups + 1));
     w.scratch = p;
     w.stride = scratch_stride(codec, chunk);
@@ -377,7 +378,7 @@ extern "C" int trc_decode_dev(int codec, const uint32_t *d_clen, const void *d_p
     if (!dir_ready) {
         trc_launch_group_sums(d_clen, w.nchunks, n, chunk, w.gsum, s);
         if (w.goff) trc_launch_scan_groups(w.gsum, w.ngroups, w.goff, nullptr, s);
-    }
+    } else w.goff = w.goff_area;                               // the encode's gather left the group bases there (trc_launch.h)
     tm_begin(1);
     switch (codec) {
     case TRC_ANS4S: trc_launch_ans4s_dec((const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
@@ -640,6 +641,9 @@ size_t slice_plan(int codec, uint32_t chunk, size_t nchunks, std::vector<size_t>
     const size_t target = forced ? forced : (size_t)16 << 20;
     size_t groups = forced || is_static(codec) ? target / ((size_t)chunk * 64) : TRC_MODEL_ROUND_CHUNKS / 64;
     if (!forced && groups * 64 * (size_t)chunk > ((size_t)256 << 20)) groups = ((size_t)256 << 20) / ((size_t)chunk * 64);   // caller-fixed chunks above 4096: the staging slots stay <= 256 MB
+    // the order-1 coder keeps 136 KiB of model per chunk of a slice in the workspace: a 65 536-chunk slice would ask for 9 GB of it
+    // (ADVICE r3); 4 GiB of models = 30 000 chunks = 123 MB slices at chunk 4096, still one launch for the inputs it is used on
+    if (codec == TRC_ANSO1 && !forced && groups > ((size_t)4 << 30) / (64u * (size_t)TRC_O1_MODEL_BYTES)) groups = ((size_t)4 << 30) / (64u * (size_t)TRC_O1_MODEL_BYTES);
     if (groups < 1) groups = 1;
     size_t per = groups * 64;
     while ((nchunks + per - 1) / per > 2000) per *= 2;                    // the totals area holds 2048 slices
@@ -939,8 +943,11 @@ extern "C" size_t trc_decode_host(int codec, const void *in, size_t inlen, void 
     if (!codec_ok(codec)) { fail(TRC_E_ARG, "codec %d not available", codec); return 0; }
     if (!in || !out) { fail(TRC_E_ARG, "decode_host: bad arguments"); return 0; }
     if (outlen == 0) return 0;
-    if (inlen == outlen) { memcpy(out, in, outlen); return outlen; }        // stored raw (the reference's convention)
-    if (trc_container_check(in, inlen, codec, outlen)) return 0;
+    // inlen == outlen is the reference's "stored raw" convention -- but trc_encode_host with a stated capacity returns the
+    // container whatever its size, so a container of exactly outlen bytes is possible (nearly incompressible input): what
+    // validates as a container of this coder and this length is decoded, anything else of that size is the raw copy.
+    if (inlen == outlen && trc_container_check(in, inlen, codec, outlen)) { memcpy(out, in, outlen); return outlen; }
+    if (inlen != outlen && trc_container_check(in, inlen, codec, outlen)) return 0;
     return host_decode(codec, (const unsigned char *)in, outlen, (unsigned char *)out, (const cdf_t *)cdf, (int)cdfnum);
 }
 

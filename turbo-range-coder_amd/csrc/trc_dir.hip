@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void trc_gather_kernel(const u8 *__restrict__ 
                                                          const u8 *__restrict__ scratch2, u32 stride2, const u32 *__restrict__ aux,
                                                          const u32 *__restrict__ clen, const u64 *__restrict__ goff,
                                                          const u32 *__restrict__ gsum, u32 ngroups,
-                                                         u8 *__restrict__ payload, u64 *__restrict__ total)
+                                                         u8 *__restrict__ payload, u64 *__restrict__ total, u64 *__restrict__ goff_out)
 {
     constexpr u32 NP = 64u * PARTS;                            // pieces per group
     constexpr u32 TPP = 256u / NP;                             // threads per piece (4 or 2)
@@ -115,7 +115,10 @@ __global__ __launch_bounds__(256) void trc_gather_kernel(const u8 *__restrict__ 
     __shared__ u64 src_s[NP];                                  // where piece p's bytes are
     __shared__ u64 base_s;
     const u32 g = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
-    if (wid == 1 || blockDim.x == 64) { const u64 b = trc_group_base(goff, gsum, g); if (lane == 0) base_s = b; }   // one wave sums, the next builds the table
+    if (wid == 1 || blockDim.x == 64) {                        // one wave sums, the next builds the table
+        const u64 b = trc_group_base(goff, gsum, g);
+        if (lane == 0) { base_s = b; if (goff_out) goff_out[g] = b; }      // (kept for a decode of this directory: TrcWork::goff_area)
+    }
     if (wid == 0) {
         const u32 c = g * 64 + lane;
         const u32 l = c < nchunks ? clen[c] : 0u;
@@ -217,11 +220,11 @@ void trc_launch_gather(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcW
     if (from_end >= 2)                                         // two pieces per chunk: mode 2 (two regions) or 3 (both ends of one region)
         hipLaunchKernelGGL(trc_gather_kernel<2>, dim3(w.ngroups), dim3(256), 0, s, d_in, (u64)n, chunk, w.nchunks,
                            w.scratch, w.stride, from_end >= 3 ? from_end : 0, w.scratch2, w.stride2, w.aux, d_clen, w.goff, w.gsum, w.ngroups,
-                           d_payload, w.goff ? (u64 *)nullptr : d_total);
+                           d_payload, w.goff ? (u64 *)nullptr : d_total, w.goff ? (u64 *)nullptr : w.goff_area);
     else
         hipLaunchKernelGGL(trc_gather_kernel<1>, dim3(w.ngroups), dim3(256), 0, s, d_in, (u64)n, chunk, w.nchunks,
                            w.scratch, w.stride, from_end, w.scratch2, w.stride2, w.aux, d_clen, w.goff, w.gsum, w.ngroups,
-                           d_payload, w.goff ? (u64 *)nullptr : d_total);
+                           d_payload, w.goff ? (u64 *)nullptr : d_total, w.goff ? (u64 *)nullptr : w.goff_area);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -291,7 +294,10 @@ __global__ __launch_bounds__(256) void trc_hist_kernel(const u8 *__restrict__ in
         atomicAdd((unsigned long long *)&tot[2 * (lane + 64) + 1], (unsigned long long)hi1);
     }
     __syncthreads();
-    if (tot[tid]) atomicAdd((unsigned long long *)&hist[tid], (unsigned long long)tot[tid]);
+    // 256 workgroups finish together and each adds up to 256 bins: rotated by the workgroup, so that at any moment they are at
+    // different bins (all starting at bin 0 serialises them on one L2 atomic after the other)
+    const u32 bin = (tid + 37u * blockIdx.x) & 255u;
+    if (tot[bin]) atomicAdd((unsigned long long *)&hist[bin], (unsigned long long)tot[bin]);
 }
 __global__ __launch_bounds__(256) void trc_cdf_build_kernel(const u64 *__restrict__ hist, u64 n, u32 cdfnum,
                                                             u16 *__restrict__ cdf, int *__restrict__ status)

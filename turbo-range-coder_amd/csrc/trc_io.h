@@ -35,10 +35,9 @@
 //     decode 124 vs 113 us, encode 101 vs 99 us in favour of the linear form -- the ring is not where the
 //     LDS conflict cycles come from (the random table reads are).
 #ifdef TRC_RING_INTERLEAVED
-__device__ __forceinline__ u32 trc_raddr(u32 lane, u32 off) { return (((off & 0x7cu) << 6) | (off & 3u)) + (lane << 2); }
-#else
-__device__ __forceinline__ u32 trc_raddr(u32 lane, u32 off) { return lane * TRC_SRING_STRIDE + off; }
+#error "TRC_RING_INTERLEAVED is gone: StreamInT<true> is the interleaved ring (static rANS decoder); StreamOut / StreamInT<false> assume the lane-major rows"
 #endif
+__device__ __forceinline__ u32 trc_raddr(u32 lane, u32 off) { return lane * TRC_SRING_STRIDE + off; }
 
 __device__ __forceinline__ u32 trc_mbcnt(u64 mask)   // number of set bits of mask below this lane
 {
@@ -256,7 +255,10 @@ struct QuadOut {
 // DOWN = false: upward from the START of the region (range coders)
 // PAIR = true (round 3, the two-stream range coder with one LANE PER STREAM): lanes 2i and 2i + 1 work on chunk c0 + i;
 // the even lane's stream goes to the chunk's region in `scratch`, the odd lane's to its region in `scratch_b`.
-template <bool DOWN, bool PAIR = false>
+// QUAD = true (round 4, the four-lanes-per-chunk rANS coding pass): lanes 4i .. 4i + 3 work on chunk c0 + i and share ONE ring
+// (row i) and one stream; wpos / nfl are kept equal across the quad by the caller, every lane writes its own units at
+// positions it computes itself (put16_at), the quad's first lane is the one that drains.
+template <bool DOWN, bool PAIR = false, bool QUAD = false>
 struct StreamOut {
     u8 *rings;           // this wave's ring array (LDS)
     u8 *scratch;         // global scratch, region of chunk c is [c*stride, (c+1)*stride)
@@ -264,7 +266,13 @@ struct StreamOut {
     u32 c0;
     u8 *scratch_b;       // PAIR only: the second stream's regions
     u32 stride_b;
-    __device__ __forceinline__ u32 my_row() const { return PAIR ? trc_lane() >> 1 : trc_lane(); }
+    __device__ __forceinline__ u32 my_row() const { return PAIR ? trc_lane() >> 1 : QUAD ? trc_lane() >> 2 : trc_lane(); }
+    __device__ __forceinline__ u32 ring_row() const { return QUAD ? trc_lane() >> 2 : trc_lane(); }
+    // (QUAD) a 16-bit unit at stream position p of the shared stream, where `take`; nothing moves
+    __device__ __forceinline__ void put16_at(bool take, u32 p, u32 v)
+    {
+        if (take) *(u16 *)(rings + trc_raddr(ring_row(), roff16(p))) = (u16)v;
+    }
     __device__ __forceinline__ u32 my_stride() const { return (PAIR && (trc_lane() & 1u)) ? stride_b : stride; }
     __device__ __forceinline__ u8 *my_region() const
     {
@@ -324,14 +332,14 @@ struct StreamOut {
     {
         const u32 lane = trc_lane();
         const u32 rw = trc_lds_addr(rings);
-        bool ready = alive && (final ? pending() > 0 : pending() >= TRC_SEG);
+        bool ready = alive && (final ? pending() > 0 : pending() >= TRC_SEG) && (!QUAD || (lane & 3u) == 0u);
         u64 mask = __ballot(ready);
         while (mask) {
             const u32 rank = trc_mbcnt(mask);
             const bool pick = ready && rank < 16u;
             const u32 cnt = (u32)__popcll(mask);
             const u32 ro = DOWN ? ((0u - TRC_SEG * (nfl + 1u)) & (TRC_SRING - 1)) : ((TRC_SEG * nfl) & (TRC_SRING - 1));
-            const u32 from = rw + trc_raddr(lane, ro);
+            const u32 from = rw + trc_raddr(ring_row(), ro);
             // place in the scratch array relative to the wave's first region (63 regions of at most 64 KiB + slack: 32 bits; offsets
             // are multiples of 64, so bit 0 can name the array: PAIR, odd lane = second stream)
             const u32 to = (my_row() * my_stride() + (DOWN ? my_stride() - TRC_SEG * (nfl + 1u) : TRC_SEG * nfl)) | (PAIR ? lane & 1u : 0u);
@@ -351,6 +359,7 @@ struct StreamOut {
             if (pick) { nfl++; ready = final ? (wpos > TRC_SEG * nfl) : pending() >= TRC_SEG; }
             mask = __ballot(ready);
         }
+        if (QUAD) nfl = (u32)__builtin_amdgcn_update_dpp(0, (int)nfl, 0x00, 0xf, 0xf, false);       // the quad follows its first lane
     }
 };
 

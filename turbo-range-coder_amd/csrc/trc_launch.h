@@ -33,6 +33,9 @@ struct TrcWork {
     uint8_t  *tables;    // per-call coder tables derived from the CDF (static coders)
     uint32_t *gsum;      // per-group (64 chunks) payload bytes
     uint64_t *goff;      // exclusive prefix of gsum (ngroups+1 entries) when the scan kernel runs; NULL = kernels sum gsum themselves
+    uint64_t *goff_area; // where that prefix lives in the workspace, always.  Round 4: the gather of an encode leaves every group's base
+                         // there (it has just computed it), and a decode of that very directory (TRC_DIR_READY) reads it instead of
+                         // having each of its waves add up the group sums below its own
     uint8_t  *scratch;   // encode only: per-chunk private output regions
     uint32_t  stride;    // bytes per scratch region
     uint8_t  *scratch2;  // second region array (RCS2: stream 1)

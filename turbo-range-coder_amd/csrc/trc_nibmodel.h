@@ -63,6 +63,8 @@ struct NibModel {
             for (u32 k = 0; k < 8; k++) ((u32 *)(row + t * 32u))[k] = trc_pk((2 * k) << 11, (2 * k + 1) << 11);
         trc_wave_lds_fence();                     // the K writes of this wave before its lanes' reads (the model belongs to ONE wave)
     }
+    // a wave that only READS the rows another wave of its workgroup initialises and adapts (the two-wave decoders)
+    __device__ __forceinline__ void attach(u8 *smem) { kb = smem; row = smem + TRC_NIBK_BYTES + trc_lane() * ROW; }
     // the same for a wave that owns only tables [first, first + count) of the rows (the two-wave model pass: a hi wave and a lo
     // wave share the rows; each initialises its own tables, both write the same K)
     __device__ __forceinline__ void init_part(u8 *smem, u32 first, u32 count)

@@ -400,6 +400,159 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_rca_dec_kernel(
     trc_wave_copy_raw(__ballot(alive && cl == len && len != 0), off, len, out + (u64)wc.c0 * chunk, chunk, payload);
 }
 
+// ---- the byte coders' DECODER as two waves per 64 chunks (round 4) -------------------------------------------------
+// A decoder cannot run ahead of its model: the symbol comes out of the table, the table moves with the symbol.  But the
+// two halves of that loop are different work -- search + range update on one side (needs the table as it IS), the 24
+// packed operations of cdf16upd on the other (needs the symbol) -- and the hi and lo tables of a byte alternate: while
+// the lo nibble is searched, the hi table can adapt, and the other way round.  Wave D (decode) owns the range coder and
+// the stream and READS tables from the LDS rows; wave M (model) owns the tables and adapts them:
+//     phase A   D: load hi table, search, range update, h -> mailbox     M: lo table of the byte before adapts by its l
+//     ---- s_barrier ----
+//     phase B   D: load lo table (h), search, range update, l -> mailbox M: hi table adapts by h; lo table (h) loaded
+//     ---- s_barrier ----
+// Two LDS-only barriers per byte; D's path per byte is two searches and two range updates (~110 instructions instead of
+// ~200), M's 64 run in its issue gaps on the same SIMD (workgroup = 4 D waves + 4 M waves: pair k on SIMD k).
+#define RCA_DMC_MBOX   512u                                    // h and l, one dword per lane each
+#define RCA_DMC_LDS    (TRC_NIB_BYTES + RCA_DMC_MBOX)
+template <int NS>
+__global__ __launch_bounds__(128 * TRC_WPG) void trc_rca_dec_mc_kernel(
+    const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
+    u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem_wg_[];
+    const u32 wv_ = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool model = wv_ >= TRC_WPG;
+    const u32 grp_ = blockIdx.x * TRC_WPG + (wv_ & (TRC_WPG - 1u));
+    if (grp_ >= (nchunks + 63u) / 64u) return;                 // (both waves of the pair)
+    u8 *const smem = smem_wg_ + (wv_ & (TRC_WPG - 1u)) * RCA_DMC_LDS;
+    const u32 lane = trc_lane();
+    NibModel<17> m;
+    if (model) m.init(smem); else m.attach(smem);
+    const u32 mb = trc_lds_addr(smem) + TRC_NIB_BYTES + lane * 4u;     // mailbox: h at +0, l at +256
+
+    WaveChunks wc;
+    wc.c0 = grp_ * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
+    wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
+    wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
+    const bool alive = lane < wc.rows;
+    const u32 c = wc.c0 + lane;
+    const u32 len = alive ? wc.len_of(lane) : 0u;
+    const u32 cl = alive ? trc_min(clen[c], len) : 0u;        // a directory entry above the chunk length (corrupt input) reads as raw
+    const bool coded = alive && cl != len;
+    const u32 S = chunk / TRC_SEG;
+    trc_lds_barrier();                                         // the model's initial tables are in place
+
+    if (model) {
+        // ---- wave M: the same walk (same trip counts: the barriers pair up), adapting what wave D has just decoded
+        NibTable T0 = m.load(m.table(0)), TL = T0;
+        u32 hp = 0;                                            // the lo table TL holds: 1 + hp (nothing to write back before the first byte)
+        bool have = false;
+        for (u32 s = 0; s < S; s++) {
+#pragma nounroll
+            for (u32 k = 0; k < 4; k++) {
+                const u32 p0 = s * TRC_SEG + k * 16u;
+                if (!__ballot(coded && p0 < len)) continue;
+#pragma nounroll
+                for (u32 b = 0; b < 16u; b++) {
+                    if (have) {                                // phase A: the byte before's lo table
+                        const u32 l = *(const __attribute__((address_space(3))) u32 *)(uintptr_t)(mb + 256u);
+                        m.adapt(TL, l & 15u); m.store(m.table(1u + hp), TL);
+                    }
+                    have = true;
+                    trc_lds_barrier();
+                    const u32 h = *(const __attribute__((address_space(3))) u32 *)(uintptr_t)mb & 15u;   // phase B
+                    m.adapt(T0, h); m.store(m.table(0), T0);
+                    TL = m.load(m.table(1u + h)); hp = h;
+                    trc_lds_barrier();
+                }
+            }
+        }
+        return;
+    }
+
+    // ---- wave D
+    const u32 ex = trc_wave_incl_scan(cl) - cl;
+    const u64 off = trc_group_base(goff, gsum, wc.c0 >> 6) + ex;
+    LaneIn<4> s0, s1;
+    const u32 len0 = (NS == 2 && coded) ? trc_min(trc_ld32_a2(payload + off), trc_sub_sat(cl, 4u)) : 0u;   // a corrupt header cannot point outside the chunk's payload
+    s0.prime(payload + off + (NS == 2 ? 4u : 0u), coded, NS == 2 ? len0 : cl);
+    s1.prime(payload + off + 4u + len0, NS == 2 && coded, trc_sub_sat(cl, 4u + len0));
+    RcDec d0, d1;
+    { const u32 a = s0.peek32(); s0.skip_if(coded); const u32 b = s0.peek32(); s0.skip_if(coded); d0.start(a, b); }
+    { const u32 a = s1.peek32(); s1.skip_if(NS == 2 && coded); const u32 b = s1.peek32(); s1.skip_if(NS == 2 && coded); d1.start(a, b); }
+
+    // a symbol against the table at `tb` as the model wave left it; bit 4 of the result says "renormalised"
+    auto get = [&](RcDec &dq, u32 w, const u8 *tb, bool act) __attribute__((always_inline)) -> u32 {
+        const NibTable T = m.load(tb);
+        u32 c0, c1;
+        const u32 x = trc_nib_search(T, dq.scaled(), c0, c1);
+        const bool rn = dq.consume_w(act, c0, c1, w);
+        return x | (rn ? 16u : 0u);
+    };
+    // one byte: phase A (hi), barrier, phase B (lo), barrier
+    auto get_byte = [&](RcDec &dh, RcDec &dl, u32 wh, u32 wl, bool act, u32 &rnh, u32 &rnl) __attribute__((always_inline)) -> u32 {
+        const u32 h = get(dh, wh, m.table(0), act);
+        *(__attribute__((address_space(3))) u32 *)(uintptr_t)mb = h;
+        trc_lds_barrier();
+        const u32 l = get(dl, wl, m.table(1u + (h & 15u)), act);
+        *(__attribute__((address_space(3))) u32 *)(uintptr_t)(mb + 256u) = l;
+        trc_lds_barrier();
+        rnh = h & 16u; rnl = l & 16u;
+        return (h & 15u) << 4 | (l & 15u);
+    };
+
+    QuadOut qout; qout.base = out + (u64)wc.c0 * chunk;
+    u8 *dst = out + (u64)c * chunk;
+    for (u32 s = 0; s < S; s++) {
+        uint4 pc0 = make_uint4(0, 0, 0, 0), pc1 = pc0, pc2 = pc0, pc3 = pc0;
+#pragma nounroll
+        for (u32 k = 0; k < 4; k++) {
+            const u32 p0 = s * TRC_SEG + k * 16u;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (__ballot(coded && p0 < len)) {
+#pragma nounroll
+                for (u32 d = 0; d < 4; d++) {
+                    const u32 q0 = p0 + d * 4u;
+                    u32 w = 0;
+                    if (NS == 1) {
+#pragma nounroll
+                        for (u32 i = 0; i < 4; i++) {          // both symbols of a byte share one look-ahead word (at most one renormalises)
+                            const bool act = coded && q0 + i < len;
+                            const uint4 pre = s0.prefetch();
+                            const u32 sw = s0.peek32();
+                            u32 rh, rl;
+                            const u32 x = get_byte(d0, d0, sw, sw, act, rh, rl);
+                            s0.advance_pre((rh | rl) >> 2, pre);
+                            w |= x << (8u * i);
+                        }
+                    } else {
+#pragma nounroll
+                        for (u32 pr = 0; pr < 2; pr++) {       // a stream advances once per PAIR of its symbols
+                            const bool acta = coded && q0 + 2u * pr < len, actb = coded && q0 + 2u * pr + 1u < len;
+                            const uint4 pre0 = s0.prefetch(), pre1 = s1.prefetch();
+                            const u32 w0 = s0.peek32(), w1 = s1.peek32();
+                            u32 rha, rla, rhb, rlb;
+                            const u32 xa = get_byte(d0, d1, w0, w1, acta, rha, rla);
+                            const u32 xb = get_byte(d0, d1, w0, w1, actb, rhb, rlb);
+                            s0.advance_pre((rha | rhb) >> 2, pre0); s1.advance_pre((rla | rlb) >> 2, pre1);
+                            w |= (xa | xb << 8) << (16u * pr);
+                        }
+                    }
+                    v.x = v.y; v.y = v.z; v.z = v.w; v.w = w;
+                }
+                if (coded && p0 < len && p0 + 16u > len) {      // ragged end of the last chunk: byte stores
+                    const u32 ww[4] = { v.x, v.y, v.z, v.w };
+                    for (u32 pos = p0; pos < len; pos++) dst[pos] = (u8)(ww[(pos - p0) >> 2] >> (8 * ((pos - p0) & 3u)));
+                }
+            }
+            pc0 = pc1; pc1 = pc2; pc2 = pc3; pc3 = v;
+        }
+        qout.put(0, pc0); qout.put(1, pc1); qout.put(2, pc2); qout.put(3, pc3);
+        qout.flush(wc, s * TRC_SEG);
+    }
+    trc_wave_copy_raw(__ballot(alive && cl == len && len != 0), off, len, out + (u64)wc.c0 * chunk, chunk, payload);
+}
+
 template <int NS, bool NIB>
 static void launch_rca_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
 {
@@ -437,9 +590,29 @@ void trc_launch_rca_enc(int nstreams, int nibble, const uint8_t *d_in, size_t n,
     if (nibble) { if (nstreams == 2) launch_rca_enc<2, true>(d_in, n, chunk, w, d_clen, s); else launch_rca_enc<1, true>(d_in, n, chunk, w, d_clen, s); }
     else        { if (nstreams == 2) launch_rca_enc<2, false>(d_in, n, chunk, w, d_clen, s); else launch_rca_enc<1, false>(d_in, n, chunk, w, d_clen, s); }
 }
+template <int NS>
+static void launch_rca_dec_mc(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
+                              const TrcWork &w, uint8_t *d_out, hipStream_t s)
+{
+    TRC_RAISE_LDS_ONCE(trc_rca_dec_mc_kernel<NS>, TRC_WPG * RCA_DMC_LDS);
+    TRC_LAUNCH_TIMED((trc_rca_dec_mc_kernel<NS>), TRC_QUAD_GRID(w.ngroups), dim3(128 * TRC_WPG), TRC_WPG * RCA_DMC_LDS, s,
+                       d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, d_out);
+}
+// TRC_RCA_DMC=1 selects the two-wave decoder.  MEASURED AND NOT USED (profiles/r04_notes.md): bit-exact, and 1.5x SLOWER than the
+// one-wave decoder (rccdf 100 MB: 1.04 ms against 0.68) -- two barriers and two dependent table loads per byte leave wave D
+// waiting longer than the 24 packed operations it hands over took.
+static bool rca_dmc_enabled()
+{
+    static const int env = getenv("TRC_RCA_DMC") ? atoi(getenv("TRC_RCA_DMC")) : 0;
+    return env != 0;
+}
 void trc_launch_rca_dec(int nstreams, int nibble, const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                         const TrcWork &w, uint8_t *d_out, hipStream_t s)
 {
+    if (!nibble && rca_dmc_enabled()) {
+        if (nstreams == 2) launch_rca_dec_mc<2>(d_payload, d_clen, n, chunk, w, d_out, s); else launch_rca_dec_mc<1>(d_payload, d_clen, n, chunk, w, d_out, s);
+        return;
+    }
     if (nibble) { if (nstreams == 2) launch_rca_dec<2, true>(d_payload, d_clen, n, chunk, w, d_out, s); else launch_rca_dec<1, true>(d_payload, d_clen, n, chunk, w, d_out, s); }
     else        { if (nstreams == 2) launch_rca_dec<2, false>(d_payload, d_clen, n, chunk, w, d_out, s); else launch_rca_dec<1, false>(d_payload, d_clen, n, chunk, w, d_out, s); }
 }

@@ -19,6 +19,7 @@ import numpy as np
 
 HDR = 32
 MAGIC = 0x31435254
+_COUNTS = {}                                                    # exchange_group: device tensors of the chunk counts of a group
 
 
 def shard_bounds(n, world, chunk):
@@ -106,8 +107,14 @@ def exchange_group(dist, rank, world, totals, clens, payloads, recv_clen=None, r
     import torch
     ns = len(totals)
     dev = totals[0].device
-    meta = torch.stack([t.reshape(()).to(torch.int64) for t in totals] +
-                       [torch.tensor(c.numel(), dtype=torch.int64, device=dev) for c in clens])
+    # the chunk counts are host numbers: one cached device tensor per shape of group (round 4 -- eight torch.tensor(n, device=...)
+    # per group were eight blocking host-to-device copies on the side stream, each waiting for the group's last encode with the
+    # HOST: 36 us per step of idle GPU at groups of 8 on one rank, profiles/r04_notes.md)
+    key = (str(dev), tuple(int(c.numel()) for c in clens))
+    counts = _COUNTS.get(key)
+    if counts is None:
+        counts = _COUNTS[key] = torch.tensor(key[1], dtype=torch.int64).to(dev)
+    meta = torch.cat([torch.cat([t.reshape(1).to(torch.int64) for t in totals]), counts])
     allmeta = torch.empty(2 * ns * world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(allmeta, meta)
     m = allmeta.tolist()
