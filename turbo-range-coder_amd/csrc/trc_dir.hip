@@ -1,5 +1,6 @@
 // trc_dir.hip -- everything around the coders: CDF-derived tables, the chunk directory
 // (per-group sums -> exclusive scan), the payload gather, and cdfini (histogram -> CDF) on device.
+#include <stdlib.h>
 #include "trc_dev.h"
 #include "trc_launch.h"
 
@@ -299,6 +300,74 @@ __global__ __launch_bounds__(256) void trc_hist_kernel(const u8 *__restrict__ in
     const u32 bin = (tid + 37u * blockIdx.x) & 255u;
     if (tot[bin]) atomicAdd((unsigned long long *)&hist[bin], (unsigned long long)tot[bin]);
 }
+// Round 4 form: SIXTEEN waves per CU instead of four.  The per-lane columns above are conflict-free but cost 32 KiB per wave: one
+// wave per SIMD, whose ~8 500 instructions and every exposed load are the kernel's time (49 us per 100 MB).  Here a wave keeps
+// 16 copies of the packed histogram (128 rows x 16 dwords = 8 KiB; lanes l, l + 16, l + 32, l + 48 share copy l & 15): a
+// ds_add_u32 of random bytes meets ~2.5-way bank conflicts and the occasional same-counter pair, but four waves per SIMD hide
+// both that and the loads.  A copy counts at most 4 x 1023 x 16 = 65 472 bytes between two reductions (no 16-bit overflow).
+#define TRC_HIST2_WAVE_LDS (128u * 16u * 4u)
+#define TRC_HIST2_WAVES 16u
+#define TRC_HIST2_ROUND_VECS 1023u
+__global__ __launch_bounds__(1024) void trc_hist2_kernel(const u8 *__restrict__ in, u64 n, u64 *__restrict__ hist)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    typedef __attribute__((address_space(3))) u32 lds_u32;
+    const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    u32 *mine = (u32 *)(smem + wv * TRC_HIST2_WAVE_LDS);           // [128 rows][16 copies]
+    u64 *tot = (u64 *)(smem + TRC_HIST2_WAVES * TRC_HIST2_WAVE_LDS);   // [256] per workgroup
+    const u32 col = trc_lds_addr(mine) + (lane & 15u) * 4u;
+    if (tid < 256u) tot[tid] = 0;
+    const u64 nvec = n >> 4, stride = (u64)gridDim.x * 1024;
+    const uint4 *v = (const uint4 *)in;
+    auto count = [&](u32 w) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 a = (__builtin_amdgcn_ubfe(w, 8 * k + 1, 7) << 6) + col;
+            const u32 inc = __umul24(__builtin_amdgcn_ubfe(w, 8 * k, 1), 0xffffu) + 1u;
+            __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)a, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+    };
+    auto count4 = [&](const uint4 q) __attribute__((always_inline)) { count(q.x); count(q.y); count(q.z); count(q.w); };
+    for (u64 r0 = 0; r0 == 0 || r0 < nvec; r0 += stride * TRC_HIST2_ROUND_VECS) {
+        for (u32 r = lane; r < 128u * 16u; r += 64u) mine[r] = 0;
+        u64 i = r0 + (u64)blockIdx.x * 1024 + tid;
+        u32 left = TRC_HIST2_ROUND_VECS;
+        if (left >= 2u && i + stride < nvec) {                     // two vectors in flight per lane, the next two requested before these are counted
+            uint4 q0 = v[i], q1 = v[i + stride];
+            left -= 2u; i += 2 * stride;
+            for (; left >= 2u && i + stride < nvec; left -= 2u, i += 2 * stride) {
+                const uint4 n0 = v[i], n1 = v[i + stride];
+                count4(q0); count4(q1);
+                q0 = n0; q1 = n1;
+            }
+            count4(q0); count4(q1);
+        }
+        for (; left && i < nvec; left--, i += stride) count4(v[i]);
+        if (r0 == 0 && blockIdx.x == 0 && wv == 0)                  // the input's last n % 16 bytes, once
+            for (u64 t = (nvec << 4) + lane; t < n; t += 64) {
+                const u32 b = in[t];
+                __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)(col + (b >> 1) * 64u), (b & 1u) ? 0x10000u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        // reduce this wave's copies: lane l sums rows l and l + 64 over the 16 copies
+        u32 lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
+#pragma unroll
+        for (u32 c4 = 0; c4 < 4u; c4++) {
+            const uint4 a = *(const uint4 *)(mine + lane * 16u + c4 * 4u), b = *(const uint4 *)(mine + (lane + 64u) * 16u + c4 * 4u);
+            lo0 += (a.x & 0xffffu) + (a.y & 0xffffu) + (a.z & 0xffffu) + (a.w & 0xffffu); hi0 += (a.x >> 16) + (a.y >> 16) + (a.z >> 16) + (a.w >> 16);
+            lo1 += (b.x & 0xffffu) + (b.y & 0xffffu) + (b.z & 0xffffu) + (b.w & 0xffffu); hi1 += (b.x >> 16) + (b.y >> 16) + (b.z >> 16) + (b.w >> 16);
+        }
+        __syncthreads();                                            // (first round: orders the zeroing of tot[])
+        atomicAdd((unsigned long long *)&tot[2 * lane], (unsigned long long)lo0);
+        atomicAdd((unsigned long long *)&tot[2 * lane + 1], (unsigned long long)hi0);
+        atomicAdd((unsigned long long *)&tot[2 * (lane + 64)], (unsigned long long)lo1);
+        atomicAdd((unsigned long long *)&tot[2 * (lane + 64) + 1], (unsigned long long)hi1);
+    }
+    __syncthreads();
+    if (tid < 256u) {
+        const u32 bin = (tid + 37u * blockIdx.x) & 255u;
+        if (tot[bin]) atomicAdd((unsigned long long *)&hist[bin], (unsigned long long)tot[bin]);
+    }
+}
 __global__ __launch_bounds__(256) void trc_cdf_build_kernel(const u64 *__restrict__ hist, u64 n, u32 cdfnum,
                                                             u16 *__restrict__ cdf, int *__restrict__ status)
 {
@@ -331,6 +400,15 @@ void trc_launch_hist(const uint8_t *d_in, size_t n, uint64_t *d_hist, hipStream_
     u64 blocks = ((n >> 4) + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 256) blocks = 256;                             // one workgroup (4 x 32 KiB of counters) per CU
+    static const int form = getenv("TRC_HIST_FORM") ? atoi(getenv("TRC_HIST_FORM")) : 2;        // 1: the per-lane columns of round 3
+    if (form == 2) {
+        const size_t sm2 = TRC_HIST2_WAVES * TRC_HIST2_WAVE_LDS + 256u * sizeof(u64);
+        u64 b2 = ((n >> 4) + 1023) / 1024;
+        b2 = b2 < 1 ? 1 : b2 > 256 ? 256 : b2;                  // one workgroup of 16 waves per CU
+        TRC_RAISE_LDS_ONCE(trc_hist2_kernel, sm2);
+        hipLaunchKernelGGL(trc_hist2_kernel, dim3((u32)b2), dim3(1024), sm2, s, d_in, (u64)n, d_hist);
+        return;
+    }
     const size_t sm = 4u * TRC_HIST_WAVE_LDS + 256u * sizeof(u64);
     TRC_RAISE_LDS_ONCE(trc_hist_kernel, sm);                    // per DEVICE (a process-wide flag left a second GPU at the 64 KiB default)
     hipLaunchKernelGGL(trc_hist_kernel, dim3((u32)blocks), dim3(256), sm, s, d_in, (u64)n, d_hist);
