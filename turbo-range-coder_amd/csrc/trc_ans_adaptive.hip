@@ -698,13 +698,7 @@ static void launch_ansa_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const
         TRC_RAISE_LDS_ONCE(trc_ansa_model2_kernel, TRC_WPG * ANSA_MODEL_LDS(false));
         TRC_RAISE_LDS_ONCE(trc_ansa_code_planar_kernel, TRC_WPG * ANSA_CODE_PLANAR_LDS);
         TRC_LAUNCH_TIMED(trc_ansa_model2_kernel, TRC_QUAD_GRID(w.ngroups), dim3(128 * TRC_WPG), TRC_WPG * ANSA_MODEL_LDS(false), s, d_in, (u64)n, chunk, w.nchunks, w.scratch2);
-        static const int codeq = getenv("TRC_ANSA_CODEQ") ? atoi(getenv("TRC_ANSA_CODEQ")) : 1;     // 0: one lane per chunk (rounds 1-3)
-        if (codeq)
-            TRC_LAUNCH_TIMED(trc_ansa_codeq_kernel, dim3(w.ngroups), dim3(256), ANSQ_LDS, s,
-                               (const u8 *)w.scratch2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
-        else
-            TRC_LAUNCH_TIMED(trc_ansa_code_planar_kernel, TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (ANSA_CODE_PLANAR_LDS), s,
-                               (const u8 *)w.scratch2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
+        trc_launch_ansa_code_planar(n, chunk, w, d_clen, s);
         return;
     }
     TRC_RAISE_LDS_ONCE((trc_ansa_model_kernel<NIB>), TRC_WPG * ANSA_MODEL_LDS(NIB));
@@ -731,6 +725,19 @@ static void launch_ansa_dec(const uint8_t *d_payload, const uint32_t *d_clen, si
     TRC_RAISE_LDS_ONCE((trc_ansa_dec_kernel<NIB>), TRC_WPG * ANSA_MODEL_LDS(NIB));
     TRC_LAUNCH_TIMED((trc_ansa_dec_kernel<NIB>), TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (ANSA_MODEL_LDS(NIB)), s,
                        d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, d_out);
+}
+// pass 2 over the planar record space (ANSA's two-wave model pass, and the order-1 coder's)
+void trc_launch_ansa_code_planar(size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
+{
+    static const int codeq = getenv("TRC_ANSA_CODEQ") ? atoi(getenv("TRC_ANSA_CODEQ")) : 1;     // 0: one lane per chunk (rounds 1-3)
+    if (codeq)
+        TRC_LAUNCH_TIMED(trc_ansa_codeq_kernel, dim3(w.ngroups), dim3(256), ANSQ_LDS, s,
+                           (const u8 *)w.scratch2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
+    else {
+        TRC_RAISE_LDS_ONCE(trc_ansa_code_planar_kernel, TRC_WPG * ANSA_CODE_PLANAR_LDS);
+        TRC_LAUNCH_TIMED(trc_ansa_code_planar_kernel, TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (ANSA_CODE_PLANAR_LDS), s,
+                           (const u8 *)w.scratch2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
+    }
 }
 // pass 2 alone (the order-1 coder of trc_ans_o1.hip produces the same record stack with its own pass 1)
 void trc_launch_ansa_code(int nibble, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)

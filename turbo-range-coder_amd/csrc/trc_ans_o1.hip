@@ -22,6 +22,7 @@
 //     entry 0 of its hi table, which the model keeps at 0 (K[x][0] = 0) and which is masked out while the table is in
 //     registers.  The 136 KiB-per-chunk fill kernel of rounds 1-2 (3.3 GB per call at 100 MB / chunk 4096, twice per
 //     step) is gone, and so is the first read of every table.
+#include <stdlib.h>
 #include "trc_io.h"
 #include "trc_lane_io.h"
 #include "trc_nibmodel.h"
@@ -192,6 +193,108 @@ __global__ __launch_bounds__(64) void trc_o1_model_kernel(
     }
 }
 
+// Pass 1 as TWO WAVES per 64 chunks (round 4; the scheme of trc_ansa_model2_kernel, trc_ans_adaptive.hip).  The hi record of a byte
+// needs the hi table of its context alone, the lo record the lo table of (context, hi nibble) alone -- and both selectors are INPUT
+// (the byte before, this byte's hi nibble), not model state.  So a "hi" wave and a "lo" wave walk the same bytes, each with ONE
+// cached table per lane and its own first-touch bits (hi: 256 contexts per lane; lo: 4096 tables per lane, [word][lane] in LDS),
+// on disjoint tables of the chunk's model block, with nothing to tell each other: no barrier.  A lane's chain is one table round
+// trip per byte instead of two, and the two chains of a chunk run side by side.  Records go to the PLANAR record space (64 B of
+// hi records, 64 B of lo records per 16 input bytes), which the four-lanes-per-chunk coding pass reads.  Workgroup = W hi waves
+// + W lo waves; launched with W = 1 (see trc_launch_anso1_model).
+#define O1M2_KB      0u
+#define O1M2_HSEEN   TRC_NIBK_BYTES                             // u32[8][64]
+#define O1M2_LSEEN   (TRC_NIBK_BYTES + 2048u)                   // u32[128][64]
+#define O1M2_LDS     (TRC_NIBK_BYTES + 2048u + 32768u)
+template <u32 W>                                               // pairs per workgroup
+__global__ __launch_bounds__(128 * W) void trc_o1_model2_kernel(
+    const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ model, u8 *__restrict__ recs)
+{
+    typedef __attribute__((address_space(3))) u32 lds_u32;
+    extern __shared__ __attribute__((aligned(16))) u8 smem_wg_[];
+    const u32 wv_ = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool lo_wave = wv_ >= W;
+    const u32 grp_ = blockIdx.x * W + (wv_ & (W - 1u));
+    if (grp_ >= (nchunks + 63u) / 64u) return;
+    u8 *const smem = smem_wg_ + (wv_ & (W - 1u)) * O1M2_LDS;
+    const u32 lane = trc_lane();
+    u8 *const kb = smem + O1M2_KB;
+    {                                                          // both waves write the same K; each zeroes its own first-touch bits
+#pragma unroll
+        for (u32 j = 0; j < 2; j++) {
+            const u32 idx = lane * 2u + j, x = idx >> 3, k = idx & 7u;
+            const u32 e0 = 2u * k, e1 = 2u * k + 1u;
+            ((u32 *)kb)[idx] = trc_pk(10u * e0 + (e0 > x ? 32736u : 0u), 10u * e1 + (e1 > x ? 32736u : 0u));
+        }
+        u32 *z = (u32 *)(smem + (lo_wave ? O1M2_LSEEN : O1M2_HSEEN));
+        for (u32 i = lane; i < (lo_wave ? 128u * 64u : 8u * 64u); i += 64u) z[i] = 0u;
+        trc_wave_lds_fence();
+    }
+    const u32 seen = trc_lds_addr(smem) + (lo_wave ? O1M2_LSEEN : O1M2_HSEEN) + lane * 4u;      // word w of this lane at seen + 256 w
+
+    WaveChunks wc;
+    wc.c0 = grp_ * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
+    wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
+    wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
+    WaveChunks wr = wc;
+    wr.chunk = 8u * chunk; wr.lastlen = 128u * ((wc.lastlen + 15u) / 16u);      // planar record space
+    const bool alive = lane < wc.rows;
+    const u32 len = alive ? wc.len_of(lane) : 0u;
+    const u32 plen = len + (len & 1u);                         // bytes coded, dummy included
+    u8 *const mine = model + (u64)(wc.c0 + (alive ? lane : 0u)) * O1_MODEL_BYTES;   // dead lanes alias lane 0's model but never touch it
+
+    NibTable Tc = O1Cache::fresh();                            // the one table this lane holds, and which (~0u: none yet)
+    u32 tid_c = ~0u;
+    // make Tc table `id` of the model block (first-touch bit `bit` of word `wd`), only where `on`
+    auto need = [&](bool on, u32 id, u32 fb) __attribute__((always_inline)) {
+        if (on && id != tid_c) {
+            if (tid_c != ~0u) o1_store(mine + (size_t)tid_c * 32u, Tc);
+            const u32 a = seen + ((fb >> 5) << 8), bits = *(const lds_u32 *)(uintptr_t)a, bit = 1u << (fb & 31u);
+            if (bits & bit) Tc = o1_load(mine + (size_t)id * 32u);
+            else { Tc = O1Cache::fresh(); *(lds_u32 *)(uintptr_t)a = bits | bit; }
+            tid_c = id;
+        }
+    };
+
+    QuadIn qin; qin.base = in + (u64)wc.c0 * chunk;
+    QuadOut qout; qout.base = recs + (u64)wc.c0 * wr.chunk;
+    u32 cx = 0;
+    const u32 S = chunk / TRC_SEG;
+    qin.issue(wc, 0);
+    for (u32 s = 0; s < S; s++) {
+        qin.commit();
+        if (s + 1 < S) qin.issue(wc, (s + 1) * TRC_SEG);
+        uint4 pc0 = qin.read(0), pc1 = qin.read(1), pc2 = qin.read(2), pc3 = qin.read(3);
+#pragma nounroll
+        for (u32 k = 0; k < 4; k++) {
+            const uint4 v = pc0; pc0 = pc1; pc1 = pc2; pc2 = pc3;
+            const u32 p0 = s * TRC_SEG + k * 16u;
+            if (!__ballot(alive && p0 < len)) continue;
+            const u32 w[4] = { v.x, v.y, v.z, v.w };
+            u32 r[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {                     // 16 input bytes -> 16 records of this wave's plane
+                const u32 pos = p0 + (u32)i;
+                u32 x = (w[i >> 2] >> (8 * (i & 3))) & 255u;
+                if (pos >= len) x = 0;                         // the coded dummy of an odd tail (and unused padding)
+                r[i] = 0;
+                const bool on = alive && pos < plen;
+                const u32 h = x >> 4, sym = lo_wave ? x & 15u : h;
+                if (lo_wave) need(on, cx * 17u + 1u + h, cx * 16u + h); else need(on, cx * 17u, cx);
+                if (on) {
+                    u32 a0, a1;
+                    o1_bounds(Tc, sym, a0, a1);
+                    o1_adapt(Tc, kb, sym);
+                    r[i] = (a0 << TRC_PROB_BITS) | (a1 - a0);
+                    cx = x;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) qout.put((u32)j, make_uint4(r[4 * j], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]));
+            qout.flush(wr, p0 * 8u + (lo_wave ? 64u : 0u));
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------- decode ---
 __global__ __launch_bounds__(64) void trc_o1_dec_kernel(
     const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
@@ -285,9 +388,21 @@ __global__ __launch_bounds__(64) void trc_o1_dec_kernel(
 }
 
 // ------------------------------------------------------------------------------------- launch ---
-void trc_launch_anso1_model(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, hipStream_t s)
+// returns true when the records were written to the PLANAR record space (the caller then runs the planar coding pass)
+bool trc_launch_anso1_model(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, hipStream_t s)
 {
+    static const int two = getenv("TRC_O1_MC") ? atoi(getenv("TRC_O1_MC")) : 1;      // 0: the one-wave pass of rounds 1-3 (interleaved records)
+    // ... up to 1024 pairs: beyond that (100 MB at chunk 1024: 1526) the unit is saturated by one wave per 64 chunks already and the
+    // second wave only adds its own input loads and record stores (3.30 -> 3.93 ms); chunk 4096: 5.35 -> 3.80 ms, 2048: 3.39 -> 3.19
+    if (two && w.ngroups <= 1024u) {
+        // ONE pair per workgroup: these waves are bound by the texture-address unit of their CU (64 scattered 16-byte accesses per
+        // table move), not by their SIMD -- four pairs per workgroup put 100 MB at chunk 4096 (382 pairs) on 96 CUs and ran 30 %
+        // slower than the one-wave pass; as single pairs they spread over all 256 (profiles/r04_notes.md)
+        TRC_LAUNCH_TIMED(trc_o1_model2_kernel<1>, dim3(w.ngroups), dim3(128), O1M2_LDS, s, d_in, (u64)n, chunk, w.nchunks, w.model, w.scratch2);
+        return true;
+    }
     TRC_LAUNCH_TIMED(trc_o1_model_kernel, dim3(w.ngroups), dim3(64), 0, s, d_in, (u64)n, chunk, w.nchunks, w.model, w.scratch2);
+    return false;
 }
 void trc_launch_anso1_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                           const TrcWork &w, uint8_t *d_out, hipStream_t s)

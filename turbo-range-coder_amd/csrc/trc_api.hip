@@ -350,8 +350,9 @@ extern "C" int trc_encode_dev(int codec, const void *d_in, size_t n, uint32_t ch
     default:        if (is_vlc(codec)) { trc_launch_vlc_enc(vlc_variant(codec), vlc_elem(codec), (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 3; }
                     else if (is_vla(codec)) { trc_launch_vla_enc(vla_variant(codec), vla_zz(codec), vla_elem(codec), (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 4; }
                     break;
-    case TRC_ANSO1: trc_launch_anso1_model((const uint8_t *)d_in, n, chunk, w, s);
-                    trc_launch_ansa_code(0, n, chunk, w, d_clen, s); from_end = 1; break;
+    case TRC_ANSO1: if (trc_launch_anso1_model((const uint8_t *)d_in, n, chunk, w, s)) trc_launch_ansa_code_planar(n, chunk, w, d_clen, s);
+                    else trc_launch_ansa_code(0, n, chunk, w, d_clen, s);
+                    from_end = 1; break;
     }
     tm_end(0);
     if (w.goff) trc_launch_scan_groups(w.gsum, w.ngroups, w.goff, d_total, s);

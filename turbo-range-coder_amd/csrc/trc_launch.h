@@ -104,7 +104,8 @@ void trc_launch_ansa_code(int nibble, size_t n, uint32_t chunk, const TrcWork &w
 
 // ANSO1: order-1 adaptive-CDF byte rANS (anscdf1enc / anscdf1dec): pass 1 with the models in HBM (w.model), then
 // trc_launch_ansa_code(0, ...); scratch2 holds the same 8 B/byte record stack as ANSA
-void trc_launch_anso1_model(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, hipStream_t s);
+bool trc_launch_anso1_model(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, hipStream_t s);   // true: records are in the planar space
+void trc_launch_ansa_code_planar(size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s);   // pass 2 over the planar record space (four lanes per chunk)
 void trc_launch_anso1_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                           const TrcWork &w, uint8_t *d_out, hipStream_t s);
 
