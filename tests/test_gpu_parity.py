@@ -289,6 +289,50 @@ def test_bitwise_rc_encoder_both_forms(torch_cuda):
         assert r.returncode == 0 and "ok" in r.stdout, (form, r.stdout[-2000:] + r.stderr[-3000:])
 
 
+def test_round4_kernel_forms(torch_cuda):
+    """round 4 gave the model-bound coders second forms that the launch code picks between: encoders as a model wave + a coder wave
+    (default) or one wave, `anscdf` pass 2 with four lanes per chunk (default) or one, the order-1 model pass as a hi wave + a lo
+    wave, decoders as two waves (measured slower, off by default), two histogram kernels.  Every form is forced in a process of its
+    own (the switches are read once): per-chunk parity with the oracle and round trip for the coders involved, ragged tails, a
+    short last wave, raw chunks."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np, torch
+        sys.path[:0] = [%r, %r]
+        import trc, trc_testlib as T
+        from golden.make_golden import gen
+        for codec in (trc.RCA, trc.RCAI, trc.RCB, trc.ANSA, trc.ANSO1):
+            for kind, n, chunk in (("text", 300001, 512), ("runs", 64 * 1024 * 2 + 5, 1024), ("uniform", 40000, 256), ("zipf", 270001, 4096), ("text", 701, 256)):
+                if codec == trc.ANSO1 and chunk < 1024:
+                    continue
+                d = gen(kind, n, 8)
+                dc = trc.DeviceCoder(codec, n, chunk, "cuda:0")
+                d_in = torch.from_numpy(np.concatenate([d, np.zeros(512, np.uint8)])).to("cuda:0")
+                dc.encode(d_in, n)
+                clen, payload = dc.result(n)
+                ep, ec, _ = T.orc_chunked_enc(codec, d, chunk, None, 0)
+                assert np.array_equal(clen, ec) and np.array_equal(payload, ep), (trc.CODEC_NAMES[codec], kind, n, chunk)
+                out = torch.full((n + 512,), 0xA5, dtype=torch.uint8, device="cuda:0")
+                dc.decode(out, n, dir_ready=True); torch.cuda.synchronize()
+                o = out.cpu().numpy()
+                assert np.array_equal(o[:n], d) and (o[n:] == 0xA5).all(), (trc.CODEC_NAMES[codec], kind, n, chunk)
+        d = gen("text", 1000003, 9)
+        dc = trc.DeviceCoder(trc.ANS4S, d.size, 512, "cuda:0")
+        d_in = torch.from_numpy(np.concatenate([d, np.zeros(512, np.uint8)])).to("cuda:0")
+        hist = torch.zeros(256, dtype=torch.int64, device="cuda:0")
+        dc.hist(d_in, d.size, hist); torch.cuda.synchronize()
+        assert np.array_equal(hist.cpu().numpy(), np.bincount(d, minlength=256))
+        print("ok")
+    """) % (os.path.dirname(os.path.abspath(trc.__file__)), os.path.dirname(os.path.abspath(__file__)))
+    forms = (dict(TRC_RCA_MC="0", TRC_RCB_MC="0", TRC_ANSA_MC="0", TRC_O1_MC="0", TRC_HIST_FORM="1"),      # everything as in round 3
+             dict(TRC_ANSA_CODEQ="0"),                                                                       # planar records, one lane per chunk in pass 2
+             dict(TRC_RCA_DMC="1", TRC_ANSA_DMC="1"),                                                        # the two-wave decoders
+             dict())                                                                                         # the defaults, same inputs
+    for env in forms:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0 and "ok" in r.stdout, (env, r.stdout[-2000:] + r.stderr[-3000:])
+
+
 def test_bounded_host_decoder(torch_cuda):
     """trc_decode_host: the decoder that is told how long its input really is.  A valid container round-trips; a truncated
     buffer, a header that claims more payload than the buffer holds and a directory that does not add up are REJECTED

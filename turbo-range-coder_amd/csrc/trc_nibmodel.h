@@ -269,7 +269,10 @@ __device__ __forceinline__ u32 trc_nib_search(const NibTable &T, GE ge, u32 &c0,
     const bool b0 = ge(gh);
     c0 = b0 ? gh : (g0 & 0xffffu);
     c1 = b0 ? (g1 & 0xffffu) : gh;
-    return (b3 ? 8u : 0u) + (b2 ? 4u : 0u) + (b1 ? 2u : 0u) + (b0 ? 1u : 0u);
+    // the index as a carry chain (x = 2x + b: one v_addc per bit) instead of four selects and three adds
+    u32 x = b3 ? 1u : 0u;
+    x = x + x + (b2 ? 1u : 0u); x = x + x + (b1 ? 1u : 0u); x = x + x + (b0 ? 1u : 0u);
+    return x;
 }
 __device__ __forceinline__ u32 trc_nib_find(const NibTable &T, u32 q, u32 &c0, u32 &c1)
 {

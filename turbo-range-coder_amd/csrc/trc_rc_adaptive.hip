@@ -342,14 +342,22 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_rca_dec_kernel(
                     // end: trc_lane_io.h `prefetch`)
                     if (!NIB && NS == 1) {
 #pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            const bool act = coded && q0 + (u32)i < len;
+                        for (int pr = 0; pr < 2; pr++) {
+                            // round 4: the stream side once per TWO bytes (<= 8 stream bytes: one word per byte at most, the window
+                            // protocol's limit): one prefetch, the words at the position and behind it, one advance -- the second
+                            // byte looks ahead at the second word if the first byte took the first
+                            const bool acta = coded && q0 + 2u * (u32)pr < len, actb = coded && q0 + 2u * (u32)pr + 1u < len;
                             const uint4 pre = s0.prefetch();
-                            const u32 sw = s0.peek32();
-                            const u32 h = get0(d0, sw, act);
-                            const u32 l = get(d0, sw, m.table(1u + (h & 15u)), act);
-                            s0.advance_pre(((h | l) & 16u) >> 2, pre);
-                            w |= ((h & 15u) << 4 | (l & 15u)) << (8 * i);
+                            u32 swa, swb;
+                            s0.two_words(swa, swb);
+                            const u32 ha = get0(d0, swa, acta);
+                            const u32 la = get(d0, swa, m.table(1u + (ha & 15u)), acta);
+                            const u32 ra = (ha | la) & 16u;
+                            const u32 sw2 = ra ? swb : swa;
+                            const u32 hb = get0(d0, sw2, actb);
+                            const u32 lb = get(d0, sw2, m.table(1u + (hb & 15u)), actb);
+                            s0.advance_pre((ra + ((hb | lb) & 16u)) >> 2, pre);
+                            w |= (((ha & 15u) << 4 | (la & 15u)) | ((hb & 15u) << 4 | (lb & 15u)) << 8) << (16 * pr);
                         }
                     } else if (!NIB) {
 #pragma unroll
