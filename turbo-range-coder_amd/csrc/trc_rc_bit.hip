@@ -303,8 +303,10 @@ __global__ __launch_bounds__(128 * TRC_WPG) void trc_rcb_enc_mc_kernel(
 #pragma unroll
                     for (u32 h = 0; h < 2; h++) {
                         const u32 a = qa + buf * 2048u;
+#ifndef RCB_ABL_NOMODEL                                         // timing ablation: the model wave only keeps the barriers company
                         model_byte((w >> (16 * h)) & 255u, a);
                         model_byte((w >> (16 * h + 8)) & 255u, a + 1024u);
+#endif
                         trc_lds_barrier();
                         buf ^= 1u;
                     }
@@ -321,22 +323,30 @@ __global__ __launch_bounds__(128 * TRC_WPG) void trc_rcb_enc_mc_kernel(
     const int lim = trc_rc_limit(len);
     LaneOutDirect so; so.start(scratch + (u64)c * stride);
     u32 rlo = ~0u, rhi = ~0u, llo = 0, lhi = 0;
-    bool cy = false;
+    u32 lx = 0;                                                // carry limb of `low` (0 / 1): see code_byte
     TrcCarry cw; cw.start();
     bool ovf = alive && lim <= 0;
     bool live = alive && !ovf;
     u32 out_len = alive ? len : 0u;
 
-    auto put_byte = [&](const uint4 rec) __attribute__((always_inline)) {
+    // One byte = 4 x (renormalisation point + two bits).  Bookkeeping on the VECTOR side only (the ablation without the emit logic
+    // ran the encoder in 0.91 instead of 1.33 ms: a third of the coder wave was mask algebra in SGPRs -- two / pend / carry flags,
+    // each a VALU -> SALU -> VALU round trip -- and one emit per byte; profiles/r04_notes.md):
+    //  * the carry of `low +=` is a third limb `lx` (0 / 1) fed by the add's carry-out (v_addc), not an ORed lane mask;
+    //  * a renormalisation point shifts the state and pushes one bit into `rnb` ("there is a word") and one into `cyb` ("it carries
+    //    into the words before it"), keeps the word in `pw` (and every point's word in pwj[] for the rare several-words case);
+    //  * the emit logic runs ONCE PER PERIOD of two bytes (a lane emits a word every ~6 bytes): popcount(rnb) >= 2 in some lane is
+    //    the wave-uniform rare path that replays the points in order.
+    auto code_byte = [&](const uint4 rec, u32 &rnb, u32 &cyb, u32 &pw, u32 (&pwj)[4]) __attribute__((always_inline)) {
         const u32 R[4] = { rec.x, rec.y, rec.z, rec.w };
-        bool rnj[4], cyj[4];
-        u32 pwj[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             {
                 const bool rn = rhi == 0u;
-                rnj[j] = rn; cyj[j] = rn && cy; pwj[j] = lhi;
-                cy = cy && !rn;
+                rnb = rnb + rnb + (rn ? 1u : 0u);
+                cyb = cyb + cyb + (rn ? lx : 0u);
+                pwj[j] = lhi; pw = rn ? lhi : pw;
+                lx = rn ? 0u : lx;
                 lhi = rn ? llo : lhi; llo = rn ? 0u : llo;
                 rhi = rn ? rlo : rhi; rlo = rn ? 0u : rlo;
             }
@@ -347,30 +357,35 @@ __global__ __launch_bounds__(128 * TRC_WPG) void trc_rcb_enc_mc_kernel(
                 const u32 slo = __builtin_amdgcn_alignbit(rhi, rlo, TRC_PROB_BITS), shi = rhi >> TRC_PROB_BITS;
                 const u64 c64 = (u64)slo * prob;
                 const u32 clo = (u32)c64, chi = __umul24(shi, prob) + (u32)(c64 >> 32);
-                u32 k1, k2;
+                u32 k1, k2, k3;
                 llo = __builtin_addc(llo, rcb_bfi(m, 0u, clo), 0u, &k1);
                 lhi = __builtin_addc(lhi, rcb_bfi(m, 0u, chi), k1, &k2);
-                cy = cy || (k2 != 0u);
+                lx = __builtin_addc(lx, 0u, k2, &k3);              // (at most one carry between two renormalisations: lx is 0 or 1)
                 u32 b1, b2;
                 const u32 tlo = __builtin_subc(rlo, clo, 0u, &b1), thi = __builtin_subc(rhi, chi, b1, &b2);
                 rlo = rcb_bfi(m, clo, tlo); rhi = rcb_bfi(m, chi, thi);
             }
         }
-        const bool two = (rnj[0] && (rnj[1] || rnj[2] || rnj[3])) || (rnj[1] && (rnj[2] || rnj[3])) || (rnj[2] && rnj[3]);
-        if (__ballot(two && live)) {
+    };
+    // the words of NP renormalisation points (rnb / cyb: point 0 in bit NP - 1), in order
+    auto emit_points = [&](u32 rnb, u32 cyb, u32 pw, const u32 (&pa)[4], const u32 (&pb)[4], const int NP) __attribute__((always_inline)) {
+#ifdef RCB_ABL_NOEMIT                                           // timing ablation (profiles/r04_notes.md): no emit logic, output wrong
+        so.wpos += rnb + cyb + (pw & 1u) + (pa[1] & pb[2] & 1u); return;
+#endif
+        const u32 cnt = (u32)__builtin_popcount(rnb);
+        if (__ballot(cnt >= 2u && live)) {                      // rare: some lane has several words in this period
 #pragma unroll
-            for (int j = 0; j < 4; j++) cw.emit_if(so, rnj[j] && live, cyj[j], pwj[j]);
-        } else {
-            const bool pend = rnj[0] || rnj[1] || rnj[2] || rnj[3];
-            const bool pcy = cyj[0] || cyj[1] || cyj[2] || cyj[3];
-            const u32 pw = rnj[3] ? pwj[3] : rnj[2] ? pwj[2] : rnj[1] ? pwj[1] : pwj[0];
-            cw.emit_if(so, pend && live, pcy, pw);
-        }
+            for (int j = 0; j < 8; j++) {
+                if (j >= NP) break;
+                const u32 bit = 1u << (NP - 1 - j);
+                cw.emit_if(so, (rnb & bit) != 0u && live, (cyb & bit) != 0u, j < 4 ? pa[j & 3] : pb[j & 3]);
+            }
+        } else cw.emit_if(so, rnb != 0u && live, cyb != 0u, pw);
     };
     auto finish = [&]() __attribute__((always_inline)) {                                      // rceflush (turborc_.h:118-128), then everything still held back
         u64 low = ((u64)lhi << 32) | llo;
         u64 rg = ((u64)rhi << 32) | rlo;
-        bool c0 = cy;
+        bool c0 = lx != 0u;
         if (rg < TRC_TOP32) { cw.emit(so, c0, (u32)(low >> 32)); low <<= 32; rg <<= 32; c0 = false; }
         if (rg > ((u64)1 << 33)) {
             const u64 nl = low + TRC_TOP32;
@@ -386,11 +401,23 @@ __global__ __launch_bounds__(128 * TRC_WPG) void trc_rcb_enc_mc_kernel(
         if (!__ballot(live)) return;
         const u32 a = qa + buf * 2048u;
         const uint4 r0 = trc_ldsr128(a), r1 = trc_ldsr128(a + 1024u);
+#ifdef RCB_ABL_NOCODER                                          // timing ablation: the coder wave only keeps the barriers company
+        so.wpos += r0.x & r1.y & 4u; return;
+#endif
         const bool ends = __ballot(live && len - q0 < 2u) != 0;        // a short last chunk ends inside this period (once per grid)
+        u32 rnb = 0, cyb = 0, pw = 0, pa[4], pb[4] = { 0, 0, 0, 0 };
         if (ends && live && q0 == len) { if ((int)(4u * cw.nwords) < lim) { finish(); out_len = so.wpos; } live = false; }
-        put_byte(r0);
-        if (ends && live && q0 + 1u == len) { if ((int)(4u * cw.nwords) < lim) { finish(); out_len = so.wpos; } live = false; }
-        put_byte(r1);
+        code_byte(r0, rnb, cyb, pw, pa);
+        if (ends) {                                             // (wave-uniform) the chunk may end between the two bytes: emit what byte 0 left first
+            emit_points(rnb, cyb, pw, pa, pb, 4);
+            rnb = cyb = 0;
+            if (live && q0 + 1u == len) { if ((int)(4u * cw.nwords) < lim) { finish(); out_len = so.wpos; } live = false; }
+            code_byte(r1, rnb, cyb, pw, pa);
+            emit_points(rnb, cyb, pw, pa, pb, 4);
+        } else {
+            code_byte(r1, rnb, cyb, pw, pb);
+            emit_points(rnb, cyb, pw, pa, pb, 8);
+        }
         ovf = ovf || (live && (int)(4u * cw.nwords) >= lim);           // OVERFLOW, monotone
         live = live && !ovf;
     };
