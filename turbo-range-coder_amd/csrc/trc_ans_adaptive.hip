@@ -171,7 +171,11 @@ __global__ __launch_bounds__(128 * TRC_WPG) void trc_ansa_model2_kernel(
                     x[i] = (w[q] >> (8 * i)) & 255u;
                     if (p0 + 4u * (u32)q + (u32)i >= len) x[i] = 0;       // the coded dummy of an odd tail (and unused padding)
                 }
-                if (lo_wave) m.template record_lo<4>(x, rr); else m.template record_hi<4>(T0, x, rr);
+                // (lo records one byte at a time: no fix-ups between the bytes of a batch; the other wave hides the LDS round trips)
+                if (lo_wave) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { const u32 x1[1] = { x[i] }; u32 r1[1]; m.template record_lo<1>(x1, r1); rr[i] = r1[0]; }
+                } else m.template record_hi<4>(T0, x, rr);
 #pragma unroll
                 for (int i = 0; i < 4; i++) r[4 * q + i] = rr[i];
             }

@@ -159,22 +159,27 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_rca_enc_kernel(
 #define RCA_MC_LDS     (TRC_NIB_BYTES + RCA_MC_QUEUE)
 
 template <int NS>
-__global__ __launch_bounds__(128 * TRC_WPG) void trc_rca_enc_mc_kernel(
+__global__ __launch_bounds__(192 * TRC_WPG) void trc_rca_enc_mc_kernel(
     const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks,
     u8 *__restrict__ scratch, u32 stride, u8 *__restrict__ scratch2, u32 stride2,
     u32 *__restrict__ clen, u32 *__restrict__ gsum)
 {
-    // a workgroup = 4 model waves (0-3) + 4 coder waves (4-7): pair k = waves k and k + 4 = group 4 blockIdx + k; the dispatcher
-    // deals a workgroup's waves over consecutive SIMDs, so SIMD k of the CU holds pair k (trc_dev.h, TRC_WPG)
+    // a workgroup = 4 hi-model waves (0-3) + 4 lo-model waves (4-7) + 4 coder waves (8-11): set k = waves k, k + 4, k + 8 = group
+    // 4 blockIdx + k; the dispatcher deals a workgroup's waves over consecutive SIMDs, so SIMD k of the CU holds set k (trc_dev.h,
+    // TRC_WPG).  THREE waves since the ablations (profiles/r04_notes.md): of the two-wave form the model wave alone took 0.56 ms,
+    // the coder wave alone 0.41, both 0.60 -- the model wave was the kernel.  Its two halves need nothing from each other (the hi
+    // record of a byte depends on the hi table alone, the lo record on the lo tables alone; the lo table is selected by the hi
+    // nibble, which is input: NibModel::record_hi / record_lo), so they are two waves; the queue holds 4 hi records, then 4 lo.
     extern __shared__ __attribute__((aligned(16))) u8 smem_wg_[];
     const u32 wv_ = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const bool coder = wv_ >= TRC_WPG;
+    const u32 role = wv_ / TRC_WPG;                            // 0: hi records, 1: lo records, 2: coder
+    const bool coder = role == 2u;
     const u32 grp_ = blockIdx.x * TRC_WPG + (wv_ & (TRC_WPG - 1u));
-    if (grp_ >= (nchunks + 63u) / 64u) return;                 // (both waves of the pair: a finished wave no longer counts at s_barrier)
+    if (grp_ >= (nchunks + 63u) / 64u) return;                 // (all waves of the set: a finished wave no longer counts at s_barrier)
     u8 *const smem = smem_wg_ + (wv_ & (TRC_WPG - 1u)) * RCA_MC_LDS;
     const u32 lane = trc_lane();
     NibModel<17> m;
-    if (!coder) m.init(smem);                                  // the model belongs to the model wave alone
+    if (role == 0u) m.init_part(smem, 0u, 1u); else if (role == 1u) m.init_part(smem, 1u, 16u);     // each model wave its own tables (and the same K)
     const u32 qa = trc_lds_addr(smem) + TRC_NIB_BYTES + lane * 16u;
 
     WaveChunks wc;
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(128 * TRC_WPG) void trc_rca_enc_mc_kernel(
     const u32 S = chunk / TRC_SEG;
 
     if (!coder) {
-        // ---- wave 0: the model.  Walks every period of the chunk (a lane past the end of a short last chunk, or one whose
+        // ---- the model waves.  Walk every period of the chunk (a lane past the end of a short last chunk, or one whose
         // chunk the coder has given up on, leaves records nobody codes).
         QuadIn qin; qin.base = in + (u64)wc.c0 * chunk;
         NibTable T0 = m.load(m.table(0));
@@ -201,11 +206,20 @@ __global__ __launch_bounds__(128 * TRC_WPG) void trc_rca_enc_mc_kernel(
                 for (u32 d = 0; d < 4; d++) {
                     const u32 w = v.x; v.x = v.y; v.y = v.z; v.z = v.w;
                     const u32 x[4] = { w & 255u, (w >> 8) & 255u, (w >> 16) & 255u, w >> 24 };
-                    u32 rc[8];
-                    m.template record_bytes<4>(T0, x, rc);
-                    const u32 a = qa + buf * 2048u;
-                    trc_ldsw128(a, make_uint4(rc[0], rc[1], rc[2], rc[3]));
-                    trc_ldsw128(a + 1024u, make_uint4(rc[4], rc[5], rc[6], rc[7]));
+                    u32 rc[4];
+#ifdef RCA_ABL_NOMODEL                                          // timing ablation: the model waves only keep the barriers company
+#pragma unroll
+                    for (int i = 0; i < 4; i++) rc[i] = (x[i] << 15) | 2048u;
+#else
+                    // the lo records one byte at a time: with two more waves on the SIMD nothing waits for the LDS round trips a batch of four
+                    // requests up front, and the batch's fix-ups between bytes of equal hi nibble (8 selects per earlier byte) are gone (0.612 -> 0.583 ms)
+                    if (role == 0u) m.template record_hi<4>(T0, x, rc);
+                    else {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) { const u32 x1[1] = { x[i] }; u32 r1[1]; m.template record_lo<1>(x1, r1); rc[i] = r1[0]; }
+                    }
+#endif
+                    trc_ldsw128(qa + buf * 2048u + role * 1024u, make_uint4(rc[0], rc[1], rc[2], rc[3]));
                     trc_lds_barrier();
                     buf ^= 1u;
                 }
@@ -214,7 +228,7 @@ __global__ __launch_bounds__(128 * TRC_WPG) void trc_rca_enc_mc_kernel(
         return;
     }
 
-    // ---- wave 1: the range coder, one period behind
+    // ---- the coder wave: the range coder, one period behind
     const bool alive = lane < wc.rows;
     const u32 c = wc.c0 + lane;
     const u32 len = alive ? wc.len_of(lane) : 0u;
@@ -229,8 +243,11 @@ __global__ __launch_bounds__(128 * TRC_WPG) void trc_rca_enc_mc_kernel(
     auto code_period = [&](u32 q0, u32 buf) __attribute__((always_inline)) {
         if (!__ballot(alive && !ovf && q0 < len)) return;
         const u32 a = qa + buf * 2048u;
-        const uint4 ra = trc_ldsr128(a), rb = trc_ldsr128(a + 1024u);
-        const u32 rc[8] = { ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w };
+        const uint4 ra = trc_ldsr128(a), rb = trc_ldsr128(a + 1024u);          // four hi records, four lo records
+        const u32 rc[8] = { ra.x, rb.x, ra.y, rb.y, ra.z, rb.z, ra.w, rb.w };
+#ifdef RCA_ABL_NOCODER                                          // timing ablation: the coder wave only keeps the barriers company
+        o0.wpos += rc[0] & rc[7] & 4u; return;
+#endif
         const bool run = alive && !ovf;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -586,7 +603,7 @@ template <int NS>
 static void launch_rca_enc_mc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
 {
     TRC_RAISE_LDS_ONCE(trc_rca_enc_mc_kernel<NS>, TRC_WPG * RCA_MC_LDS);
-    TRC_LAUNCH_TIMED((trc_rca_enc_mc_kernel<NS>), TRC_QUAD_GRID(w.ngroups), dim3(128 * TRC_WPG), TRC_WPG * RCA_MC_LDS, s,
+    TRC_LAUNCH_TIMED((trc_rca_enc_mc_kernel<NS>), TRC_QUAD_GRID(w.ngroups), dim3(192 * TRC_WPG), TRC_WPG * RCA_MC_LDS, s,
                        d_in, (u64)n, chunk, w.nchunks, w.scratch, w.stride, w.scratch2, w.stride2, d_clen, w.gsum);
 }
 void trc_launch_rca_enc(int nstreams, int nibble, const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
