@@ -316,7 +316,7 @@ def test_round4_kernel_forms(torch_cuda):
                 dc.decode(out, n, dir_ready=True); torch.cuda.synchronize()
                 o = out.cpu().numpy()
                 assert np.array_equal(o[:n], d) and (o[n:] == 0xA5).all(), (trc.CODEC_NAMES[codec], kind, n, chunk)
-        d = gen("text", 1000003, 9)
+        d = gen("text", 40000003, 9)                               # (several rounds of the histogram when TRC_HIST_ROUND_VECS=3: 12.6 MB per round)
         dc = trc.DeviceCoder(trc.ANS4S, d.size, 512, "cuda:0")
         d_in = torch.from_numpy(np.concatenate([d, np.zeros(512, np.uint8)])).to("cuda:0")
         hist = torch.zeros(256, dtype=torch.int64, device="cuda:0")
@@ -325,6 +325,7 @@ def test_round4_kernel_forms(torch_cuda):
         print("ok")
     """) % (os.path.dirname(os.path.abspath(trc.__file__)), os.path.dirname(os.path.abspath(__file__)))
     forms = (dict(TRC_RCA_MC="0", TRC_RCB_MC="0", TRC_ANSA_MC="0", TRC_O1_MC="0", TRC_HIST_FORM="1"),      # everything as in round 3
+             dict(TRC_HIST_ROUND_VECS="3"),                                                                  # the histogram's many-round path (real inputs: beyond 4.29 GB)
              dict(TRC_ANSA_CODEQ="0"),                                                                       # planar records, one lane per chunk in pass 2
              dict(TRC_RCA_DMC="1", TRC_ANSA_DMC="1"),                                                        # the two-wave decoders
              dict())                                                                                         # the defaults, same inputs

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void trc_hist_kernel(const u8 *__restrict__ in
 #define TRC_HIST2_WAVE_LDS (128u * 16u * 4u)
 #define TRC_HIST2_WAVES 16u
 #define TRC_HIST2_ROUND_VECS 1023u
-__global__ __launch_bounds__(1024) void trc_hist2_kernel(const u8 *__restrict__ in, u64 n, u64 *__restrict__ hist)
+__global__ __launch_bounds__(1024) void trc_hist2_kernel(const u8 *__restrict__ in, u64 n, u64 *__restrict__ hist, u32 round_vecs)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     typedef __attribute__((address_space(3))) u32 lds_u32;
@@ -328,10 +328,10 @@ __global__ __launch_bounds__(1024) void trc_hist2_kernel(const u8 *__restrict__ 
         }
     };
     auto count4 = [&](const uint4 q) __attribute__((always_inline)) { count(q.x); count(q.y); count(q.z); count(q.w); };
-    for (u64 r0 = 0; r0 == 0 || r0 < nvec; r0 += stride * TRC_HIST2_ROUND_VECS) {
+    for (u64 r0 = 0; r0 == 0 || r0 < nvec; r0 += stride * round_vecs) {
         for (u32 r = lane; r < 128u * 16u; r += 64u) mine[r] = 0;
         u64 i = r0 + (u64)blockIdx.x * 1024 + tid;
-        u32 left = TRC_HIST2_ROUND_VECS;
+        u32 left = round_vecs;
         if (left >= 2u && i + stride < nvec) {                     // two vectors in flight per lane, the next two requested before these are counted
             uint4 q0 = v[i], q1 = v[i + stride];
             left -= 2u; i += 2 * stride;
@@ -406,7 +406,11 @@ void trc_launch_hist(const uint8_t *d_in, size_t n, uint64_t *d_hist, hipStream_
         u64 b2 = ((n >> 4) + 1023) / 1024;
         b2 = b2 < 1 ? 1 : b2 > 256 ? 256 : b2;                  // one workgroup of 16 waves per CU
         TRC_RAISE_LDS_ONCE(trc_hist2_kernel, sm2);
-        hipLaunchKernelGGL(trc_hist2_kernel, dim3((u32)b2), dim3(1024), sm2, s, d_in, (u64)n, d_hist);
+        // TRC_HIST_ROUND_VECS (test aid): vectors per lane between two reductions, so that a few MB exercise the many-round path
+        // that real inputs take only beyond 4.29 GB
+        static const u32 rv = getenv("TRC_HIST_ROUND_VECS") ? (u32)atoi(getenv("TRC_HIST_ROUND_VECS")) : TRC_HIST2_ROUND_VECS;
+        hipLaunchKernelGGL(trc_hist2_kernel, dim3((u32)b2), dim3(1024), sm2, s, d_in, (u64)n, d_hist,
+                           rv >= 1u && rv <= TRC_HIST2_ROUND_VECS ? rv : TRC_HIST2_ROUND_VECS);
         return;
     }
     const size_t sm = 4u * TRC_HIST_WAVE_LDS + 256u * sizeof(u64);
