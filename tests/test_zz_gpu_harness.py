@@ -217,7 +217,7 @@ def run_gather(args, env=None, timeout=400):
     return r, hashes
 
 
-@pytest.mark.parametrize("size,chunk", [(30000001, 512), (5000, 4096), (700, 256)], ids=["30MB", "5000B", "700B"])
+@pytest.mark.parametrize("size,chunk", [(30000001, 512), (5000, 4096), (700, 256), (8000003, 2560)], ids=["30MB", "5000B", "700B", "8MB-world8"])
 def test_c_gather_exchange_with_peers_on_one_gpu(torch_cuda, size, chunk):
     """trc_exchange_dev and trc_hist_allreduce_dev with world = 2, 3, 4 (and 5 for the ragged sizes: more ranks than chunks,
     empty shards) on ONE GPU: the ranks are processes sharing device 0 and the dozen RCCL calls are served by
@@ -230,10 +230,14 @@ def test_c_gather_exchange_with_peers_on_one_gpu(torch_cuda, size, chunk):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "harness"), "fake_rccl"])
     env = {"TRC_RCCL_LIB": FAKE, "TRC_FAKE_RCCL_TIMEOUT": "60"}
     base = ["--steps", "2", "--size", str(size), "--chunk", str(chunk), "--watchdog", "90"]
-    r, ref = run_gather(["--gpus", "1", "--batches", "5"] + base, env)
-    assert r.returncode == 0 and len(ref) == 5 and all(v for _, v in ref.values()), r.stdout + r.stderr
-    for world in (2, 3, 4) + ((5,) if size < 100000 else ()):
-        for nb in sorted({1, world, min(world + 1, 5)}):
+    # round 4: the shape of the first real 8-GPU run -- world 8, 8 batches (every rank a root once) and 9 (wraps around), the chunk
+    # the library picks for BASELINE config 5's 1 GB shards (2560), shards of 1 MB
+    eight = size == 8000003
+    nref = 9 if eight else 5
+    r, ref = run_gather(["--gpus", "1", "--batches", str(nref)] + base, env)
+    assert r.returncode == 0 and len(ref) == nref and all(v for _, v in ref.values()), r.stdout + r.stderr
+    for world in ((8,) if eight else (2, 3, 4) + ((5,) if size < 100000 else ())):
+        for nb in ((8, 9) if eight else sorted({1, world, min(world + 1, 5)})):
             r, got = run_gather(["--gpus", str(world), "--batches", str(nb)] + base, env)
             assert r.returncode == 0 and "FAILED" not in r.stdout, (world, nb, r.stdout + r.stderr)
             assert sorted(got) == list(range(nb)), (world, nb, r.stdout + r.stderr)
