@@ -495,7 +495,8 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_rcb_dec_kernel(
                 cnt += rn ? 1u : 0u;
             }
             // both children are requested before this bit is known (not below the last level)
-            const u32 c0 = (a << 1) + negm;                    // row 2*ctx
+            u32 c0;                                            // row 2*ctx (one v_lshl_add_u32: the compiler made a shift and a subtract of it)
+            asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(c0) : "v"(a), "v"(negm));
             u32 pl = 0, pr = 0;
             if (k < 7) { pl = trc_ldsr16(RCB_A(c0)); pr = trc_ldsr16(RCB_A(c0) + 128u); }
             const u32 slo = __builtin_amdgcn_alignbit(rhi, rlo, TRC_PROB_BITS), shi = rhi >> TRC_PROB_BITS;
