@@ -478,7 +478,7 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_ansa_dec_kernel(
         NibTable T = m.load(tb);
         u32 c0, c1;
         const u32 x = trc_nib_find(T, slot, c0, c1);
-        s = act ? __umul24(c1 - c0, s >> TRC_PROB_BITS) + slot - c0 : s;
+        s = (NIB ? act : true) ? __umul24(c1 - c0, s >> TRC_PROB_BITS) + slot - c0 : s;      // (byte coder: lanes that are not decoding run along, see trc_rc_adaptive.hip)
         m.adapt(T, x); m.store(tb, T);
         return x;
     };
@@ -490,13 +490,13 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_ansa_dec_kernel(
         const u32 slot = s & (TRC_PROB_ONE - 1);
         u32 c0, c1;
         const u32 x = trc_nib_find(T0, slot, c0, c1);
-        s = act ? __umul24(c1 - c0, s >> TRC_PROB_BITS) + slot - c0 : s;
+        s = (NIB ? act : true) ? __umul24(c1 - c0, s >> TRC_PROB_BITS) + slot - c0 : s;
         m.adapt(T0, x);
         return x;
     };
     auto renorm = [&](u32 &s, bool act) {
         const u32 w = si.peek16();
-        const bool rn = act && s < TRC_ANS_LOW;
+        const bool rn = (NIB ? act : true) && s < TRC_ANS_LOW;
         s = rn ? (s << 16) | w : s;
         si.skip_if(rn);
     };

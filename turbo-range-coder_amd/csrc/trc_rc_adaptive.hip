@@ -324,10 +324,13 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_rca_dec_kernel(
     // trips out of every byte (one wave per SIMD: nothing else hides them).
     NibTable T0 = m.load(m.table(0));
     // a symbol of a pair: `w` is the pair's look-ahead word, the return value's bit 4 says "renormalised"
+    // (byte coders: no predication on `act`.  A lane that is not decoding -- raw chunk, dead lane, past the end of a short last
+    // chunk -- runs along on its own registers, its own model row and whatever its clamped stream window holds; nothing of it is
+    // observable: its bytes are overwritten by the raw copy or never stored.  Four selects and a mask operation per symbol less.)
     auto get0 = [&](RcDec &dq, u32 w, bool act) -> u32 {
         u32 c0, c1;
         const u32 x = trc_nib_search(T0, dq.scaled(), c0, c1);
-        const bool rn = dq.consume_w(act, c0, c1, w);
+        const bool rn = dq.consume_w(NIB ? act : true, c0, c1, w);
         m.adapt(T0, x);
         return x | (rn ? 16u : 0u);
     };
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_rca_dec_kernel(
         NibTable T = m.load(tb);
         u32 c0, c1;
         const u32 x = trc_nib_search(T, dq.scaled(), c0, c1);  // == first i with t[i+1]*r > code, else 15 (cdflget16)
-        const bool rn = dq.consume_w(act, c0, c1, w);
+        const bool rn = dq.consume_w(NIB ? act : true, c0, c1, w);
         m.adapt(T, x); m.store(tb, T);
         return x | (rn ? 16u : 0u);
     };
