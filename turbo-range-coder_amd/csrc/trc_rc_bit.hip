@@ -488,7 +488,10 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_rcb_dec_kernel(
                         cnt = cnt == 2u ? 0u : cnt;
                     }
                 }
-                const bool rn = act && rhi == 0u;
+                // (no predication on `act`: a lane that is not decoding -- raw chunk, dead lane, past the end of a short last chunk -- runs
+                // along on its own registers, its own model column and whatever its clamped stream window holds, statistically like any
+                // other lane; nothing of it is observable.  An `act &&` here is a mask operation between the compare and five selects.)
+                const bool rn = rhi == 0u;
                 rhi = rn ? rlo : rhi; rlo = rn ? 0u : rlo;
                 chi = rn ? clo : chi; clo = rn ? w0 : clo;
                 w0 = rn ? w1 : w0;
@@ -533,10 +536,9 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_rcb_dec_kernel(
             if (__ballot(coded && p0 < len)) {
 #pragma nounroll
                 for (u32 d = 0; d < 4; d++) {
-                    const u32 q0 = p0 + d * 4u;
                     u32 w = 0;
 #pragma nounroll
-                    for (u32 i = 0; i < 4; i++) w |= get_byte(coded && q0 + i < len) << (8 * i);
+                    for (u32 i = 0; i < 4; i++) w |= get_byte(true) << (8 * i);
                     v.x = v.y; v.y = v.z; v.z = v.w; v.w = w;
                 }
                 if (coded && p0 < len && p0 + 16u > len) {      // ragged end of the last chunk: byte stores
