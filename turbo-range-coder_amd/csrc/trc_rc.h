@@ -128,6 +128,61 @@ struct RcEncD {
     }
 };
 
+// RcEncD once more for the CODER WAVES of round 4 (trc_rca_enc_mc_kernel): the same arithmetic with its books on the vector side.
+// With one or two other waves on the SIMD a coder wave's time is still made of its dependency chains, and every Boolean that the
+// compiler keeps as a lane mask (carry flag, "renormalised", "a word is pending", the predicate "this lane is coding") is an SGPR
+// operation between a vector compare and the selects that wait for it (profiles/r04_notes.md, sections 8 and 12).  Here the state is
+// four 32-bit halves plus a carry limb `lx` fed by the add's carry-out, the pending word's flags are integers, and `sym<false>` carries
+// no predicate at all: a lane that is not coding runs along on its own registers, and the caller keeps it from emitting.
+struct RcEncV {
+    u32 rlo, rhi, llo, lhi, lx;          // range, low, carry limb of low (0 / 1)
+    u32 pend, pcy, pw;                   // a word waits for flush(): its carry flag and itself
+    TrcCarry cw;
+    __device__ __forceinline__ void start() { rlo = rhi = ~0u; llo = lhi = lx = 0; pend = pcy = pw = 0; cw.start(); }
+    template <bool PRED>
+    __device__ __forceinline__ void sym(bool act, u32 c0, u32 f)        // _rccdfenc_ + renorm; PRED: nothing where !act
+    {
+        const u32 slo = __builtin_amdgcn_alignbit(rhi, rlo, TRC_PROB_BITS), shi = rhi >> TRC_PROB_BITS;      // r = range >> 15 (49 bits)
+        const u32 cc = PRED ? (act ? c0 : 0u) : c0;
+        const u64 p64 = (u64)slo * cc;                                   // low += r * c0 (< 2^64)
+        const u32 plo = (u32)p64, phi = __umul24(shi, cc) + (u32)(p64 >> 32);
+        u32 k1, k2, k3;
+        llo = __builtin_addc(llo, plo, 0u, &k1);
+        lhi = __builtin_addc(lhi, phi, k1, &k2);
+        lx = __builtin_addc(lx, 0u, k2, &k3);
+        const u64 q64 = (u64)slo * f;                                    // range = r * freq
+        const u32 qlo = (u32)q64, qhi = __umul24(shi, f) + (u32)(q64 >> 32);
+        const bool rn = PRED ? (act && qhi == 0u) : qhi == 0u;           // range < 2^32: the top word of low goes out
+        pw = rn ? lhi : pw; pcy = rn ? lx : pcy; pend = rn ? 1u : pend;
+        lx = rn ? 0u : lx; lhi = rn ? llo : lhi; llo = rn ? 0u : llo;
+        const u32 nrh = rn ? qlo : qhi, nrl = rn ? 0u : qlo;
+        rhi = PRED ? (act ? nrh : rhi) : nrh; rlo = PRED ? (act ? nrl : rlo) : nrl;
+    }
+    // after every second symbol (two consecutive symbols cannot both renormalise, see RcEncD): the pending word, where `on`
+    template <class SO>
+    __device__ __forceinline__ void flush(SO &so, bool on)
+    {
+        cw.emit_if(so, pend != 0u && on, pcy != 0u, pw);
+        pend = pcy = 0;
+    }
+    template <class SO>
+    __device__ __forceinline__ void finish(SO &so)                      // rceflush, then release everything still held back
+    {
+        u64 low = ((u64)lhi << 32) | llo, range = ((u64)rhi << 32) | rlo;
+        bool c0 = lx != 0u;
+        if (range < TRC_TOP32) { cw.emit(so, c0, (u32)(low >> 32)); low <<= 32; range <<= 32; c0 = false; }
+        if (range > ((u64)1 << 33)) {
+            const u64 nl = low + TRC_TOP32;
+            cw.emit(so, c0 || nl < low, (u32)(nl >> 32));
+        } else {
+            const u64 nl = low + 1;
+            cw.emit(so, c0 || nl < low, (u32)(nl >> 32));
+            cw.emit(so, false, (u32)nl);
+        }
+        cw.release(so);
+    }
+};
+
 struct RcDec {
     u64 range, code;
     __device__ __forceinline__ void start(u32 w0, u32 w1) { range = ~(u64)0; code = ((u64)w0 << 32) | w1; }

@@ -22,6 +22,7 @@
 // first the model walks them and leaves {cdf_lo, freq} records in registers (pure packed-16 VALU + LDS, no
 // dependence on the coder state), then the range coder consumes the records with predicated, branch-free steps.
 #include <stdlib.h>
+#include <type_traits>
 #include "trc_rc.h"
 #include "trc_lane_io.h"
 #include "trc_nibmodel.h"
@@ -237,28 +238,44 @@ __global__ __launch_bounds__(192 * TRC_WPG) void trc_rca_enc_mc_kernel(
     LaneOutDirect o0, o1;
     o0.start(scratch + (u64)c * stride + (NS == 2 ? 4u : 0u));
     o1.start(NS == 2 ? scratch2 + (u64)c * stride2 : scratch);
-    RcEncD e0, e1; e0.start(); e1.start();
+    RcEncV e0, e1; e0.start(); e1.start();
     bool ovf = alive && NS == 1 && lim <= 0;
+    // A lane codes without a predicate (RcEncV::sym<false>).  The one lane of the grid whose chunk is short ends before its wave
+    // does: in the period in which some lane's chunk ends (wave-uniform; also the last period of every full chunk) the symbols are
+    // predicated, the ending lanes' coder states are set aside (`done`, snapshots) and given back before finish(); what such a lane
+    // computes afterwards is observed by nobody (flush() is gated by `run`).
+    bool done = false;
+    u32 s0a = 0, s0b = 0, s0c = 0, s0d = 0, s0e = 0, s1a = 0, s1b = 0, s1c = 0, s1d = 0, s1e = 0;
 
     auto code_period = [&](u32 q0, u32 buf) __attribute__((always_inline)) {
-        if (!__ballot(alive && !ovf && q0 < len)) return;
+        if (!__ballot(alive && !ovf && !done && q0 < len)) return;
         const u32 a = qa + buf * 2048u;
         const uint4 ra = trc_ldsr128(a), rb = trc_ldsr128(a + 1024u);          // four hi records, four lo records
         const u32 rc[8] = { ra.x, rb.x, ra.y, rb.y, ra.z, rb.z, ra.w, rb.w };
 #ifdef RCA_ABL_NOCODER                                          // timing ablation: the coder wave only keeps the barriers company
         o0.wpos += rc[0] & rc[7] & 4u; return;
 #endif
-        const bool run = alive && !ovf;
+        const bool run = alive && !ovf && !done;
+        auto body = [&](auto pred) __attribute__((always_inline)) {
+            constexpr bool PRED = decltype(pred)::value;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const bool act = run && q0 + (u32)i < len;
-            e0.sym_rec(act, rc[2 * i] >> TRC_PROB_BITS, rc[2 * i] & 0x7fffu);
-            if (NS == 1) { e0.sym_rec(act, rc[2 * i + 1] >> TRC_PROB_BITS, rc[2 * i + 1] & 0x7fffu); e0.flush(o0); }
-            else {
-                e1.sym_rec(act, rc[2 * i + 1] >> TRC_PROB_BITS, rc[2 * i + 1] & 0x7fffu);
-                if (i & 1) { e0.flush(o0); e1.flush(o1); }
+            for (int i = 0; i < 4; i++) {
+                const bool act = run && q0 + (u32)i < len;
+                e0.template sym<PRED>(act, rc[2 * i] >> TRC_PROB_BITS, rc[2 * i] & 0x7fffu);
+                if (NS == 1) { e0.template sym<PRED>(act, rc[2 * i + 1] >> TRC_PROB_BITS, rc[2 * i + 1] & 0x7fffu); e0.flush(o0, run); }
+                else {
+                    e1.template sym<PRED>(act, rc[2 * i + 1] >> TRC_PROB_BITS, rc[2 * i + 1] & 0x7fffu);
+                    if (i & 1) { e0.flush(o0, run); e1.flush(o1, run); }
+                }
             }
-        }
+        };
+        if (__ballot(run && q0 < len && q0 + 4u >= len)) {     // some lane's chunk ends in this period
+            body(std::integral_constant<bool, true>());
+            const bool now = run && q0 + 4u >= len;
+            s0a = now ? e0.rlo : s0a; s0b = now ? e0.rhi : s0b; s0c = now ? e0.llo : s0c; s0d = now ? e0.lhi : s0d; s0e = now ? e0.lx : s0e;
+            s1a = now ? e1.rlo : s1a; s1b = now ? e1.rhi : s1b; s1c = now ? e1.llo : s1c; s1d = now ? e1.lhi : s1d; s1e = now ? e1.lx : s1e;
+            done = done || now;
+        } else body(std::integral_constant<bool, false>());
         if (NS == 1) ovf = ovf || (run && q0 < len && (int)(4u * e0.cw.nwords) >= lim);
         else ovf = ovf || (run && q0 + 4u <= len &&
                            ((int)(off1 + 4u * e1.cw.nwords) >= lim || 4u + 4u * e0.cw.nwords >= off1));
@@ -272,6 +289,10 @@ __global__ __launch_bounds__(192 * TRC_WPG) void trc_rca_enc_mc_kernel(
             if (p < P) trc_lds_barrier();
             buf ^= 1u;
         }
+    }
+    if (done) {                                                // the states as they were when the chunk ended
+        e0.rlo = s0a; e0.rhi = s0b; e0.llo = s0c; e0.lhi = s0d; e0.lx = s0e;
+        e1.rlo = s1a; e1.rhi = s1b; e1.llo = s1c; e1.lhi = s1d; e1.lx = s1e;
     }
     u32 out_len = 0;
     if (alive) {
