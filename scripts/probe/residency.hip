@@ -69,6 +69,13 @@ int main(int argc, char **argv)
     }
     std::map<unsigned, unsigned> shist;
     for (auto &kv : per_simd) shist[kv.second]++;
+    // which waves of a workgroup share a SIMD?  pairs[d] = workgroups' wave pairs (w, w + d) found on the same SIMD
+    unsigned pairs[16] = {0}, wgs_seen = 0;
+    if (wpg > 1) for (unsigned g = 0; g < wgs; g++) {
+        wgs_seen++;
+        for (unsigned a = 0; a < wpg; a++) for (unsigned b = a + 1; b < wpg; b++)
+            if (((h[g * wpg + a].hw >> 4) & 3) == ((h[g * wpg + b].hw >> 4) & 3)) pairs[b - a]++;
+    }
     std::map<unsigned, unsigned> hist;
     for (auto &kv : per_cu) hist[kv.second]++;
     printf("wgs %u x %u threads, lds %u B (prior launch: lds %u, %u threads): occupancy API says %d per CU; waves resident together %u, late %u; "
@@ -78,6 +85,11 @@ int main(int argc, char **argv)
     for (auto &kv : hist) printf("%u CUs x %u, ", kv.second, kv.first);
     printf("\n  SIMDs seen %zu of 1024; waves per SIMD (first round): ", per_simd.size());
     for (auto &kv : shist) printf("%u SIMDs x %u, ", kv.second, kv.first);
+    if (wpg > 1) {
+        printf("\n  waves of a workgroup on the same SIMD, by distance in the workgroup: ");
+        for (unsigned d = 1; d < wpg && d < 16; d++) printf("+%u: %u  ", d, pairs[d]);
+        printf("(of %u workgroups)", wgs_seen);
+    }
     printf("\n  per XCD: ");
     for (auto &kv : per_xcc) printf("%u:%u ", kv.first, kv.second);
     printf("\n");
