@@ -342,13 +342,24 @@ __global__ __launch_bounds__(128 * TRC_WPG) void trc_rcb_enc_mc_kernel(
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             {
-                const bool rn = rhi == 0u;
-                rnb = rnb + rnb + (rn ? 1u : 0u);
-                cyb = cyb + cyb + (rn ? lx : 0u);
-                pwj[j] = lhi; pw = rn ? lhi : pw;
-                lx = rn ? 0u : lx;
-                lhi = rn ? llo : lhi; llo = rn ? 0u : llo;
-                rhi = rn ? rlo : rhi; rlo = rn ? 0u : rlo;
+                // rn = (rhi == 0) as the borrow of rhi - 1; everything that hangs on it is carry chain or bit-select (hand-written:
+                // the compiler's form is a compare into an SGPR pair, ten selects on it and the wait states between them)
+                u32 mr, t, lhin;
+                pwj[j] = lhi;
+                asm("v_subrev_co_u32_e32 %1, vcc, 1, %7\n\t"
+                    "v_subb_co_u32_e64 %0, vcc, 0, 0, vcc\n\t"        // mr = -rn, VCC = rn
+                    "v_addc_co_u32_e32 %3, vcc, %3, %3, vcc\n\t"      // rnb = 2 rnb + rn
+                    "v_and_b32_e32 %1, %0, %6\n\t"
+                    "v_lshl_add_u32 %4, %4, 1, %1\n\t"                // cyb = 2 cyb + (rn ? lx : 0)
+                    "v_bfi_b32 %5, %0, %10, %5\n\t"                   // pw = rn ? lhi : pw
+                    "v_bfi_b32 %6, %0, 0, %6\n\t"                     // lx = rn ? 0 : lx
+                    "v_bfi_b32 %2, %0, %9, %10\n\t"                   // lhi = rn ? llo : lhi
+                    "v_bfi_b32 %9, %0, 0, %9\n\t"                     // llo = rn ? 0 : llo
+                    "v_bfi_b32 %7, %0, %8, %7\n\t"                    // rhi = rn ? rlo : rhi
+                    "v_bfi_b32 %8, %0, 0, %8"                           // rlo = rn ? 0 : rlo
+                    : "=&v"(mr), "=&v"(t), "=&v"(lhin), "+v"(rnb), "+v"(cyb), "+v"(pw), "+v"(lx), "+v"(rhi), "+v"(rlo), "+v"(llo)
+                    : "v"(lhi) : "vcc");
+                lhi = lhin;
             }
 #pragma unroll
             for (int h = 0; h < 2; h++) {
@@ -357,13 +368,20 @@ __global__ __launch_bounds__(128 * TRC_WPG) void trc_rcb_enc_mc_kernel(
                 const u32 slo = __builtin_amdgcn_alignbit(rhi, rlo, TRC_PROB_BITS), shi = rhi >> TRC_PROB_BITS;
                 const u64 c64 = (u64)slo * prob;
                 const u32 clo = (u32)c64, chi = __umul24(shi, prob) + (u32)(c64 >> 32);
-                u32 k1, k2, k3;
-                llo = __builtin_addc(llo, rcb_bfi(m, 0u, clo), 0u, &k1);
-                lhi = __builtin_addc(lhi, rcb_bfi(m, 0u, chi), k1, &k2);
-                lx = __builtin_addc(lx, 0u, k2, &k3);              // (at most one carry between two renormalisations: lx is 0 or 1)
-                u32 b1, b2;
-                const u32 tlo = __builtin_subc(rlo, clo, 0u, &b1), thi = __builtin_subc(rhi, chi, b1, &b2);
-                rlo = rcb_bfi(m, clo, tlo); rhi = rcb_bfi(m, chi, thi);
+                // low += bit ? 0 : cut (carry into lx: at most one between two renormalisations), range = bit ? cut : range - cut;
+                // one block, the carry chains back to back (the compiler keeps an s_nop between its own v_add_co and v_addc)
+                u32 t0, t1;
+                asm("v_bfi_b32 %0, %7, 0, %8\n\t"
+                    "v_bfi_b32 %1, %7, 0, %9\n\t"
+                    "v_add_co_u32_e32 %2, vcc, %2, %0\n\t"
+                    "v_addc_co_u32_e32 %3, vcc, %3, %1, vcc\n\t"
+                    "v_addc_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
+                    "v_sub_co_u32_e32 %0, vcc, %5, %8\n\t"
+                    "v_subb_co_u32_e32 %1, vcc, %6, %9, vcc\n\t"
+                    "v_bfi_b32 %5, %7, %8, %0\n\t"
+                    "v_bfi_b32 %6, %7, %9, %1"
+                    : "=&v"(t0), "=&v"(t1), "+v"(llo), "+v"(lhi), "+v"(lx), "+v"(rlo), "+v"(rhi)
+                    : "v"(m), "v"(clo), "v"(chi) : "vcc");
             }
         }
     };
@@ -474,6 +492,7 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_rcb_dec_kernel(
     auto get_byte = [&](bool act) -> u32 {
         uint4 pre = si.prefetch();                             // the window behind the current one: taken in at the end of the byte
         u32 a = mcol + 128u;                                   // LDS address of the current node (row stride 128 B)
+        u32 c0 = mcol + 256u;                                  // row 2*ctx: the node's children
         u32 p = p1;
         u32 cnt = 0;                                           // words taken in this byte
 #pragma unroll
@@ -491,32 +510,52 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_rcb_dec_kernel(
                 // (no predication on `act`: a lane that is not decoding -- raw chunk, dead lane, past the end of a short last chunk -- runs
                 // along on its own registers, its own model column and whatever its clamped stream window holds, statistically like any
                 // other lane; nothing of it is observable.  An `act &&` here is a mask operation between the compare and five selects.)
-                const bool rn = rhi == 0u;
-                rhi = rn ? rlo : rhi; rlo = rn ? 0u : rlo;
-                chi = rn ? clo : chi; clo = rn ? w0 : clo;
-                w0 = rn ? w1 : w0;
-                cnt += rn ? 1u : 0u;
+                // rn = (rhi == 0) as the borrow of rhi - 1: mask and count from the carry chain, five bit-selects -- no SGPR mask
+                // (v_cmp + v_cndmask needs two wait states between them on gfx950 and the compiler made a branch of some of these)
+                u32 mr, t;
+                asm("v_subrev_co_u32_e32 %1, vcc, 1, %2\n\t"
+                    "v_subb_co_u32_e64 %0, vcc, 0, 0, vcc\n\t"
+                    "v_addc_co_u32_e32 %7, vcc, 0, %7, vcc\n\t"
+                    "v_bfi_b32 %2, %0, %3, %2\n\t"
+                    "v_bfi_b32 %3, %0, 0, %3\n\t"
+                    "v_bfi_b32 %4, %0, %5, %4\n\t"
+                    "v_bfi_b32 %5, %0, %6, %5\n\t"
+                    "v_bfi_b32 %6, %0, %8, %6"
+                    : "=&v"(mr), "=&v"(t), "+v"(rhi), "+v"(rlo), "+v"(chi), "+v"(clo), "+v"(w0), "+v"(cnt) : "v"(w1) : "vcc");
             }
-            // both children are requested before this bit is known (not below the last level)
-            u32 c0;                                            // row 2*ctx (one v_lshl_add_u32: the compiler made a shift and a subtract of it)
-            asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(c0) : "v"(a), "v"(negm));
+            // both children (row c0 = 2*ctx) are requested before this bit is known (not below the last level)
             u32 pl = 0, pr = 0;
             if (k < 7) { pl = trc_ldsr16(RCB_A(c0)); pr = trc_ldsr16(RCB_A(c0) + 128u); }
             const u32 slo = __builtin_amdgcn_alignbit(rhi, rlo, TRC_PROB_BITS), shi = rhi >> TRC_PROB_BITS;
             const u64 c64 = (u64)slo * p;
             const u32 cl = (u32)c64, ch = __umul24(shi, p) + (u32)(c64 >> 32);
-            u32 b1, b2, e1, e2;
-            const u32 dlo = __builtin_subc(clo, cl, 0u, &b1), dhi = __builtin_subc(chi, ch, b1, &b2);
-            const u32 tlo = __builtin_subc(rlo, cl, 0u, &e1), thi = __builtin_subc(rhi, ch, e1, &e2);
-            // the bit is the borrow of code - cut; everything that depends on it is a bit-select under its mask (written as
-            // ?: the compiler turned the group of selects into a divergent branch)
-            const u32 m = 0u - b2;                             // code < cut: all ones
-            rlo = (cl & m) | (tlo & ~m); rhi = (ch & m) | (thi & ~m);      // (lanes that are not decoding run along on their own
-            clo = (clo & m) | (dlo & ~m); chi = (chi & m) | (dhi & ~m);    //  registers and model column: only `act` lanes consume words)
-            const u32 t5 = (p | (m & 0xffff8000u)) >> 5;       // p - (bit << 15) in 32 bits (p < 2^15: the or is the add), then >> 5
-            trc_ldsw16(RCB_A(a), p - t5 + m);                  // rcb_adapt: p - (t5 + bit), 16 bits kept by the store
-            a = c0 | (m & 128u);                               // child 2*ctx + bit (bit 7 of c0 is clear)
-            p = (pr & m) | (pl & ~m);
+            // The bit is the borrow of code - cut.  It stays on the vector side: m = 0 - 0 - borrow (all ones for a 1) leaves the
+            // borrow in VCC, the adapted probability p - ((p | m & ~0x7fff) >> 5) - bit takes it from there, the child is
+            // c0 | (m & 128), the next row 2 * child.  Left to the compiler the borrow became an SGPR mask read by nine selects
+            // (v_cndmask), each group behind the wait states a vector-written mask needs on gfx950.
+            // The rest of the step sits in the same block: range - cut, the four bit-selects of the state.  (Between a compiler-made
+            // v_sub_co and its v_subb there is an s_nop -- the compiler keeps two wait states between a vector write of VCC and
+            // any vector read of it; the carry chain does not need them: parity tests on back-to-back pairs.)
+            u32 m, t5, t6, np, an, cn;
+            asm("v_sub_co_u32_e32 %0, vcc, %8, %10\n\t"             // code - cut
+                "v_subb_co_u32_e32 %1, vcc, %9, %11, vcc\n\t"
+                "v_subb_co_u32_e64 %2, vcc, 0, 0, vcc\n\t"          // m = -bit, VCC = bit
+                "v_bfi_b32 %8, %2, %8, %0\n\t"                      // code = bit ? code : code - cut
+                "v_bfi_b32 %9, %2, %9, %1\n\t"
+                "v_and_or_b32 %0, %2, %13, %12\n\t"
+                "v_lshrrev_b32_e32 %0, 5, %0\n\t"
+                "v_subb_co_u32_e32 %3, vcc, %12, %0, vcc\n\t"       // p - ((p | m & ~0x7fff) >> 5) - bit
+                "v_and_or_b32 %4, %2, %14, %15\n\t"                 // child
+                "v_lshl_add_u32 %5, %4, 1, %16\n\t"                 // its children's row
+                "v_sub_co_u32_e32 %0, vcc, %6, %10\n\t"             // range - cut
+                "v_subb_co_u32_e32 %1, vcc, %7, %11, vcc\n\t"
+                "v_bfi_b32 %6, %2, %10, %0\n\t"                     // range = bit ? cut : range - cut
+                "v_bfi_b32 %7, %2, %11, %1"
+                : "=&v"(t5), "=&v"(t6), "=&v"(m), "=&v"(np), "=&v"(an), "=&v"(cn), "+v"(rlo), "+v"(rhi), "+v"(clo), "+v"(chi)
+                : "v"(cl), "v"(ch), "v"(p), "s"(0xffff8000u), "s"(128u), "v"(c0), "v"(negm) : "vcc");
+            trc_ldsw16(RCB_A(a), np);                          // rcb_adapt: p - (t5 + bit), 16 bits kept by the store
+            a = an; c0 = cn;                                   // child 2*ctx + bit (bit 7 of c0 is clear) and its children's row
+            p = rcb_bfi(m, pr, pl);
         }
         p1 = trc_ldsr16(mcol + 128u);                          // node 1 as the next byte will find it
         si.advance_pre(cnt << 2, pre);                         // the stream moves once per byte
