@@ -475,36 +475,37 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_rcb_dec_kernel(
     const u64 off = trc_group_base(goff, gsum, wc.c0 >> 6) + ex;
     const bool coded = alive && cl != len;
 
-    LaneIn<4> si; si.prime(payload + off, coded, cl);
-    // rcbd_ (turborc_.h:447-452) on 32-bit halves: range = rhi:rlo, code = chi:clo (rcdinit: two words)
-    u32 rlo = ~0u, rhi = ~0u, chi, clo;
-    si.two_words(chi, clo);
-    si.advance(coded ? 8u : 0u);
-    // The stream side of a byte: two look-ahead words (w0 at the stream position, w1 behind it) are fetched once per byte; a
-    // renormalisation point takes w0 and moves w1 up -- no window select, no position arithmetic at the four points.  A byte
-    // that renormalises more than twice (>= 64 bits of range spent on <= 6 bits) refills behind a wave-uniform test.
-    u32 w0, w1;
-    si.two_words(w0, w1);
+    // rcbd_ (turborc_.h:447-452) on 32-bit halves: range = rhi:rlo, code = chi:clo (rcdinit: two words).
+    // The stream side of a byte: ONE 16-byte load from the lane's stream position at the start of the byte (W: the words at rpos,
+    // rpos + 4, + 8, + 12; requested ~1300 cycles before its first ordinary use).  Two look-ahead words w0 / w1 are carried in
+    // registers: a renormalisation point takes w0 and moves w1 up -- no window select, no position arithmetic at the four points;
+    // at the end of the byte the next pair is W[cnt], W[cnt + 1] (two bit-selects each).  A byte that renormalises more than
+    // twice (>= 64 bits of range spent on <= 6 bits) takes W.z / W.w behind a wave-uniform test; one that takes more than two
+    // words in all reloads behind another.  (Rounds 2-4 kept a 32-byte register window per lane, LaneIn: window refill, boundary
+    // test and two three-level selects were ~24 instructions per byte; this is ~11.)
+    const u8 *src = payload + off;
+    const u32 lim = cl;                                        // no load from beyond this stream offset (corrupt input: re-reads the end)
+    u32 rpos = 8u;
+    u32 rlo = ~0u, rhi = ~0u, chi, clo, w0, w1;
+    { const uint4 W0 = trc_ld16_a2(src); chi = W0.x; clo = W0.y; w0 = W0.z; w1 = W0.w; }
     u32 p1 = (u32)(TRC_PROB_ONE >> 1);                         // probability of node 1, read back at the end of every byte
 
     const u32 mcol = trc_lds_addr(smem) + lane * 2u;           // this lane's model column as an LDS byte address
     const u32 negm = 0u - mcol;
     auto get_byte = [&](bool act) -> u32 {
-        uint4 pre = si.prefetch();                             // the window behind the current one: taken in at the end of the byte
+        const uint4 W = trc_ld16_a2(src + trc_min(rpos, lim));
         u32 a = mcol + 128u;                                   // LDS address of the current node (row stride 128 B)
         u32 c0 = mcol + 256u;                                  // row 2*ctx: the node's children
         u32 p = p1;
         u32 cnt = 0;                                           // words taken in this byte
+        bool many = false;                                     // (wave-uniform) some lane may end the byte with more than two
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             if (!(k & 1)) {                                    // renorm before bits 7,5,3,1 only
                 if (k >= 4) {
-                    if (__ballot(cnt == 2u)) {                 // rare: both look-ahead words are gone
-                        si.advance(cnt == 2u ? 8u : 0u);
-                        pre = si.prefetch();                   // (the position moved: the prefetch must follow it)
-                        u32 n0, n1; si.two_words(n0, n1);
-                        w0 = cnt == 2u ? n0 : w0; w1 = cnt == 2u ? n1 : w1;
-                        cnt = cnt == 2u ? 0u : cnt;
+                    if (__ballot(cnt >= 2u)) {                 // rare: both look-ahead words are gone -- the window's upper half
+                        w0 = cnt == 2u ? W.z : w0; w1 = cnt == 2u ? W.w : w1;      // (cnt == 3: W.w has moved up into w0 already)
+                        many = true;
                     }
                 }
                 // (no predication on `act`: a lane that is not decoding -- raw chunk, dead lane, past the end of a short last chunk -- runs
@@ -558,8 +559,15 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_rcb_dec_kernel(
             p = rcb_bfi(m, pr, pl);
         }
         p1 = trc_ldsr16(mcol + 128u);                          // node 1 as the next byte will find it
-        si.advance_pre(cnt << 2, pre);                         // the stream moves once per byte
-        si.two_words(w0, w1);
+        rpos += cnt << 2;                                      // the stream moves once per byte
+        {
+            const u32 m0 = (u32)__builtin_amdgcn_sbfe((int)cnt, 0, 1), m1 = (u32)__builtin_amdgcn_sbfe((int)cnt, 1, 1);
+            w0 = rcb_bfi(m1, W.z, rcb_bfi(m0, W.y, W.x)); w1 = rcb_bfi(m1, W.w, rcb_bfi(m0, W.z, W.y));
+        }
+        if (many && __ballot(cnt > 2u)) {                      // rare: the next pair lies behind W
+            const uint4 X = trc_ld16_a2(src + trc_min(rpos, lim));
+            w0 = cnt > 2u ? X.x : w0; w1 = cnt > 2u ? X.y : w1;
+        }
         return ((a + negm) >> 7) & 255u;
     };
 
