@@ -1,0 +1,15 @@
+#!/bin/bash
+# round 4: look-ahead registers instead of register windows in the rccdf / anscdf byte decoders; consume_w_m A/B
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
+L=gpurun_out/r04_lookahead_decoders.log
+b() { python bench.py --codec $1 --no-cpu --no-beyond 2>/dev/null | grep '^{' | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('$1', '$2', 'value', d['value'], 'ms', d['ms_per_step'], 'enc', r['enc_kernel_ms'], 'dec', r['dec_kernel_ms'])"; }
+{
+echo "### parity (rccdf / anscdf)"
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -m gpu -x -q -k "rccdf or anscdf or random or forms" 2>&1 | tail -3
+echo "### bench"
+for i in 1 2; do b rccdf; b rccdfi; b anscdf; done
+echo "### rccdf with the compiler's consume_w"
+for i in 1 2; do TRC_LIB=$PWD/turbo-range-coder_amd/build/ab/libconsume_bool.so b rccdf bool; done
+} > $L 2>&1
+cat $L

@@ -470,7 +470,9 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_ansa_dec_kernel(
     constexpr u32 NST = NIB ? 2u : 4u;
     u32 st[4] = { TRC_ANS_LOW, TRC_ANS_LOW, TRC_ANS_LOW, TRC_ANS_LOW };
     if (coded) for (u32 k = 0; k < NST; k++) st[k] = trc_ld32_a2(payload + off + 4u * k);   // decoder st[i] = encoder st[NST-1-i] (mnfill)
-    LaneInWide si; si.prime(payload + off + 4u * NST, coded, trc_sub_sat(cl, 4u * NST));   // words follow the states
+    LaneInWide si; si.prime(payload + off + 4u * NST, coded && NIB, trc_sub_sat(cl, 4u * NST));   // words follow the states
+    LaneLook16 sl;                                             // (the byte coder's stream side: trc_lane_io.h)
+    if (!NIB) sl.prime(payload + off + 4u * NST, trc_sub_sat(cl, 4u * NST));
 
     // cdf16ansdec: search + state update + model update; the renorm comes separately (its order is the word order)
     auto get_nibble = [&](u32 &s, u8 *tb, bool act) -> u32 {
@@ -519,11 +521,12 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_ansa_dec_kernel(
 #pragma unroll
                         for (int j = 0; j < 2; j++) {          // mndec8x2: two bytes, then four renorms in order st0..st3
                             const bool act = coded && q0 + 2u * (u32)j < len;     // the second byte of an odd tail is the dummy
-                            const uint4 pre = si.prefetch();   // (<= 8 stream bytes per group: trc_lane_io.h LaneInWide)
+                            const uint4 W = sl.fetch();        // (<= 8 stream bytes per group: trc_lane_io.h LaneLook16)
                             const u32 h0 = get_hi(st[0], act), l0 = get_nibble(st[1], m.table(1u + h0), act);
                             const u32 h1 = get_hi(st[2], act), l1 = get_nibble(st[3], m.table(1u + h1), act);
-                            renorm(st[0], act); renorm(st[1], act); renorm(st[2], act); renorm(st[3], act);
-                            si.end_step(pre);
+                            u32 cnt = 0;
+                            sl.renorm<0>(st[0], cnt); sl.renorm<1>(st[1], cnt); sl.renorm<2>(st[2], cnt); sl.renorm<3>(st[3], cnt);
+                            sl.end_group(cnt, W);
                             w |= ((h0 << 4 | l0) | (h1 << 4 | l1) << 8) << (16 * j);
                         }
                     } else {

@@ -162,3 +162,101 @@ struct LaneInWide {
     }
 };
 
+// Round 4, the rANS byte decoders (four renormalisation points per group of two bytes, in stream order): the next FOUR 16-bit units
+// of the lane's stream ride in two registers (l0 = units 0-1, l1 = units 2-3).  A point takes the low half of l0 and moves the rest
+// down where it fires -- mask and count come off the carry chain of `state - 2^15`, the moves are bit-selects, and a point only
+// moves what the points behind it can still reach (point 3 moves nothing).  One 16-byte load per group, from the stream position at
+// the START of the group (units 0-7): the group consumes cnt <= 4 units, so the next look-ahead is units cnt .. cnt + 3 of it, taken
+// out at the end of the group with a three-level bit-select.  LaneInWide's peek (a three-level select of a 32-byte register window
+// per POINT) and window move were ~37 instructions per byte of the decoder's ~165; this is ~22.
+struct LaneLook16 {
+    const u8 *src;       // this lane's stream (2-byte aligned; the payload buffer carries TRC_PAD bytes of slack)
+    u32 rpos;            // bytes consumed
+    u32 lim;             // no bytes are fetched from beyond this stream offset (a corrupt stream re-reads its end)
+    u32 l0, l1;          // the four units at rpos
+
+    __device__ __forceinline__ void prime(const u8 *s, u32 limit)
+    {
+        src = s; rpos = 0; lim = limit;
+        const uint4 q = trc_ld16_a2(src);
+        l0 = q.x; l1 = q.y;
+    }
+    __device__ __forceinline__ uint4 fetch() const { return trc_ld16_a2(src + trc_min(rpos, lim)); }
+    // ecdnorm (anscdf_.h:51-73) at point J of the group: if (st < 2^15) st = st << 16 | next unit
+    template <int J>
+    __device__ __forceinline__ void renorm(u32 &st, u32 &cnt)
+    {
+        u32 m, t;
+        const u32 sel = 0x05040100u;                            // v_perm: { st.b1, st.b0, l0.b1, l0.b0 } = st << 16 | unit
+        if (J == 0)
+            asm("v_subrev_co_u32_e32 %1, vcc, 0x8000, %2\n\t"
+                "v_subb_co_u32_e64 %0, vcc, 0, 0, vcc\n\t"
+                "v_addc_co_u32_e32 %3, vcc, 0, %3, vcc\n\t"
+                "v_perm_b32 %1, %2, %4, %6\n\t"
+                "v_bfi_b32 %2, %0, %1, %2\n\t"
+                "v_alignbit_b32 %1, %5, %4, 16\n\t"
+                "v_bfi_b32 %4, %0, %1, %4\n\t"
+                "v_lshrrev_b32_e32 %1, 16, %5\n\t"
+                "v_bfi_b32 %5, %0, %1, %5"
+                : "=&v"(m), "=&v"(t), "+v"(st), "+v"(cnt), "+v"(l0), "+v"(l1) : "s"(sel) : "vcc");
+        else if (J == 1)
+            asm("v_subrev_co_u32_e32 %1, vcc, 0x8000, %2\n\t"
+                "v_subb_co_u32_e64 %0, vcc, 0, 0, vcc\n\t"
+                "v_addc_co_u32_e32 %3, vcc, 0, %3, vcc\n\t"
+                "v_perm_b32 %1, %2, %4, %6\n\t"
+                "v_bfi_b32 %2, %0, %1, %2\n\t"
+                "v_alignbit_b32 %1, %5, %4, 16\n\t"
+                "v_bfi_b32 %4, %0, %1, %4"
+                : "=&v"(m), "=&v"(t), "+v"(st), "+v"(cnt), "+v"(l0) : "v"(l1), "s"(sel) : "vcc");
+        else if (J == 2)
+            asm("v_subrev_co_u32_e32 %1, vcc, 0x8000, %2\n\t"
+                "v_subb_co_u32_e64 %0, vcc, 0, 0, vcc\n\t"
+                "v_addc_co_u32_e32 %3, vcc, 0, %3, vcc\n\t"
+                "v_perm_b32 %1, %2, %4, %5\n\t"
+                "v_bfi_b32 %2, %0, %1, %2\n\t"
+                "v_lshrrev_b32_e32 %1, 16, %4\n\t"
+                "v_bfi_b32 %4, %0, %1, %4"
+                : "=&v"(m), "=&v"(t), "+v"(st), "+v"(cnt), "+v"(l0) : "s"(sel) : "vcc");
+        else
+            asm("v_subrev_co_u32_e32 %1, vcc, 0x8000, %2\n\t"
+                "v_subb_co_u32_e64 %0, vcc, 0, 0, vcc\n\t"
+                "v_addc_co_u32_e32 %3, vcc, 0, %3, vcc\n\t"
+                "v_perm_b32 %1, %2, %4, %5\n\t"
+                "v_bfi_b32 %2, %0, %1, %2"
+                : "=&v"(m), "=&v"(t), "+v"(st), "+v"(cnt) : "v"(l0), "s"(sel) : "vcc");
+    }
+    // the group took cnt (0..4) units; W = fetch() of the group's start
+    __device__ __forceinline__ void end_group(u32 cnt, const uint4 W)
+    {
+        rpos += cnt << 1;
+        const u32 m0 = (u32)__builtin_amdgcn_sbfe((int)cnt, 0, 1), m1 = (u32)__builtin_amdgcn_sbfe((int)cnt, 1, 1), m2 = (u32)__builtin_amdgcn_sbfe((int)cnt, 2, 1);
+        const u32 a0 = trc_bfi(m2, W.z, W.x), a1 = trc_bfi(m2, W.w, W.y), a2 = W.z;
+        const u32 b0 = trc_bfi(m1, a1, a0), b1 = trc_bfi(m1, a2, a1), b2 = trc_bfi(m1, W.w, a2);
+        l0 = trc_bfi(m0, __builtin_amdgcn_alignbit(b1, b0, 16), b0);
+        l1 = trc_bfi(m0, __builtin_amdgcn_alignbit(b2, b1, 16), b1);
+    }
+};
+
+// The same for the range decoders of the byte coders (32-bit words, at most two per group of two bytes): the two words at the stream
+// position ride in registers, one 16-byte load per group, the next pair is W[cnt], W[cnt + 1].
+struct LaneLook32 {
+    const u8 *src;
+    u32 rpos, lim;
+    u32 w0, w1;          // the words at rpos and rpos + 4
+    // rcdinit's two words come back in a / b, the look-ahead starts behind them
+    __device__ __forceinline__ void prime(const u8 *s, u32 limit, u32 &a, u32 &b)
+    {
+        src = s; rpos = 8u; lim = limit;
+        const uint4 q = trc_ld16_a2(src);
+        a = q.x; b = q.y; w0 = q.z; w1 = q.w;
+    }
+    __device__ __forceinline__ uint4 fetch() const { return trc_ld16_a2(src + trc_min(rpos, lim)); }
+    __device__ __forceinline__ void end_group(u32 cnt, const uint4 W)      // cnt = 0, 1, 2 words taken
+    {
+        rpos += cnt << 2;
+        const u32 m0 = (u32)__builtin_amdgcn_sbfe((int)cnt, 0, 1), m1 = (u32)__builtin_amdgcn_sbfe((int)cnt, 1, 1);
+        w0 = trc_bfi(m1, W.z, trc_bfi(m0, W.y, W.x));
+        w1 = trc_bfi(m1, W.w, trc_bfi(m0, W.z, W.y));
+    }
+};
+
