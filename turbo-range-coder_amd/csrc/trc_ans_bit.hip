@@ -182,34 +182,37 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_ansb_dec_kernel(
 
     u32 st[4] = { TRC_ANS_LOW, TRC_ANS_LOW, TRC_ANS_LOW, TRC_ANS_LOW };
     if (coded) for (u32 k = 0; k < 4; k++) st[k] = trc_ld32_a2(payload + off + 4u * k);   // decoder st[i] = encoder st[3-i]
-    LaneInWide si; si.prime(payload + off + 16u, coded, trc_sub_sat(cl, 16u));   // <= 8 stream bytes per four bits (trc_lane_io.h)
+    // the stream side: four units of look-ahead in two registers, one 16-byte load per FOUR bits (<= 4 units), trc_lane_io.h LaneLook16
+    // (round 4; rounds 2-3 selected every unit out of a 32-byte register window: ten instructions per bit).  No predicate on "this
+    // lane is decoding": a lane that is not -- raw chunk, dead lane, past the end of a short last chunk -- runs along on its own
+    // registers and model column, nothing of it is stored.
+    LaneLook16 sl; sl.prime(payload + off + 16u, trc_sub_sat(cl, 16u));
 
-    auto get_byte = [&](bool act) -> u32 {
+    auto get_byte = [&](bool) -> u32 {
         u32 ctx = 1;
         u32 p = mb[64];
-        uint4 pre = si.prefetch();
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            if (j == 4) { si.end_step(pre); pre = si.prefetch(); }
-            // both children are requested before this bit is known (below the last level the index wraps, values unused)
-            const u32 lc = (2u * ctx) & 255u;
-            const u32 pl = mb[lc * 64], pr = mb[(lc + 1u) * 64];
-            u32 s = st[j & 3];
-            {                                                  // ecdnorm before the step
-                const u32 w = si.peek16();
-                const bool rn = act && s < TRC_ANS_LOW;
-                s = rn ? (s << 16) | w : s;
-                si.skip_if(rn);
+        for (int h = 0; h < 2; h++) {
+            const uint4 W = sl.fetch();
+            u32 cnt = 0;
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                const int j = 4 * h + jj;
+                // both children are requested before this bit is known (below the last level the index wraps, values unused)
+                const u32 lc = (2u * ctx) & 255u;
+                const u32 pl = mb[lc * 64], pr = mb[(lc + 1u) * 64];
+                u32 s = st[j & 3];
+                if (jj == 0) sl.renorm<0>(s, cnt); else if (jj == 1) sl.renorm<1>(s, cnt);      // ecdnorm before the step
+                else if (jj == 2) sl.renorm<2>(s, cnt); else sl.renorm<3>(s, cnt);
+                const u32 r = s & (TRC_PROB_ONE - 1), rcx = __umul24(s >> TRC_PROB_BITS, p);   // s >> 15 < 2^17, p < 2^15: the product fits 32 bits
+                const u32 m = (u32)((int)(r - p) >> 31);       // ecbd: bit = r < p, as a mask (r, p < 2^15); everything below selects under it
+                st[j & 3] = trc_bfi(m, rcx + r, s - rcx - p);
+                mb[ctx * 64] = (u16)ansb_adapt(p, m & 1u);
+                ctx = ctx * 2 - m;
+                p = trc_bfi(m, pr, pl);
             }
-            const u32 r = s & (TRC_PROB_ONE - 1), rcx = __umul24(s >> TRC_PROB_BITS, p);   // s >> 15 < 2^17, p < 2^15: the product fits 32 bits
-            const u32 m = (u32)((int)(r - p) >> 31);           // ecbd: bit = r < p, as a mask (r, p < 2^15); everything below selects under it
-            const u32 ns = trc_bfi(m, rcx + r, s - rcx - p);
-            st[j & 3] = act ? ns : s;
-            mb[ctx * 64] = (u16)ansb_adapt(p, m & 1u);
-            ctx = ctx * 2 - m;
-            p = trc_bfi(m, pr, pl);
+            sl.end_group(cnt, W);
         }
-        si.end_step(pre);
         return ctx & 255u;
     };
 

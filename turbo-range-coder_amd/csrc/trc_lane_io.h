@@ -258,5 +258,10 @@ struct LaneLook32 {
         w0 = trc_bfi(m1, W.z, trc_bfi(m0, W.y, W.x));
         w1 = trc_bfi(m1, W.w, trc_bfi(m0, W.z, W.y));
     }
+    __device__ __forceinline__ void end_group1(u32 cnt, const uint4 W)     // groups that take at most ONE word: only w0 is carried
+    {
+        rpos += cnt << 2;
+        w0 = trc_bfi((u32)__builtin_amdgcn_sbfe((int)cnt, 0, 1), W.y, W.x);
+    }
 };
 

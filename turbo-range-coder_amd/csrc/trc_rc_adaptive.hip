@@ -334,14 +334,19 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_rca_dec_kernel(
 
     LaneIn<4> s0, s1;
     const u32 len0 = (NS == 2 && coded) ? trc_min(trc_ld32_a2(payload + off), trc_sub_sat(cl, 4u)) : 0u;   // a corrupt header cannot point outside the chunk's payload
-    s0.prime(payload + off + (NS == 2 ? 4u : 0u), coded && !(!NIB && NS == 1), NS == 2 ? len0 : cl);
-    s1.prime(payload + off + 4u + len0, NS == 2 && coded, trc_sub_sat(cl, 4u + len0));
+    s0.prime(payload + off + (NS == 2 ? 4u : 0u), coded && NIB, NS == 2 ? len0 : cl);
+    s1.prime(payload + off + 4u + len0, NS == 2 && coded && NIB, trc_sub_sat(cl, 4u + len0));
     RcDec d0, d1;
-    constexpr bool LOOK = !NIB && NS == 1;                     // the byte coder's stream side: trc_lane_io.h LaneLook32
-    LaneLook32 sl;
-    if (LOOK) { u32 a, b; sl.prime(payload + off, cl, a, b); d0.start(a, b); }
-    else { const u32 a = s0.peek32(); s0.skip_if(coded); const u32 b = s0.peek32(); s0.skip_if(coded); d0.start(a, b); }
-    { const u32 a = s1.peek32(); s1.skip_if(NS == 2 && coded); const u32 b = s1.peek32(); s1.skip_if(NS == 2 && coded); d1.start(a, b); }
+    constexpr bool LOOK = !NIB;                                // the byte coders' stream side: trc_lane_io.h LaneLook32
+    LaneLook32 sl, sl1;
+    if (LOOK) {
+        u32 a, b;
+        sl.prime(payload + off + (NS == 2 ? 4u : 0u), NS == 2 ? len0 : cl, a, b); d0.start(a, b);
+        if (NS == 2) { sl1.prime(payload + off + 4u + len0, trc_sub_sat(cl, 4u + len0), a, b); d1.start(a, b); }
+    } else {
+        { const u32 a = s0.peek32(); s0.skip_if(coded); const u32 b = s0.peek32(); s0.skip_if(coded); d0.start(a, b); }
+        { const u32 a = s1.peek32(); s1.skip_if(NS == 2 && coded); const u32 b = s1.peek32(); s1.skip_if(NS == 2 && coded); d1.start(a, b); }
+    }
 
     // Table 0 (the hi-nibble table of the byte model, the only table of the nibble coders) is used at every step: it
     // lives in registers for the whole chunk and never travels to LDS, which takes two of the four dependent LDS round
@@ -408,13 +413,13 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_rca_dec_kernel(
 #pragma unroll
                         for (int pr = 0; pr < 2; pr++) {
                             const bool acta = coded && q0 + 2u * (u32)pr < len, actb = coded && q0 + 2u * (u32)pr + 1u < len;
-                            const uint4 pre0 = s0.prefetch(), pre1 = s1.prefetch();
-                            const u32 w0 = s0.peek32(), w1 = s1.peek32();
+                            const uint4 W0 = sl.fetch(), W1 = sl1.fetch();
+                            const u32 w0 = sl.w0, w1 = sl1.w0;
                             const u32 ha = get0(d0, w0, acta);
                             const u32 la = get(d1, w1, m.table(1u + (ha & 15u)), acta);
                             const u32 hb = get0(d0, w0, actb);
                             const u32 lb = get(d1, w1, m.table(1u + (hb & 15u)), actb);
-                            s0.advance_pre(((ha | hb) & 16u) >> 2, pre0); s1.advance_pre(((la | lb) & 16u) >> 2, pre1);
+                            sl.end_group1(((ha | hb) & 16u) >> 4, W0); sl1.end_group1(((la | lb) & 16u) >> 4, W1);
                             w |= (((ha & 15u) << 4 | (la & 15u)) | ((hb & 15u) << 4 | (lb & 15u)) << 8) << (16 * pr);
                         }
                     } else if (NS == 1) {
