@@ -194,13 +194,7 @@ __device__ __forceinline__ void ansa_put(u32 &st, u32 rec, StreamOut<true> &so, 
     const bool emit = act && st >= (f << 16);
     so.put16_if(emit, st);
     const u32 s1 = emit ? st >> 16 : st;
-    u32 q = (u32)((float)s1 * __builtin_amdgcn_rcpf((float)f));          // st/f within +-1 (garbage where !act: f may be 0)
-    u32 r = s1 - __umul24(q, f);                                         // q < 2^16+1, f < 2^15
-    const bool dn = (int)r < 0;
-    q -= dn ? 1u : 0u; r += dn ? f : 0u;
-    const bool up = r >= f;
-    q += up ? 1u : 0u; r -= up ? f : 0u;
-    st = act ? (q << TRC_PROB_BITS) + r + c0 : st;
+    st = act ? trc_rans_step(s1, f, TRC_PROB_ONE - f, c0) : st;          // (garbage where !act: f may be 0)
 }
 
 template <bool NIB>
@@ -416,13 +410,7 @@ __global__ __launch_bounds__(256) void trc_ansa_codeq_kernel(
                 trc_lds_write16(emit ? at : dummy, st);
                 so.wpos += 2u * tot;
                 const u32 s1 = emit ? st >> 16 : st;
-                u32 q = (u32)((float)s1 * __builtin_amdgcn_rcpf((float)f));           // st/f within +-1 (garbage where !go: f may be 0)
-                u32 rm = s1 - __umul24(q, f);
-                const u32 dn = (u32)((int)rm >> 31);                                  // all ones: one too many
-                q += dn; rm += dn & f;
-                const bool up = rm >= f;
-                q += up ? 1u : 0u; rm -= up ? f : 0u;
-                st = go ? (q << TRC_PROB_BITS) + rm + c0 : st;
+                st = go ? trc_rans_step(s1, f, TRC_PROB_ONE - f, c0) : st;            // (garbage where !go: f may be 0)
             }
             so.drain(false, alive);                            // <= 32 new bytes (16 records) per chunk
         }

@@ -17,7 +17,6 @@
 #include "trc_launch.h"
 
 #define ANSB_MODEL_BYTES (256u * 64u * 2u)                 // [ctx][lane] u16
-#define ANSB_CODE_LDS    (TRC_TILE_BYTES + TRC_SRING_BYTES)
 
 // bit 1: p += (2^15 - p) >> 5, bit 0: p -= p >> 5 -- as mask arithmetic (written as ?: the compiler made a divergent if / else of it,
 // eight per byte)
@@ -41,26 +40,38 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_ansb_model_kernel(
     wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
     wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
     WaveChunks wr = wc;                                        // the same chunks in record space (16 B per byte)
-    wr.chunk = 16u * chunk; wr.lastlen = 16u * wc.lastlen;
+    wr.chunk = 16u * chunk; wr.lastlen = 16u * ((wc.lastlen + 3u) & ~3u);     // whole groups of four bytes: a group's pieces are per STATE, not per byte
     const bool alive = lane < wc.rows;
     const u32 len = alive ? wc.len_of(lane) : 0u;
 
     QuadIn qin; qin.base = in + (u64)wc.c0 * chunk;
     QuadOut qout; qout.base = recs + (u64)wc.c0 * wr.chunk;
 
-    // one byte -> eight 16-bit records, packed two per dword in push order (bit 7 first)
+    // one byte -> eight 16-bit records (push order: bit 7 first), packed per rANS state: the last record pushed goes to state 0,
+    // dword s = record of push position 7 - s | record of position 3 - s << 16.  The two nodes of a dword adapt together in packed
+    // 16-bit arithmetic (bit 1: p += (2^15 - p) >> 5, bit 0: p -= p >> 5 under the halves' masks): 12 operations per pair, 18 as scalars.
+    typedef unsigned short trc_us2 __attribute__((ext_vector_type(2)));
     auto byte_records = [&](u32 x) -> uint4 {
         const u32 path = 0x100u | x;
         u32 r[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) r[k] = mb[(path >> (8 - k)) * 64];          // node of bit 7-k
+        const u32 y = x | x << 12;                             // bit s: the bit of position 7 - s, bit 16 + s: of position 3 - s
+        u32 D[4];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const u32 bit = (x >> (7 - k)) & 1u;
-            mb[(path >> (8 - k)) * 64] = (u16)ansb_adapt(r[k], bit);
-            r[k] |= bit << TRC_PROB_BITS;
+        for (int sidx = 0; sidx < 4; sidx++) {
+            const u32 P = r[7 - sidx] | r[3 - sidx] << 16;
+            const u32 B = (y >> sidx) & 0x10001u;
+            const u32 M = __umul24(B, 0xffffu), NM = ~M;       // all ones in the halves whose bit is 1
+            const trc_us2 t = __builtin_bit_cast(trc_us2, P ^ M) + __builtin_bit_cast(trc_us2, M & 0x80018001u);     // bit ? 2^15 - p : p
+            const u32 sft = __builtin_bit_cast(u32, t >> (trc_us2)5);
+            const trc_us2 np = __builtin_bit_cast(trc_us2, P) + (__builtin_bit_cast(trc_us2, sft ^ NM) - __builtin_bit_cast(trc_us2, NM));
+            const u32 NP = __builtin_bit_cast(u32, np);
+            mb[(path >> (1 + sidx)) * 64] = (u16)NP;           // node of position 7 - s
+            mb[(path >> (5 + sidx)) * 64] = (u16)(NP >> 16);   // node of position 3 - s
+            D[sidx] = P | B << TRC_PROB_BITS;
         }
-        return make_uint4(r[0] | r[1] << 16, r[2] | r[3] << 16, r[4] | r[5] << 16, r[6] | r[7] << 16);
+        return make_uint4(D[0], D[1], D[2], D[3]);
     };
 
     const u32 S = chunk / TRC_SEG;
@@ -77,8 +88,13 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_ansb_model_kernel(
 #pragma nounroll
             for (u32 d = 0; d < 4; d++) {                      // 4 input bytes -> 32 records = one 64-byte record segment
                 const u32 w = v.x; v.x = v.y; v.y = v.z; v.z = v.w;
+                // the coding pass works with four lanes per chunk, lane s on state s = push positions 7 - s and 3 - s of every
+                // byte: piece s of the segment holds exactly that lane's records, one dword per byte
+                uint4 R[4];
 #pragma unroll
-                for (int i = 0; i < 4; i++) qout.put((u32)i, byte_records((w >> (8 * i)) & 255u));
+                for (int i = 0; i < 4; i++) R[i] = byte_records((w >> (8 * i)) & 255u);
+                qout.put(0, make_uint4(R[0].x, R[1].x, R[2].x, R[3].x)); qout.put(1, make_uint4(R[0].y, R[1].y, R[2].y, R[3].y));
+                qout.put(2, make_uint4(R[0].z, R[1].z, R[2].z, R[3].z)); qout.put(3, make_uint4(R[0].w, R[1].w, R[2].w, R[3].w));
                 qout.flush(wr, (p0 + 4u * d) * 16u);           // (records of bytes past a ragged end are never read)
             }
         }
@@ -86,77 +102,91 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_ansb_model_kernel(
 }
 
 // ------------------------------------------------------------------------------ encode, pass 2 ---
-__device__ __forceinline__ void ansb_put(u32 &st, u32 rec, StreamOut<true> &so)
-{
-    const u32 bit = rec >> TRC_PROB_BITS, p0 = rec & (TRC_PROB_ONE - 1);
-    const u32 ls = bit ? p0 : TRC_PROB_ONE - p0;                         // ecbe_: the coded interval's width
-    const bool emit = st >= (ls << 16);
-    so.put16_if(emit, st);
-    st = emit ? st >> 16 : st;
-    u32 q = (u32)((float)st * __builtin_amdgcn_rcpf((float)ls));          // st/ls within +-1
-    u32 r = st - __umul24(q, ls);                                        // q < 2^16+1, ls < 2^15
-    if ((int)r < 0) { q--; r += ls; }
-    if (r >= ls) { q++; r -= ls; }
-    st = st + __umul24(q, TRC_PROB_ONE - ls) + (bit ? 0u : p0);
-}
-
-__global__ __launch_bounds__(64 * TRC_WPG) void trc_ansb_code_kernel(
+// Four lanes per chunk (round 4; the scheme of trc_ansa_codeq_kernel, trc_ans_adaptive.hip): the four rANS states of ansbc are
+// independent chains that share the ORDER of their 16-bit words.  Lanes 4i .. 4i + 3 take chunk i of the wave, lane s state s;
+// a step is four consecutive records (descending record order = ascending lane order: the last record pushed is state 0's), the
+// quad's emit flags come from one __ballot, a lane's word goes to the shared stream position + 2 x (emits of the lanes before it)
+// in the chunk's ring (StreamOut<DOWN, false, QUAD>), a lane with nothing to store writes to its own dummy slot.  The model pass
+// leaves every lane's records contiguous (16 B per four input bytes), so they come straight from HBM into registers.
+// ecbe_ (anscdf.c:659-668) is a plain rANS step with frequency ls = bit ? p : 2^15 - p and start bit ? 0 : p; its divisor is
+// different every bit: f32 estimate + exact correction (st < 2^31).  Raw rule: words + 16 >= len (the reference has no test
+// before the end of a block; the words only grow, so a chunk that is there already stops coding).
+#define ANSBQ_WAVE_LDS  (16u * TRC_SRING_STRIDE + 256u)        // 16 rings + 16 x 4 dummy slots
+#define ANSBQ_LDS       (4u * ANSBQ_WAVE_LDS + 16u)
+__global__ __launch_bounds__(256) void trc_ansb_codeq_kernel(
     const u8 *__restrict__ recs, u64 n, u32 chunk, u32 nchunks,
     u8 *__restrict__ scratch, u32 stride, u32 *__restrict__ clen, u32 *__restrict__ gsum)
 {
-    TRC_QUAD_PROLOGUE(ANSB_CODE_LDS);
-    WaveChunks wc;
-    wc.c0 = grp_ * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
-    wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
-    wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
-    WaveChunks wr = wc; wr.chunk = 16u * chunk; wr.lastlen = 16u * wc.lastlen;
-    const bool alive = lane < wc.rows;
-    const u32 c = wc.c0 + lane;
-    const u32 len = alive ? wc.len_of(lane) : 0u;
+    extern __shared__ __attribute__((aligned(16))) u8 smem_wg_[];
+    const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const u32 lane = trc_lane(), s = lane & 3u, ci = lane >> 2;
+    u8 *const smem = smem_wg_ + wv * ANSBQ_WAVE_LDS;
+    u32 *const wsum = (u32 *)(smem_wg_ + 4u * ANSBQ_WAVE_LDS);
+    const u32 cw0 = blockIdx.x * 64u + wv * 16u;               // this wave's first chunk
+    const u32 c = cw0 + ci;
+    const bool alive = c < nchunks;
+    const u32 lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
+    const u32 len = alive ? (c == nchunks - 1u ? lastlen : chunk) : 0u;
+    const u8 *rbase = recs + (u64)(alive ? c : 0u) * (16u * (u64)chunk) + 16u * s;
 
-    TileIn tin; tin.tile = smem; tin.base = recs + (u64)wc.c0 * wr.chunk;
-    StreamOut<true> so;
-    so.rings = smem + TRC_TILE_BYTES;
-    so.scratch = scratch; so.stride = stride; so.c0 = wc.c0; so.wpos = 0; so.nfl = 0;
-    u32 st[4] = { TRC_ANS_LOW, TRC_ANS_LOW, TRC_ANS_LOW, TRC_ANS_LOW };
+    StreamOut<true, false, true> so;
+    so.rings = smem;
+    so.scratch = scratch; so.stride = stride; so.c0 = cw0; so.wpos = 0; so.nfl = 0;
+    u32 st = TRC_ANS_LOW;
     bool ovf = false;
+    const u32 sh = lane & ~3u, below = (1u << s) - 1u;
+    const u32 ringw = trc_lds_addr(so.rings) + ci * TRC_SRING_STRIDE;
+    const u32 dummy = trc_lds_addr(smem) + 16u * TRC_SRING_STRIDE + 16u * ci + 4u * s;
 
-    const u32 S = wr.chunk / TRC_SEG;                          // record segments of a full chunk: 4 input bytes each
-    const u32 top = alive ? (len - 1u) / 4u : 0u;              // segment holding the chunk's last byte
-    const u32 topbytes = len - 4u * top;                       // bytes of the chunk in it (1..4)
-    tin.issue(wr, (S - 1u) * TRC_SEG);
-    for (u32 s = S - 1u;; s--) {
-        tin.commit();
-        if (s) tin.issue(wr, (s - 1u) * TRC_SEG);
-        const bool act = alive && s <= top && !ovf;
-        const u32 nb = (act && s == top) ? topbytes : 4u;
-        if (act) {
-            const uint4 q[4] = { tin.read(0), tin.read(1), tin.read(2), tin.read(3) };
-            const u32 *rr = (const u32 *)q;                    // rr[2*byte + ...]: 4 dwords per byte, 2 records per dword
+    const u32 T = chunk / 4u;                                  // groups (4 input bytes = 32 records) of a full chunk
+    const u32 top = len ? (len - 1u) / 4u : 0u;                // group holding the chunk's last byte
+    const u32 topbytes = len - 4u * top;
+    uint4 nx = make_uint4(0, 0, 0, 0);
+    if (alive && len && T - 1u <= top) nx = trc_ld16_nt(rbase + (size_t)(T - 1u) * 64u);
+    for (u32 t = T - 1u;; t--) {
+        const uint4 q = nx;
+        if (t && alive && len && t - 1u <= top) nx = trc_ld16_nt(rbase + (size_t)(t - 1u) * 64u);
+        const bool act = alive && len != 0u && t <= top;
+        const u32 nb = act ? (t == top ? topbytes : 4u) : 0u;
+        ovf = ovf || (act && so.wpos + 16u >= len);            // with the four states it cannot end below len any more
+        const u32 d[4] = { q.x, q.y, q.z, q.w };
 #pragma unroll
-            for (int i = 31; i >= 0; i--) {                    // record i of the segment: byte i/8, push position i%8
-                if ((u32)(i >> 3) < nb) {
-                    const u32 rec = (rr[i >> 1] >> (16 * (i & 1))) & 0xffffu;
-                    ansb_put(st[(~i) & 3], rec, so);           // last record first on state 0: state = (31 - i) & 3
-                }
+        for (int b = 3; b >= 0; b--) {
+            const bool go = (u32)b < nb && !ovf;               // (the same for the four lanes of a chunk)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {                      // push positions 7 - s, then 3 - s
+                const u32 p0 = h ? __builtin_amdgcn_ubfe(d[b], 16, 15) : d[b] & 0x7fffu;
+                const u32 m = h ? (u32)((int)d[b] >> 31) : (u32)__builtin_amdgcn_sbfe((int)d[b], 15, 1);   // bit 1: all ones
+                const u32 np0 = TRC_PROB_ONE - p0;
+                const u32 f = trc_bfi(m, p0, np0), g = trc_bfi(m, np0, p0), c0 = trc_bfi(m, 0u, p0);
+                const bool emit = go && st >= (f << 16);
+                const u32 q4 = (u32)(__ballot(emit) >> sh) & 15u;
+                const u32 pre = (u32)__builtin_popcount(q4 & below), tot = (u32)__builtin_popcount(q4);
+                const u32 at = ringw + ((0u - (so.wpos + 2u * pre + 2u)) & (TRC_SRING - 1u));
+                trc_lds_write16(emit ? at : dummy, st);
+                so.wpos += 2u * tot;
+                const u32 s1 = emit ? st >> 16 : st;
+                st = go ? trc_rans_step(s1, f, g, c0) : st;
             }
         }
-        so.drain(false, alive);                                // <= 64 new bytes (32 records) per lane
-        ovf = ovf || (alive && so.wpos + 16u >= len);          // with the four states it cannot end below len any more
-        if (s == 0) break;
+        so.drain(false, alive);                                // <= 64 new bytes (32 records) per chunk
+        if (t == 0) break;
     }
     u32 out_len = 0;
     if (alive) {
-        if (!ovf) {
-            for (int k = 0; k < 4; k++) { so.put16(st[k] >> 16); so.put16(st[k]); }
+        if (!ovf) {                                            // states 0..3, high half first, each below the one before
+            so.put16_at(true, so.wpos + 4u * s, st >> 16); so.put16_at(true, so.wpos + 4u * s + 2u, st);
+            so.wpos += 16u;
             if (so.wpos >= len) ovf = true;
         }
         out_len = ovf ? len : so.wpos;
     }
     so.drain(true, alive && !ovf);
-    if (alive) clen[c] = out_len;
-    const u32 gs = trc_wave_sum(out_len);
-    if (lane == 0) gsum[wc.c0 >> 6] = gs;
+    if (alive && s == 0u) clen[c] = out_len;
+    const u32 ws = trc_wave_sum(s == 0u ? out_len : 0u);
+    if (lane == 0) wsum[wv] = ws;
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x * 64u < nchunks) gsum[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 // ------------------------------------------------------------------------------------- decode ---
@@ -252,7 +282,7 @@ void trc_launch_ansb_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const Tr
 {
     TRC_RAISE_LDS_ONCE(trc_ansb_model_kernel, TRC_WPG * ANSB_MODEL_BYTES);
     TRC_LAUNCH_TIMED(trc_ansb_model_kernel, TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (ANSB_MODEL_BYTES), s, d_in, (u64)n, chunk, w.nchunks, w.scratch2);
-    TRC_LAUNCH_TIMED(trc_ansb_code_kernel, TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (ANSB_CODE_LDS), s,
+    TRC_LAUNCH_TIMED(trc_ansb_codeq_kernel, dim3(w.ngroups), dim3(256), ANSBQ_LDS, s,
                        (const u8 *)w.scratch2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
 }
 void trc_launch_ansb_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,

@@ -118,11 +118,7 @@ __device__ __forceinline__ void vla_put(u32 &st, u32 rec, StreamOut<true> &so)
     const bool emit = st >= (f << 16);
     so.put16_if(emit, st);
     st = emit ? st >> 16 : st;
-    u32 q = (u32)((float)st * __builtin_amdgcn_rcpf((float)f));          // st/f within +-1
-    u32 r = st - __umul24(q, f);
-    if ((int)r < 0) { q--; r += f; }
-    if (r >= f) { q++; r -= f; }
-    st = (q << TRC_PROB_BITS) + r + c0;
+    st = trc_rans_step(st, f, TRC_PROB_ONE - f, c0);
 }
 
 template <int ES>

@@ -226,3 +226,16 @@ __device__ __forceinline__ u64 trc_group_base(const u64 *goff, const u32 *gsum, 
     }
     return (((u64)hi) << 32) | lo;
 }
+
+// One rANS step with a run-time divisor (ece, anscdf_.h:90-94): st -> (st / f) << 15 + st % f + c0, computed as
+// st + (st / f) * g + c0 with g = 2^15 - f -- only the QUOTIENT has to be exact, no remainder fix-up.  st < 2^31 and st / f <= 2^16,
+// so the f32 estimate is within +-1 of it; the sign of st - q * f and the comparison with f say which way (7 operations less
+// than correcting quotient and remainder in turn: these passes are bound by instruction issue).
+__device__ __forceinline__ u32 trc_rans_step(u32 st, u32 f, u32 g, u32 c0)
+{
+    const u32 q = (u32)((float)st * __builtin_amdgcn_rcpf((float)f));
+    const int rm = (int)(st - __umul24(q, f));
+    const u32 qe = q + (u32)(rm >> 31) + (rm >= (int)f ? 1u : 0u);
+    return st + __umul24(qe, g) + c0;
+}
+
