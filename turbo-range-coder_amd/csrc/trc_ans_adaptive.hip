@@ -401,12 +401,14 @@ __global__ __launch_bounds__(256) void trc_ansa_codeq_kernel(
                 const int u = 4 * half + uu;
                 const bool go = 4u * (u32)u < left && !ovf;    // (records exist in fours: the same for the four lanes)
                 const u32 f = r[u] & 0x7fffu, c0 = r[u] >> 15;
-                const bool emit = go && st >= (f << 16);
-                const u32 q4 = (u32)(__ballot(emit) >> sh) & 15u;
+                // (the vote is taken on the bare compare and masked with `go` as a value: a vote on `go && compare` makes the compiler
+                // rebuild the lane mask through a 0 / 1 vector, two instructions per step)
+                const bool ge = st >= (f << 16), emit = go && ge;
+                const u32 q4 = (u32)(__ballot(ge) >> sh) & (go ? 15u : 0u);
                 const u32 pre = (u32)__builtin_popcount(q4 & below), tot = (u32)__builtin_popcount(q4);
                 if (t == 0 && half == 0 && uu == 0)            // before the last record (lane 3's; the others' counts are smaller)
                     ovf = ovf || (((u32)(__ballot(go && so.wpos + 2u * pre + room >= len) >> sh) & 15u) != 0u);
-                const u32 at = ringw + ((0u - (so.wpos + 2u * pre + 2u)) & (TRC_SRING - 1u));
+                const u32 at = ringw + 2u * (~((so.wpos >> 1) + pre) & (TRC_SRING / 2u - 1u));      // (ring offset of unit u: -(2u + 2) mod the ring)
                 trc_lds_write16(emit ? at : dummy, st);
                 so.wpos += 2u * tot;
                 const u32 s1 = emit ? st >> 16 : st;

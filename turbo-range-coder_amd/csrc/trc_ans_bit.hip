@@ -150,25 +150,30 @@ __global__ __launch_bounds__(256) void trc_ansb_codeq_kernel(
         const u32 nb = act ? (t == top ? topbytes : 4u) : 0u;
         ovf = ovf || (act && so.wpos + 16u >= len);            // with the four states it cannot end below len any more
         const u32 d[4] = { q.x, q.y, q.z, q.w };
+        u32 wh = so.wpos >> 1;                                 // 16-bit units appended so far
 #pragma unroll
         for (int b = 3; b >= 0; b--) {
             const bool go = (u32)b < nb && !ovf;               // (the same for the four lanes of a chunk)
+            const u32 go15 = go ? 15u : 0u;
 #pragma unroll
             for (int h = 0; h < 2; h++) {                      // push positions 7 - s, then 3 - s
                 const u32 p0 = h ? __builtin_amdgcn_ubfe(d[b], 16, 15) : d[b] & 0x7fffu;
                 const u32 m = h ? (u32)((int)d[b] >> 31) : (u32)__builtin_amdgcn_sbfe((int)d[b], 15, 1);   // bit 1: all ones
                 const u32 np0 = TRC_PROB_ONE - p0;
                 const u32 f = trc_bfi(m, p0, np0), g = trc_bfi(m, np0, p0), c0 = trc_bfi(m, 0u, p0);
-                const bool emit = go && st >= (f << 16);
-                const u32 q4 = (u32)(__ballot(emit) >> sh) & 15u;
-                const u32 pre = (u32)__builtin_popcount(q4 & below), tot = (u32)__builtin_popcount(q4);
-                const u32 at = ringw + ((0u - (so.wpos + 2u * pre + 2u)) & (TRC_SRING - 1u));
+                // (the vote is taken on the bare compare and masked with `go` as a value: a vote on `go && compare` makes the compiler
+                // rebuild the lane mask through a 0 / 1 vector, two instructions per step)
+                const bool ge = st >= (f << 16), emit = go && ge;
+                const u32 q4 = (u32)(__ballot(ge) >> sh) & go15;
+                const u32 u = wh + (u32)__builtin_popcount(q4 & below);               // this lane's unit: the u-th of the chunk
+                const u32 at = ringw + 2u * (~u & (TRC_SRING / 2u - 1u));            // (ring offset of unit u: -(2u + 2) mod the ring)
                 trc_lds_write16(emit ? at : dummy, st);
-                so.wpos += 2u * tot;
+                wh += (u32)__builtin_popcount(q4);
                 const u32 s1 = emit ? st >> 16 : st;
                 st = go ? trc_rans_step(s1, f, g, c0) : st;
             }
         }
+        so.wpos = wh << 1;
         so.drain(false, alive);                                // <= 64 new bytes (32 records) per chunk
         if (t == 0) break;
     }
