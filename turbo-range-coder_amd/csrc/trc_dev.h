@@ -227,6 +227,14 @@ __device__ __forceinline__ u64 trc_group_base(const u64 *goff, const u32 *gsum, 
     return (((u64)hi) << 32) | lo;
 }
 
+// u32 -> f32 as the one instruction it is (from `(float)(u32)(x >> 32)` of a 64-bit x the compiler builds a 64-bit conversion)
+__device__ __forceinline__ float trc_u2f(u32 v)
+{
+    float r;
+    asm("v_cvt_f32_u32_e32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
 // One rANS step with a run-time divisor (ece, anscdf_.h:90-94): st -> (st / f) << 15 + st % f + c0, computed as
 // st + (st / f) * g + c0 with g = 2^15 - f -- only the QUOTIENT has to be exact, no remainder fix-up.  st < 2^31 and st / f <= 2^16,
 // so the f32 estimate is within +-1 of it; the sign of st - q * f and the comparison with f say which way (7 operations less

@@ -192,17 +192,19 @@ struct RcDec {
         const u32 a = si.peek32(); si.rpos += 4; const u32 b = si.peek32(); si.rpos += 4;
         start(a, b);
     }
-    // t = code / r for r = range >> 15 (the caller has NOT shifted range), branch-free: the f32 estimate is within
-    // +-1 of the exact quotient (relative errors: operand truncation 2^-23, cvt 2^-24, v_rcp_f32 1 ulp, product 2^-24,
-    // times t < 2^15 => < 0.02 absolute), so one correction step each way is exact for every valid stream.
+    // t = code / r for r = range >> 15 (the caller has NOT shifted range), branch-free: the f32 estimate is within +-1 of the
+    // exact quotient, so one correction step each way is exact for every valid stream.  Both operands go to f32 as
+    // hi * 2^32 + lo (two conversions and an fma: relative error <= 2^-23 whatever the magnitude; rounds 1-3 normalised them
+    // with a count-leading-zeros and two 64-bit shifts first, eight instructions more); v_rcp_f32 is 1 ulp, the product 2^-24:
+    // relative 2^-21 at most, times t < 2^15 => < 0.02 absolute.
     __device__ __forceinline__ u32 quotient15() const
     {
         const u64 r = range >> TRC_PROB_BITS;                             // 2^17 <= r < 2^49
-        const int bl = 64 - __clzll((long long)r);
-        const int sh = bl > 24 ? bl - 24 : 0;
-        const float rf = (float)(u32)(r >> sh);
-        const u64 cs = code >> sh;                                       // < 2^39
-        const float cf = (float)(u32)(cs >> 16) * 65536.0f + (float)(u32)(cs & 0xffffu);
+        // (on explicit 32-bit halves: from `(float)(u32)(r >> 32)` the compiler builds a 64-bit integer conversion, normalising shift and all)
+        const u32 rh = (u32)(range >> 32), ch = (u32)(code >> 32);
+        const float rf = __builtin_fmaf(trc_u2f(rh >> TRC_PROB_BITS), 4294967296.0f,
+                                        trc_u2f(__builtin_amdgcn_alignbit(rh, (u32)range, TRC_PROB_BITS)));
+        const float cf = __builtin_fmaf(trc_u2f(ch), 4294967296.0f, trc_u2f((u32)code));
         u32 t = (u32)(cf * __builtin_amdgcn_rcpf(rf));
         t = t > TRC_PROB_ONE - 1 ? TRC_PROB_ONE - 1 : t;
         const u64 p = r * t;
