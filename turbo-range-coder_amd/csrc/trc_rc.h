@@ -135,6 +135,7 @@ struct RcEncD {
 // four 32-bit halves plus a carry limb `lx` fed by the add's carry-out, the pending word's flags are integers, and `sym<false>` carries
 // no predicate at all: a lane that is not coding runs along on its own registers, and the caller keeps it from emitting.
 struct RcEncV {
+    static constexpr u32 WBYTES = 4;     // bytes per emitted word
     u32 rlo, rhi, llo, lhi, lx;          // range, low, carry limb of low (0 / 1)
     u32 pend, pcy, pw;                   // a word waits for flush(): its carry flag and itself
     TrcCarry cw;
@@ -165,6 +166,12 @@ struct RcEncV {
         cw.emit_if(so, pend != 0u && on, pcy != 0u, pw);
         pend = pcy = 0;
     }
+    template <class SO>
+    __device__ __forceinline__ void sym(SO &so, u32 c0, u32 f) { sym<true>(true, c0, f); flush(so, true); }    // one symbol, emitted at once
+    // RcEncD's names, for the static coders (every lane of a full piece codes: no predicate)
+    __device__ __forceinline__ void sym_rec(bool, u32 c0, u32 f) { sym<false>(true, c0, f); }
+    template <class SO>
+    __device__ __forceinline__ void flush(SO &so) { flush(so, true); }
     template <class SO>
     __device__ __forceinline__ void finish(SO &so)                      // rceflush, then release everything still held back
     {

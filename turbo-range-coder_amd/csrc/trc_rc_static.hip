@@ -19,7 +19,7 @@
 #define RCS_WAVE_LDS(NS) ((NS) * TRC_SRING_BYTES)     // chunk bytes travel through in-register quad transposes
 
 template <int GEO> struct RcGeo;
-template <> struct RcGeo<0> { typedef RcEncD Enc; typedef RcDec Dec; };
+template <> struct RcGeo<0> { typedef RcEncV Enc; typedef RcDec Dec; };      // (RcEncV: the state on 32-bit halves with a carry limb, trc_rc.h)
 template <> struct RcGeo<1> { typedef RcEncSm Enc; typedef RcDecSm Dec; };
 
 template <int NS, int GEO>
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(128) void trc_rcs2p_enc_kernel(
         so.rings = wbase;
         so.scratch = scrA; so.stride = strideA; so.scratch_b = scrB; so.stride_b = strideB; so.c0 = wc.c0;
         so.wpos = b ? 0u : 4u; so.nfl = 0;
-        RcEncD e; e.start();
+        RcEncV e; e.start();                                   // (state on 32-bit halves with a carry limb: trc_rc.h; RcEncD: 0.141 ms)
         const u32 off1 = len >= 4u ? 4u + ((len - 4u) * 37u) / 64u : 0u;       // stream-1 base inside `out` (rccdf.c:126)
         bool ovf = alive && len < 10u;                                         // tiny inputs: always raw
         const u32 pairs = len & ~1u;
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(128) void trc_rcs2p_enc_kernel(
                     for (u32 d = 0; d < 4; d++) {               // a dword = two pairs: this lane's bytes are b and b + 2
                         const u32 wd = v.x; v.x = v.y; v.y = v.z; v.z = v.w;
                         const u32 ta = tab[(wd >> sh0) & 255u], tb = tab[(wd >> sh1) & 255u];
-                        e.sym_rec(true, ta & 0xffffu, ta >> 16); e.sym_rec(true, tb & 0xffffu, tb >> 16); e.flush(so);
+                        e.sym<false>(true, ta & 0xffffu, ta >> 16); e.sym<false>(true, tb & 0xffffu, tb >> 16); e.flush(so, true);
                     }
                 } else if (act) {                               // last chunk's final partial piece (both lanes of its pair walk it)
                     const u8 *mine = in + (u64)c * chunk;
