@@ -204,7 +204,18 @@ __global__ __launch_bounds__(64) void trc_o1_model_kernel(
 #define O1M2_KB      0u
 #define O1M2_HSEEN   TRC_NIBK_BYTES                             // u32[8][64]
 #define O1M2_LSEEN   (TRC_NIBK_BYTES + 2048u)                   // u32[128][64]
-#define O1M2_LDS     (TRC_NIBK_BYTES + 2048u + 32768u)
+// End of round 4: between a lane's one table in registers and its model block in HBM sits a small write-back cache in LDS --
+// O1C_E entries per lane, direct-mapped by a hash of the table's index, the tag in the low half of dword 0 (entry 0 of a CDF16
+// table is always 0).  On data whose statistics drift (what an order-1 coder is for) a lane works on a handful of contexts at a
+// time: a register miss was a round trip to HBM on 61 % (hi wave) / 70 % (lo wave) of the bytes; with eight entries it is one
+// on 9 % / 21 % (simulation over `drift_bytes`; i.i.d. bytes gain nothing: 95 % -> 67 % / 89 %).  A miss evicts the slot's
+// occupant to the model block and fills from it (first-touch rule unchanged); nothing is flushed at the end -- the model of a
+// chunk is not needed after its records.
+#define O1C_E        8u
+#define O1C_BYTES    (O1C_E * 2u * 64u * 16u)                   // [entry][half][lane] 16 B
+#define O1M2_CACHE   (TRC_NIBK_BYTES + 2048u + 32768u)          // the hi wave's cache, then the lo wave's
+#define O1M2_LDS     (TRC_NIBK_BYTES + 2048u + 32768u + 2u * O1C_BYTES)
+__device__ __forceinline__ u32 o1c_slot(u32 id) { return (id ^ (id >> 4) ^ (id >> 8)) & (O1C_E - 1u); }
 template <u32 W>                                               // pairs per workgroup
 __global__ __launch_bounds__(128 * W) void trc_o1_model2_kernel(
     const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ model, u8 *__restrict__ recs)
@@ -227,8 +238,11 @@ __global__ __launch_bounds__(128 * W) void trc_o1_model2_kernel(
         }
         u32 *z = (u32 *)(smem + (lo_wave ? O1M2_LSEEN : O1M2_HSEEN));
         for (u32 i = lane; i < (lo_wave ? 128u * 64u : 8u * 64u); i += 64u) z[i] = 0u;
+        uint4 *zc = (uint4 *)(smem + O1M2_CACHE + (lo_wave ? O1C_BYTES : 0u));
+        for (u32 i = lane; i < O1C_BYTES / 16u; i += 64u) zc[i] = make_uint4(0, 0, 0, 0);        // (tag 0: empty)
         trc_wave_lds_fence();
     }
+    u8 *const cache = smem + O1M2_CACHE + (lo_wave ? O1C_BYTES : 0u) + lane * 16u;             // this lane's column: entry e at + e * 2048, second half + 1024
     const u32 seen = trc_lds_addr(smem) + (lo_wave ? O1M2_LSEEN : O1M2_HSEEN) + lane * 4u;      // word w of this lane at seen + 256 w
 
     WaveChunks wc;
@@ -247,10 +261,27 @@ __global__ __launch_bounds__(128 * W) void trc_o1_model2_kernel(
     // make Tc table `id` of the model block (first-touch bit `bit` of word `wd`), only where `on`
     auto need = [&](bool on, u32 id, u32 fb) __attribute__((always_inline)) {
         if (on && id != tid_c) {
-            if (tid_c != ~0u) o1_store(mine + (size_t)tid_c * 32u, Tc);
-            const u32 a = seen + ((fb >> 5) << 8), bits = *(const lds_u32 *)(uintptr_t)a, bit = 1u << (fb & 31u);
-            if (bits & bit) Tc = o1_load(mine + (size_t)id * 32u);
-            else { Tc = O1Cache::fresh(); *(lds_u32 *)(uintptr_t)a = bits | bit; }
+            if (tid_c != ~0u) {                                // the table in hand goes back to its slot (tag = index + 1)
+                u8 *sl = cache + o1c_slot(tid_c) * 2048u;
+                *(uint4 *)sl = make_uint4(Tc.d[0] | (tid_c + 1u), Tc.d[1], Tc.d[2], Tc.d[3]);
+                *(uint4 *)(sl + 1024u) = make_uint4(Tc.d[4], Tc.d[5], Tc.d[6], Tc.d[7]);
+            }
+            const u8 *sl = cache + o1c_slot(id) * 2048u;
+            const uint4 c0 = *(const uint4 *)sl, c1 = *(const uint4 *)(sl + 1024u);
+            const u32 tag = c0.x & 0xffffu;
+            if (tag == id + 1u) {
+                Tc.d[0] = c0.x & 0xffff0000u; Tc.d[1] = c0.y; Tc.d[2] = c0.z; Tc.d[3] = c0.w;
+                Tc.d[4] = c1.x; Tc.d[5] = c1.y; Tc.d[6] = c1.z; Tc.d[7] = c1.w;
+            } else {
+                if (tag) {                                     // the slot's occupant leaves for the model block
+                    u8 *tb = mine + (size_t)(tag - 1u) * 32u;
+                    *(uint4 *)tb = make_uint4(c0.x & 0xffff0000u, c0.y, c0.z, c0.w);
+                    *(uint4 *)(tb + 16) = c1;
+                }
+                const u32 a = seen + ((fb >> 5) << 8), bits = *(const lds_u32 *)(uintptr_t)a, bit = 1u << (fb & 31u);
+                if (bits & bit) Tc = o1_load(mine + (size_t)id * 32u);
+                else { Tc = O1Cache::fresh(); *(lds_u32 *)(uintptr_t)a = bits | bit; }
+            }
             tid_c = id;
         }
     };
@@ -398,6 +429,7 @@ bool trc_launch_anso1_model(const uint8_t *d_in, size_t n, uint32_t chunk, const
         // ONE pair per workgroup: these waves are bound by the texture-address unit of their CU (64 scattered 16-byte accesses per
         // table move), not by their SIMD -- four pairs per workgroup put 100 MB at chunk 4096 (382 pairs) on 96 CUs and ran 30 %
         // slower than the one-wave pass; as single pairs they spread over all 256 (profiles/r04_notes.md)
+        TRC_RAISE_LDS_ONCE(trc_o1_model2_kernel<1>, O1M2_LDS);
         TRC_LAUNCH_TIMED(trc_o1_model2_kernel<1>, dim3(w.ngroups), dim3(128), O1M2_LDS, s, d_in, (u64)n, chunk, w.nchunks, w.model, w.scratch2);
         return true;
     }
