@@ -10,8 +10,9 @@
 //
 // Same two-kernel shape as the adaptive CDF rANS: the model pass walks the chunk forward (eight nodes per byte,
 // known from the byte: one batch of reads, one of writes; model = 256 x u16 per lane in LDS, [context][lane]) and
-// streams 16 B of records per input byte to HBM scratch; the coding pass pops them in reverse.  The divisor of an
-// rANS step is the record's probability, different every bit: f32 estimate + exact correction (st < 2^31).
+// streams 16 B of records per input byte to HBM scratch; the coding pass pops them in reverse -- four lanes per chunk, one
+// per rANS state (round 4), the records laid out per state by the model pass.  The divisor of an rANS step is the record's
+// probability, different every bit: f32 estimate of the quotient + exact correction (trc_rans_step, trc_dev.h).
 #include "trc_io.h"
 #include "trc_lane_io.h"
 #include "trc_launch.h"

@@ -11,14 +11,17 @@
 // One lane = one chunk = one range-coder state.  The lane's 256 x u16 model lives in LDS in a [context][lane] layout
 // (2 lanes per bank, independent of the context each lane is at), 32 KiB per wave, and it is the ONLY thing in LDS:
 // chunk bytes move through in-register quad transposes (trc_io.h QuadIn/QuadOut), the coded stream through per-lane
-// registers (trc_lane_io.h: released words are stored directly; the decoder keeps a 32-byte window whose next half every
-// lane prefetches at the start of a byte), so five waves share a CU: one wave per SIMD, where a kernel's time is its
-// instruction count, scalar mask logic and branches included (profiles/r02_notes.md).  The two sides:
+// registers (trc_lane_io.h: released words are stored directly; the decoder carries two look-ahead words and makes one
+// 16-byte load from its stream position per byte -- end of round 4; rounds 2-4: a 32-byte window), so five waves share a
+// CU: one wave per SIMD, where a kernel's time is its instruction count, scalar mask logic, branches and the wait states
+// behind a vector-written mask included (profiles/r02_notes.md, r04_notes.md 14).  The two sides:
 //   encoder  the eight nodes a byte visits are known from the byte itself ((0x100|x) >> (8-k)) and are all different,
 //            so their probabilities are read in one batch, adapted with packed 16-bit arithmetic and written back before
 //            the eight coding steps run on registers (state on 32-bit halves, mask selects, one emit per byte);
 //   decoder  the path depends on the decoded bits; both children of the current node are requested before the bit is
-//            resolved, the bit is the borrow of code - cut and everything that depends on it a select under its mask.
+//            resolved, the bit is the borrow of code - cut and everything that depends on it a bit-select under the mask made
+//            from it -- one hand-written block per bit (the compiler turns the C form back into v_cndmask on an SGPR pair).
+// Round 4: the encoder is a model wave + a coder wave per 64 chunks (trc_rcb_enc_mc_kernel, the default).
 // Round 3, ENCODER only: the deepest tree level (nodes 128..255: half of the model) lives in global memory, one 256-byte row per
 // lane, filled by the wave itself at its start -- 16 KiB of model per wave in LDS instead of 32: nine waves per CU where five fit,
 // i.e. more than two per SIMD, which is what fills the issue gaps of a one-wave-per-SIMD kernel (round 2's half-model ablation:
