@@ -554,7 +554,8 @@ def main():
                     tj = json.load(open(tpath))
                     traffic = tj.get("%s_%s_chunk%d" % (args.codec, dom, chunk))
                     if traffic is not None:
-                        traffic_source = "profiles/pmc_traffic.json (%s)" % tj.get("source", "rocprofv3 --pmc passes of `python bench.py`, TCC_EA0_RDREQ/WRREQ by request size")
+                        traffic_source = "profiles/pmc_traffic.json (%s)" % tj.get("source" if args.codec == "anscdf4s" else "source_cfg34",
+                                                                                    "rocprofv3 --pmc passes of `python bench.py`, TCC_EA0_RDREQ/WRREQ by request size")
             except Exception:
                 traffic = None
         default_metric = args.codec == "anscdf4s" and args.workload == "default" and n == 100 * 1000 * 1000
