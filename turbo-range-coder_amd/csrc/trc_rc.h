@@ -212,8 +212,7 @@ struct RcDec {
         const float rf = __builtin_fmaf(trc_u2f(rh >> TRC_PROB_BITS), 4294967296.0f,
                                         trc_u2f(__builtin_amdgcn_alignbit(rh, (u32)range, TRC_PROB_BITS)));
         const float cf = __builtin_fmaf(trc_u2f(ch), 4294967296.0f, trc_u2f((u32)code));
-        u32 t = (u32)(cf * __builtin_amdgcn_rcpf(rf));
-        t = t > TRC_PROB_ONE - 1 ? TRC_PROB_ONE - 1 : t;
+        u32 t = (u32)(cf * __builtin_amdgcn_rcpf(rf));             // (a corrupt stream's estimate can be anything: the clamp behind the correction keeps it in the table)
         const u64 p = r * t;
         const bool dn = p > code, up = !dn && code - p >= r;
         t = dn ? t - 1u : up ? t + 1u : t;

@@ -17,6 +17,9 @@
 #include "trc_launch.h"
 
 #define RCS_WAVE_LDS(NS) ((NS) * TRC_SRING_BYTES)     // chunk bytes travel through in-register quad transposes
+// the decoders' slot -> symbol LUT sits at LDS offset 0: read on the integer address (through the generic pointer the compiler adds
+// the segment base, a relocated 0, to every index); the kernels trap at entry if the dynamic segment does not start at 0
+#define RCS_LUT(t) ((u32)*(const trc_lds_u8 *)(uintptr_t)(t))
 
 template <int GEO> struct RcGeo;
 template <> struct RcGeo<0> { typedef RcEncV Enc; typedef RcDec Dec; };      // (RcEncV: the state on 32-bit halves with a carry limb, trc_rc.h)
@@ -139,6 +142,7 @@ __global__ __launch_bounds__(896) void trc_rcs_dec_kernel(
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     u8 *lut = smem;                                            // 32768
     u32 *tab = (u32 *)(smem + 32768);                          // 256 x {f<<16 | c0}
+    if (trc_lds_addr(smem) != 0u) __builtin_trap();            // (RCS_LUT: absolute LDS offsets)
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, BLOCK = blockDim.x;
     u8 *wbase = smem + 32768 + 1024 + wv * RCS_WAVE_LDS(NS);
     if (BLOCK >= 704u) {                                        // one batch of loads (a copy loop waits for each load before the next: trc_ans_static.hip)
@@ -188,12 +192,12 @@ __global__ __launch_bounds__(896) void trc_rcs_dec_kernel(
     auto get = [&](Dec &d, StreamIn &si) -> u32 {
         if constexpr (GEO == 0) {                                  // one correction step each way, no loops, predicated renorm
                                                                    // (rccdfs decode 194 -> 182 us, rccdfs2 288 -> 231 us)
-            const u32 x = lut[d.quotient15()];
+            const u32 x = RCS_LUT(d.quotient15());
             const u32 t = tab[x];
             d.consume_if(si, true, t & 0xffffu, (t & 0xffffu) + (t >> 16));
             return x;
         } else {
-            const u32 x = lut[d.slot()];
+            const u32 x = RCS_LUT(d.slot());
             const u32 t = tab[x];
             d.consume(si, t & 0xffffu, (t & 0xffffu) + (t >> 16));
             return x;
@@ -205,10 +209,10 @@ __global__ __launch_bounds__(896) void trc_rcs_dec_kernel(
     auto get2 = [&](Dec &d, StreamIn &si, u32 &xa, u32 &xb) {
         if constexpr (GEO == 0) {
             const u32 w = si.peek32();
-            xa = lut[d.quotient15()];
+            xa = RCS_LUT(d.quotient15());
             const u32 ta = tab[xa];
             const bool ra = d.consume_w(true, ta & 0xffffu, (ta & 0xffffu) + (ta >> 16), w);
-            xb = lut[d.quotient15()];
+            xb = RCS_LUT(d.quotient15());
             const u32 tb = tab[xb];
             const bool rb = d.consume_w(true, tb & 0xffffu, (tb & 0xffffu) + (tb >> 16), w);
             si.skip_if(ra || rb);
@@ -358,6 +362,7 @@ __global__ __launch_bounds__(896) void trc_rcs2p_dec_kernel(
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     u8 *lut = smem;                                            // 32768
     u32 *tab = (u32 *)(smem + 32768);                          // 256 x {f<<16 | c0}
+    if (trc_lds_addr(smem) != 0u) __builtin_trap();            // (RCS_LUT: absolute LDS offsets)
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, BLOCK = blockDim.x;
     u8 *wbase = smem + 32768 + 1024 + wv * RCS_WAVE_LDS(1);
     if (BLOCK >= 704u) {
@@ -422,10 +427,10 @@ __global__ __launch_bounds__(896) void trc_rcs2p_dec_kernel(
                     if (full) {
                         // two symbols of one stream: at most one of them renormalises (trc_rc.h RcEncD), one look-ahead word
                         const u32 w = si.peek32();
-                        const u32 xa = lut[d.quotient15()];
+                        const u32 xa = RCS_LUT(d.quotient15());
                         const u32 ta = tab[xa];
                         const bool ra = d.consume_w(true, ta & 0xffffu, (ta & 0xffffu) + (ta >> 16), w);
-                        const u32 xb = lut[d.quotient15()];
+                        const u32 xb = RCS_LUT(d.quotient15());
                         const u32 tb = tab[xb];
                         const bool rb = d.consume_w(true, tb & 0xffffu, (tb & 0xffffu) + (tb >> 16), w);
                         si.skip_if(ra || rb);
@@ -438,7 +443,7 @@ __global__ __launch_bounds__(896) void trc_rcs2p_dec_kernel(
                     for (u32 pos = p0; pos < len; pos++) {
                         const bool second = pos < pairs && (pos & 1u);
                         if ((second ? 1u : 0u) == b) {
-                            const u32 x = lut[d.quotient15()];
+                            const u32 x = RCS_LUT(d.quotient15());
                             const u32 t = tab[x];
                             d.consume_if(si, true, t & 0xffffu, (t & 0xffffu) + (t >> 16));
                             dst[pos] = (u8)x;
