@@ -206,14 +206,16 @@ struct RcDec {
     // relative 2^-21 at most, times t < 2^15 => < 0.02 absolute.
     __device__ __forceinline__ u32 quotient15() const
     {
-        const u64 r = range >> TRC_PROB_BITS;                             // 2^17 <= r < 2^49
-        // (on explicit 32-bit halves: from `(float)(u32)(r >> 32)` the compiler builds a 64-bit integer conversion, normalising shift and all)
+        // (everything on explicit 32-bit halves: from `(float)(u32)(r >> 32)` the compiler builds a 64-bit integer conversion, normalising
+        // shift and all; from `r * t` with an unbounded t two full 64-bit multiply-adds where a 24-bit one does for the high half)
         const u32 rh = (u32)(range >> 32), ch = (u32)(code >> 32);
-        const float rf = __builtin_fmaf(trc_u2f(rh >> TRC_PROB_BITS), 4294967296.0f,
-                                        trc_u2f(__builtin_amdgcn_alignbit(rh, (u32)range, TRC_PROB_BITS)));
+        const u32 slo = __builtin_amdgcn_alignbit(rh, (u32)range, TRC_PROB_BITS), shi = rh >> TRC_PROB_BITS;     // r = range >> 15: 2^17 <= r < 2^49
+        const u64 r = ((u64)shi << 32) | slo;
+        const float rf = __builtin_fmaf(trc_u2f(shi), 4294967296.0f, trc_u2f(slo));
         const float cf = __builtin_fmaf(trc_u2f(ch), 4294967296.0f, trc_u2f((u32)code));
         u32 t = (u32)(cf * __builtin_amdgcn_rcpf(rf));             // (a corrupt stream's estimate can be anything: the clamp behind the correction keeps it in the table)
-        const u64 p = r * t;
+        const u64 plo = (u64)slo * t;
+        const u64 p = ((u64)((u32)(plo >> 32) + __umul24(shi, t)) << 32) | (u32)plo;      // r * t for t < 2^24
         const bool dn = p > code, up = !dn && code - p >= r;
         t = dn ? t - 1u : up ? t + 1u : t;
         return t > TRC_PROB_ONE - 1 ? TRC_PROB_ONE - 1 : t;              // corrupt input: stay inside the table
