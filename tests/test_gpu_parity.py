@@ -88,6 +88,19 @@ def device_roundtrip(torch, codec, d, chunk, cdf, cdfnum):
     torch.cuda.synchronize()
     out = d_out.cpu().numpy()
     assert np.array_equal(out[:n], d) and (out[n:] == 0x5A).all(), "decode with TRC_DIR_READY (after an encode) mismatch"
+    # the decode-only contract: a workspace that has NEVER encoded -- a receiver of gathered containers, the reference
+    # harness's repeat-decode loop -- decodes a foreign directory, then decodes it again under TRC_DIR_READY.  The workspace is
+    # poisoned first: nothing an earlier call left behind may make this pass.
+    rx = trc.DeviceCoder(codec, n, chunk, "cuda:0")
+    rx.work.fill_(0xEE)
+    if codec in trc.STATIC:
+        rx.set_cdf(cdf, cdfnum)
+    for flag in (False, True, True):
+        d_out.fill_(0x3C)
+        rx.decode(d_out, n, clen=dc.clen, payload=dc.payload, dir_ready=flag)
+        torch.cuda.synchronize()
+        out = d_out.cpu().numpy()
+        assert np.array_equal(out[:n], d) and (out[n:] == 0x3C).all(), "decode-only workspace, dir_ready=%s: mismatch" % flag
     return clen, payload
 
 
@@ -365,8 +378,10 @@ def test_bounded_host_decoder(torch_cuda):
         bad = comp.copy(); bad[32:36] = np.frombuffer(np.uint32(7).tobytes(), dtype=np.uint8)                        # clen[0]: sums no longer match
         r, _ = dec(bad, comp.size)
         assert r == 0
+        before = L.trc_last_error()
         r, out = dec(d, d.size)                                           # stored raw: inlen == outlen
         assert r == d.size and np.array_equal(out[:d.size], d)
+        assert L.trc_last_error() == before, "a raw copy is a success: it must not report a container error (ADVICE r4)"
 
 
 def test_host_pointer_layer_is_thread_safe(torch_cuda):

@@ -376,10 +376,15 @@ extern "C" int trc_decode_dev(int codec, const uint32_t *d_clen, const void *d_p
     TrcWork w;
     if ((rc = carve(codec, n, chunk, d_work, work_bytes, w))) return rc;
     if (is_static(codec) && !tables_ready) trc_launch_static_prep(d_cdf, cdfnum, w.tables, s);
+    // TRC_DIR_READY promises that the last encode OR DECODE on this workspace was of this directory (include/trc_hip.h), so both must
+    // leave every group's base in goff_area: an encode's gather does (trc_launch.h); a decode derives the sums from clen[] and scans
+    // them into the same place.  (Round 4 read goff_area after a decode that had never written it -- a workspace that only ever
+    // decoded fed its second decode whatever the memory held: ADVICE r4.)
     if (!dir_ready) {
         trc_launch_group_sums(d_clen, w.nchunks, n, chunk, w.gsum, s);
-        if (w.goff) trc_launch_scan_groups(w.gsum, w.ngroups, w.goff, nullptr, s);
-    } else w.goff = w.goff_area;                               // the encode's gather left the group bases there (trc_launch.h)
+        trc_launch_scan_groups(w.gsum, w.ngroups, w.goff_area, nullptr, s);
+    }
+    w.goff = w.goff_area;
     tm_begin(1);
     switch (codec) {
     case TRC_ANS4S: trc_launch_ans4s_dec((const uint8_t *)d_payload, d_clen, n, chunk, w, (uint8_t *)d_out, s); break;
@@ -935,6 +940,7 @@ extern "C" size_t trc_encode_host(int codec, const void *in, size_t n, uint32_t 
     return host_encode(codec, (const unsigned char *)in, n, (unsigned char *)out, (const cdf_t *)cdf, (int)cdfnum, chunk, outcap);
 }
 
+static int container_verdict(const void *buf, size_t buflen, int codec, size_t outlen, char *why, size_t whysz);
 // The bounded decoder: like the reference-named decoder of `codec`, but the caller states how many bytes `in` really holds and the
 // container is validated against THAT before anything is read (the reference prototypes carry no input length, so through them a
 // forged header can make a decoder read past a short buffer).  Raw streams (inlen == outlen) are copied.  Returns outlen, 0 on error.
@@ -947,7 +953,8 @@ extern "C" size_t trc_decode_host(int codec, const void *in, size_t inlen, void 
     // inlen == outlen is the reference's "stored raw" convention -- but trc_encode_host with a stated capacity returns the
     // container whatever its size, so a container of exactly outlen bytes is possible (nearly incompressible input): what
     // validates as a container of this coder and this length is decoded, anything else of that size is the raw copy.
-    if (inlen == outlen && trc_container_check(in, inlen, codec, outlen)) { memcpy(out, in, outlen); return outlen; }
+    char why[200];
+    if (inlen == outlen && container_verdict(in, inlen, codec, outlen, why, sizeof why)) { memcpy(out, in, outlen); return outlen; }   // raw: not an error, nothing reported
     if (inlen != outlen && trc_container_check(in, inlen, codec, outlen)) return 0;
     return host_decode(codec, (const unsigned char *)in, outlen, (unsigned char *)out, (const cdf_t *)cdf, (int)cdfnum);
 }
@@ -955,19 +962,22 @@ extern "C" size_t trc_decode_host(int codec, const void *in, size_t inlen, void 
 // ---- container validation for untrusted input (the reference prototypes carry no input length) ------
 // Everything a decoder will read from buf is checked against buflen: header fields, the directory, and that the
 // directory's (clamped) lengths add up to exactly the stated payload, which must end inside the buffer.
-extern "C" int trc_container_check(const void *buf, size_t buflen, int codec, size_t outlen)
+// quiet form: the verdict and, on failure, its reason in `why` -- nothing printed, trc_last_error() untouched (the raw-or-container
+// probe of trc_decode_host is not an error)
+static int container_verdict(const void *buf, size_t buflen, int codec, size_t outlen, char *why, size_t whysz)
 {
+#define BAD(...) do { snprintf(why, whysz, __VA_ARGS__); return TRC_E_ARG; } while (0)
     trc_container_hdr h;
-    if (!buf || buflen < sizeof h) return fail(TRC_E_ARG, "container: %zu bytes is shorter than the header", buflen);
+    if (!buf || buflen < sizeof h) BAD("container: %zu bytes is shorter than the header", buflen);
     memcpy(&h, buf, sizeof h);
-    if (h.magic != TRC_MAGIC || h.version != 1) return fail(TRC_E_ARG, "container: bad magic/version");
-    if (!codec_ok(h.codec) || (codec && h.codec != codec)) return fail(TRC_E_ARG, "container: codec %u (expected %d)", h.codec, codec);
-    if (!chunk_ok(h.chunk)) return fail(TRC_E_ARG, "container: chunk %u", h.chunk);
-    if (outlen != (size_t)-1 && h.n != outlen) return fail(TRC_E_ARG, "container: holds %llu bytes, caller expects %zu", (unsigned long long)h.n, outlen);
-    if (h.n == 0 || (h.n + h.chunk - 1) / h.chunk != h.nchunks) return fail(TRC_E_ARG, "container: nchunks %u does not match n/chunk", h.nchunks);
+    if (h.magic != TRC_MAGIC || h.version != 1) BAD("container: bad magic/version");
+    if (!codec_ok(h.codec) || (codec && h.codec != codec)) BAD("container: codec %u (expected %d)", h.codec, codec);
+    if (!chunk_ok(h.chunk)) BAD("container: chunk %u", h.chunk);
+    if (outlen != (size_t)-1 && h.n != outlen) BAD("container: holds %llu bytes, caller expects %zu", (unsigned long long)h.n, outlen);
+    if (h.n == 0 || (h.n + h.chunk - 1) / h.chunk != h.nchunks) BAD("container: nchunks %u does not match n/chunk", h.nchunks);
     const size_t dir = 4 * (size_t)h.nchunks;
-    if (dir > buflen - sizeof h) return fail(TRC_E_ARG, "container: directory (%zu B) runs past the buffer", dir);
-    if (h.payload > h.n || h.payload > buflen - sizeof h - dir) return fail(TRC_E_ARG, "container: payload (%llu B) runs past the buffer", (unsigned long long)h.payload);
+    if (dir > buflen - sizeof h) BAD("container: directory (%zu B) runs past the buffer", dir);
+    if (h.payload > h.n || h.payload > buflen - sizeof h - dir) BAD("container: payload (%llu B) runs past the buffer", (unsigned long long)h.payload);
     const uint8_t *d = (const uint8_t *)buf + sizeof h;
     uint64_t sum = 0;
     for (uint32_t c = 0; c < h.nchunks; c++) {
@@ -975,8 +985,14 @@ extern "C" int trc_container_check(const void *buf, size_t buflen, int codec, si
         const uint64_t len = (c + 1 == h.nchunks) ? h.n - (uint64_t)c * h.chunk : h.chunk;
         sum += l < len ? l : len;                               // the decoders read an entry above the chunk length as "raw"
     }
-    if (sum != h.payload) return fail(TRC_E_ARG, "container: directory sums to %llu, header says %llu", (unsigned long long)sum, (unsigned long long)h.payload);
+    if (sum != h.payload) BAD("container: directory sums to %llu, header says %llu", (unsigned long long)sum, (unsigned long long)h.payload);
     return TRC_OK;
+#undef BAD
+}
+extern "C" int trc_container_check(const void *buf, size_t buflen, int codec, size_t outlen)
+{
+    char why[200];
+    return container_verdict(buf, buflen, codec, outlen, why, sizeof why) ? fail(TRC_E_ARG, "%s", why) : TRC_OK;
 }
 
 // ---- exports with the reference's names (include/turborc.h:500, include/anscdf.h:40-96) ----------
