@@ -97,6 +97,22 @@ KERNEL(k_ds_w16,   asm volatile(S16("ds_write_b16 %8, %0\n ds_write_b16 %8, %2 o
 KERNEL(k_ds_w32,   asm volatile(S16("ds_write_b32 %8, %0\n ds_write_b32 %8, %2 offset:256\n ds_write_b32 %8, %4 offset:512\n ds_write_b32 %8, %6 offset:768") "\n s_waitcnt lgkmcnt(0)" V4 : "v"(la) : "memory");)
 KERNEL(k_ds_b128,  asm volatile(S16("ds_read_b128 v[60:63], %0\n ds_read_b128 v[64:67], %0 offset:1024\n ds_read_b128 v[68:71], %0 offset:2048\n ds_read_b128 v[72:75], %0 offset:3072") "\n s_waitcnt lgkmcnt(0)" :: "v"(la * 2u) : "memory", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75");)
 KERNEL(k_ds_perm,  asm volatile(S16("ds_bpermute_b32 %0, %8, %0\n ds_bpermute_b32 %2, %8, %2\n ds_bpermute_b32 %4, %8, %4\n ds_bpermute_b32 %6, %8, %6") "\n s_waitcnt lgkmcnt(0)" V4 : "v"(la) : "memory");)
+// --- third batch: what separates two v_cndmask_b32 (VOP2 / DPP / SDWA: implicit VCC) enough?
+KERNEL(k_cd_nop,   asm volatile("s_mov_b64 vcc, 0x5555\n s_nop 0\n" S16("v_cndmask_b32_dpp %0, %1, %0, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n s_nop 0\n v_cndmask_b32_dpp %2, %3, %2, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n s_nop 0\n v_cndmask_b32_dpp %4, %5, %4, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n s_nop 0\n v_cndmask_b32_dpp %6, %7, %6, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n s_nop 0") V4 :: "vcc");)
+KERNEL(k_cd_mov,   asm volatile("s_mov_b64 vcc, 0x5555\n s_nop 0\n" S16("v_cndmask_b32_dpp %0, %1, %0, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_e32 %1, %0\n v_cndmask_b32_dpp %2, %3, %2, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_e32 %3, %2\n v_cndmask_b32_dpp %4, %5, %4, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_e32 %5, %4\n v_cndmask_b32_dpp %6, %7, %6, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_e32 %7, %6") V4 :: "vcc");)
+KERNEL(k_cd_22,    asm volatile("s_mov_b64 vcc, 0x5555\n s_nop 0\n" S16("v_cndmask_b32_dpp %0, %1, %0, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_cndmask_b32_dpp %2, %3, %2, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_u32_e32 %1, %1, %0\n v_add_u32_e32 %3, %3, %2\n v_cndmask_b32_dpp %4, %5, %4, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_cndmask_b32_dpp %6, %7, %6, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_u32_e32 %5, %5, %4\n v_add_u32_e32 %7, %7, %6") V4 :: "vcc");)
+KERNEL(k_cd_vcmp,  asm volatile("v_cmp_gt_u32_e32 vcc, %0, %1\n s_nop 1\n" S16("v_cndmask_b32_dpp %0, %1, %0, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_cndmask_b32_dpp %2, %3, %2, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_cndmask_b32_dpp %4, %5, %4, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_cndmask_b32_dpp %6, %7, %6, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") V4 :: "vcc");)
+KERNEL(k_cd_salu,  asm volatile("s_mov_b64 vcc, 0x5555\n s_nop 0\n" S16("v_cndmask_b32_dpp %0, %1, %0, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n s_and_b32 s20, s20, s21\n v_cndmask_b32_dpp %2, %3, %2, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n s_and_b32 s20, s20, s21\n v_cndmask_b32_dpp %4, %5, %4, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n s_and_b32 s20, s20, s21\n v_cndmask_b32_dpp %6, %7, %6, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n s_and_b32 s20, s20, s21") V4 :: "vcc", "s20", "s21", "scc");)
+KERNEL(k_cd_bfi,   asm volatile("s_mov_b64 vcc, 0x5555\n s_nop 0\n" S16("v_cndmask_b32_dpp %0, %1, %0, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_bfi_b32 %1, %0, %1, %3\n v_cndmask_b32_dpp %2, %3, %2, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_bfi_b32 %3, %2, %3, %5\n v_cndmask_b32_dpp %4, %5, %4, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_bfi_b32 %5, %4, %5, %7\n v_cndmask_b32_dpp %6, %7, %6, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_bfi_b32 %7, %6, %7, %1") V4 :: "vcc");)
+KERNEL(k_movdpp_cnd64, asm volatile("s_mov_b64 s[20:21], 0x5555\n" S16("v_mov_b32_dpp %1, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_cndmask_b32_e64 %0, %1, %0, s[20:21]\n v_mov_b32_dpp %3, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_cndmask_b32_e64 %2, %3, %2, s[20:21]") V4 :: "s20", "s21");)
+KERNEL(k_movdpp_bfi, asm volatile(S16("v_mov_b32_dpp %1, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_bfi_b32 %0, %7, %1, %0\n v_mov_b32_dpp %3, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_bfi_b32 %2, %7, %3, %2") V4);)
+KERNEL(k_cnd32_b2b_2, asm volatile(S16("v_cndmask_b32_e32 %0, %0, %1, vcc\n v_cndmask_b32_e32 %2, %2, %3, vcc\n v_add_u32_e32 %4, %4, %5\n v_add_u32_e32 %6, %6, %7") V4 :: "vcc");)
+KERNEL(k_cnd32_3,  asm volatile(S16("v_cndmask_b32_e32 %0, %0, %1, vcc\n v_add_u32_e32 %2, %2, %3\n v_add_u32_e32 %4, %4, %5\n v_add_u32_e32 %6, %6, %7") V4 :: "vcc");)
+// --- fourth batch: how long may a run of VCC-implicit v_cndmask be?
+KERNEL(k_run3,  asm volatile(S16("v_cndmask_b32_e32 %0, %0, %1, vcc\n v_cndmask_b32_e32 %2, %2, %3, vcc\n v_cndmask_b32_e32 %4, %4, %5, vcc\n v_add_u32_e32 %6, %6, %7") V4 :: "vcc");)
+KERNEL(k_run4,  asm volatile(S16("v_cndmask_b32_e32 %0, %0, %1, vcc\n v_cndmask_b32_e32 %2, %2, %3, vcc\n v_cndmask_b32_e32 %4, %4, %5, vcc\n v_cndmask_b32_e32 %6, %6, %7, vcc\n v_add_u32_e32 %1, %1, %0\n v_add_u32_e32 %3, %3, %2") V4 :: "vcc");)
+KERNEL(k_run6,  asm volatile(S16("v_cndmask_b32_e32 %0, %0, %1, vcc\n v_cndmask_b32_e32 %2, %2, %3, vcc\n v_cndmask_b32_e32 %4, %4, %5, vcc\n v_cndmask_b32_e32 %6, %6, %7, vcc\n v_cndmask_b32_e32 %0, %0, %3, vcc\n v_cndmask_b32_e32 %2, %2, %5, vcc\n v_add_u32_e32 %1, %1, %0\n v_add_u32_e32 %3, %3, %2") V4 :: "vcc");)
+KERNEL(k_run3b, asm volatile(S16("v_cndmask_b32_e32 %0, %0, %1, vcc\n v_cndmask_b32_e32 %2, %2, %3, vcc\n v_cndmask_b32_e32 %4, %4, %5, vcc\n v_bfi_b32 %6, %7, %6, %0") V4 :: "vcc");)
 // LDS mixes (counted: the s_waitcnt at the end of the body drains them)
 KERNEL(k_ds_u8_mix, asm volatile(S16("ds_read_u8 %0, %8\n v_add_u32 %2, %2, %3\n v_add_u32 %4, %4, %5\n v_add_u32 %6, %6, %7") "\n s_waitcnt lgkmcnt(0)" V4 : "v"(la) : "memory");)
 KERNEL(k_ds_b64_mix, asm volatile(S16("ds_read_b64 %0, %7\n v_add_u32 %1, %1, %2\n v_add_u32 %3, %3, %4\n v_add_u32 %5, %5, %6") "\n s_waitcnt lgkmcnt(0)" : "+v"(A), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(la) : "memory");)
@@ -121,6 +137,10 @@ static Case cases[] = {
     C("readfirstlane", k_rfl, 64), C("add_u16", k_add_u16, 64), C("subb,3add", k_subb, 64), C("add,bfi,and,perm", k_simple_complex, 64), C("salu x4", k_salu4, 64),
     C("s_nop 0", k_snop, 64), C("add,ds_b32 1:1", k_add_lds1, 64), C("ds_read_b32 x4", k_ds_b32, 64), C("ds_read_u16 x4", k_ds_u16, 64), C("ds_write_b16 x4", k_ds_w16, 64),
     C("ds_write_b32 x4", k_ds_w32, 64), C("ds_read_b128 x4", k_ds_b128, 64), C("ds_bpermute x4", k_ds_perm, 64),
+    C("cnd_dpp,s_nop (x8)", k_cd_nop, 128), C("cnd_dpp,v_mov (x8)", k_cd_mov, 128), C("2cnd_dpp,2add (x8)", k_cd_22, 128), C("cnd_dpp b2b, valu vcc", k_cd_vcmp, 64),
+    C("cnd_dpp,s_and (x8)", k_cd_salu, 128), C("cnd_dpp,bfi (x8)", k_cd_bfi, 128), C("mov_dpp,cnd_e64", k_movdpp_cnd64, 64), C("mov_dpp,bfi", k_movdpp_bfi, 64),
+    C("2cnd_e32,2add", k_cnd32_b2b_2, 64), C("cnd_e32,3add", k_cnd32_3, 64),
+    C("3cnd_e32,add", k_run3, 64), C("4cnd_e32,2add", k_run4, 96), C("6cnd_e32,2add", k_run6, 128), C("3cnd_e32,bfi", k_run3b, 64),
 };
 
 int main(int argc, char **argv)

@@ -14,10 +14,16 @@
 // quad segments through the LDS tiles/rings of trc_io.h.  No MFMA: integer work, bounded by VALU
 // issue (4 cycles per wave64 op) and LDS, not by HBM (DESIGN.md has the arithmetic).
 #include <stdlib.h>
+#include <stdio.h>
+#include <string.h>
 #include "trc_io.h"
 #include "trc_launch.h"
 
 #define ENC_WAVE_LDS (TRC_SRING_BYTES)       // input arrives through an in-register quad transpose
+#define ENC_PACE_LDS 64u                     // TrcPace's progress counters, behind the symbol table
+#ifndef TRC_ENC_BALANCE
+#define TRC_ENC_BALANCE 1                    // workgroups of twelve waves that keep each other's pace when the launch is one residency round
+#endif
 #define DEC_WAVE_LDS (TRC_SRING_BYTES)       // 8.3 KiB: 12 waves + 34 KiB of tables fit one CU
 #ifndef TRC_DEC_LATE_FLUSH
 #define TRC_DEC_LATE_FLUSH 1    // decoder: a segment's output stores behind the next period's commit (0: before it, as in round 2)
@@ -134,8 +140,9 @@ __global__ __launch_bounds__(BLOCK) void trc_ans4s_enc_kernel(
     constexpr int SH = REP == 16 ? 8 : REP == 8 ? 7 : REP == 4 ? 6 : 4;
     static_assert(REP == 1 || REP == 8 || REP == 16, "replica count");
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    u8 *wbase = smem + TAB + wv * ENC_WAVE_LDS;
+    u8 *wbase = smem + TAB + ENC_PACE_LDS + wv * ENC_WAVE_LDS;
     for (u32 i = tid; i < 256u * REP; i += BLOCK) ((uint4 *)smem)[i] = etab_g[i / REP];
+    TrcPace pace; pace.init(trc_lds_addr(smem) + TAB, tid, wv);
     __syncthreads();
 
     WaveChunks wc;
@@ -175,6 +182,7 @@ __global__ __launch_bounds__(BLOCK) void trc_ans4s_enc_kernel(
     };
     take(S - 1u);
     for (u32 s = S - 1u;; s--) {
+        if (BLOCK > 256) pace.step(S - s);                     // (workgroups of more than four waves: some share a SIMD)
 #if !TRC_ENC_EARLY_COMMIT
         if (s != S - 1u) take(s);
 #endif
@@ -269,7 +277,11 @@ typedef __attribute__((address_space(3))) u32 trc_lds_u32;
 typedef StreamInT<true> AnsStreamIn;
 #define DEC_LDS_LUT   0u          // u8[32768]
 #define DEC_LDS_DTAB  32768u      // uint2[256]  { f, -c0 }
-#define DEC_LDS_WAVES 34816u
+#ifndef TRC_DEC_BALANCE
+#define TRC_DEC_BALANCE 2       // the waves of a SIMD keep each other's pace (TrcPace, trc_dev.h); 0: off; 1 / 2 / 3: every period / segment / second period
+#endif
+#define DEC_LDS_PROG  34816u      // u32[16]     progress counters, [SIMD][age]
+#define DEC_LDS_WAVES 34880u
 
 // one symbol, any position (the ragged tail of the last chunk)
 __device__ __forceinline__ u32 ans_get(u32 &st, AnsStreamIn &si)
@@ -328,6 +340,20 @@ __device__ __forceinline__ void ans_get_pair(u32 &s0, u32 &s1, u32 &sl0, u32 &sl
     s0 = t0; s1 = t1;
 }
 
+#ifdef TRC_DEC_PROF                                              // variant builds only (scripts/build_variant.sh prof -DTRC_DEC_PROF): where a decoder wave's cycles go
+__device__ unsigned long long trc_dec_prof[8];                  // fill, directory + prime, periods, flushes, symbols, total, waves
+__device__ unsigned long long trc_dec_wall[2 * 4096];            // wall clock (100 MHz) per wave: start, end (plain stores: same-address atomics from 3052 waves cost 500 us)
+#ifdef TRC_DEC_PROF_LIGHT                                        // wall-clock span of the launch only: no clock reads inside the loop (each one drains the LDS queue)
+#define PROF_T(x) const u64 x = 0
+#define PROF_ACC(acc, a, b)
+#else
+#define PROF_T(x) const u64 x = clock64()
+#define PROF_ACC(acc, a, b) acc += (b) - (a)
+#endif
+#else
+#define PROF_T(x)
+#define PROF_ACC(acc, a, b)
+#endif
 __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
     const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
     u64 n, u32 chunk, u32 nchunks,
@@ -337,6 +363,11 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
     if (trc_lds_addr(smem) != 0u) __builtin_trap();            // the decoders address LUT / dtab / rings by ABSOLUTE LDS offsets (DEC_LDS_*): a static __shared__ object in front of the dynamic segment must fail loudly, not decode from the wrong tables
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, BLOCK = blockDim.x;
     u8 *wbase = smem + DEC_LDS_WAVES + wv * DEC_WAVE_LDS;
+    PROF_T(pt0);
+#ifdef TRC_DEC_PROF
+    u64 acc_p = 0, acc_f = 0, acc_s = 0;
+    const u64 wall0 = wall_clock64();
+#endif
     WaveChunks wc;
     wc.c0 = (blockIdx.x * (BLOCK / 64) + wv) * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
     wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
@@ -345,6 +376,14 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
     const bool alive = lane < wc.rows;
     const u32 c = wc.c0 + lane;
     const u32 len = alive ? wc.len_of(lane) : 0u;
+    // Round 5, start-up order.  In-kernel clocks put 8 us of the 66 between the table fill and the first symbol: a chain of
+    // dependent round trips (tables -> barrier -> clen -> group base -> states and first ring fill), the last of them a burst of
+    // 128 bytes per stream from every wave of the launch at once.  Now: the directory entry and the group base are requested
+    // FIRST, together with the tables (nothing of them depends on the tables); the states and the ring fill are requested before
+    // the barrier, which waits for LDS only (__syncthreads() would sit out every load in flight); the rings' second halves land
+    // one period later (StreamInT::prime_issue / prime_land).
+    const u32 cl_raw = alive ? clen[c] : 0u;
+    const u64 gbase0 = valid ? trc_group_base(goff, gsum, wc.c0 >> 6) : 0ull;
     // the table fill as one batch of loads (a plain copy loop waits for each of its three loads before it issues the next:
     // 75.9 -> 73.6 us for 100 MB in round 2)
     {
@@ -363,15 +402,14 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
             for (u32 i = tid; i < 256; i += BLOCK) { const u32 d = dtab_g[i]; dtab[i] = make_uint2(d >> 16, 0u - (d & 0xffffu)); }
         }
     }
-    __syncthreads();
-    if (!valid) return;
-#ifdef TRC_DEC_ABL_EXIT
-    return;
+    PROF_T(pt1);
+#if TRC_DEC_BALANCE
+    TrcPace pace; pace.init(DEC_LDS_PROG, tid, wv);
 #endif
 
-    const u32 cl = alive ? trc_min(clen[c], len) : 0u;        // a directory entry above the chunk length (corrupt input) reads as raw
+    const u32 cl = alive ? trc_min(cl_raw, len) : 0u;         // a directory entry above the chunk length (corrupt input) reads as raw
     const u32 ex = trc_wave_incl_scan(cl) - cl;
-    const u64 off = trc_group_base(goff, gsum, wc.c0 >> 6) + ex;
+    const u64 off = gbase0 + ex;
     const bool coded = alive && cl != len;
 
     QuadOut tout; tout.base = out + (u64)wc.c0 * chunk;        // output leaves through an in-register quad transpose
@@ -380,11 +418,14 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
     si.gbase = payload; si.soff = off + 8; si.lim = trc_sub_sat(cl, 8u);   // words follow the two states
     u32 sa = 0, sb = 0;
     if (coded) { sa = trc_ld32_a2(payload + off); sb = trc_ld32_a2(payload + off + 4); }   // sa = enc state 1, sb = enc state 0
-#ifdef TRC_DEC_ABL_NOPRIME                                      // timing ablations (results wrong by construction; scripts/gpu_ablate.sh)
-    si.prime(false); si.lbytes = coded ? TRC_SRING : 0u;
-#else
-    si.prime(coded);
+    AnsStreamIn::Prime P;
+    si.prime_issue(coded, P);
+    trc_lds_barrier();                                         // the tables are in place (LDS only: the loads above stay in flight)
+    if (!valid) return;
+#ifdef TRC_DEC_ABL_EXIT
+    return;
 #endif
+    si.prime_land(P, 0, coded);
 
     const u32 S = chunk / TRC_SEG;
     const u32 body4 = len & ~3u;
@@ -395,19 +436,29 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
 #endif
     u32 sel_lo = 0x05040100u, sel_hi = 0x05040302u;            // byte selectors of the pair step's permutes (VGPR operands: VCC takes the one constant-bus slot)
     asm volatile("" : "+v"(sel_lo), "+v"(sel_hi));
+    PROF_T(pt2);
     for (u32 s = 0; s < S; s++) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const u32 p0 = s * TRC_SEG + (u32)k * 16u;          // chunk offset of this 16-byte piece
+#if TRC_DEC_BALANCE
+            // (policies measured, profiles/r05_notes.md: every period 64 us, every segment 62-63, every second period 62-63, graded
+            // priorities 63, laggards 3 / leader 1: 63; off: 67)
+            if (TRC_DEC_BALANCE == 1 || k == 0 || (TRC_DEC_BALANCE == 3 && k == 2)) pace.step(s * 4u + (u32)k + 1u);
+#endif
+            if (k == 1 && s == 0) si.prime_land(P, 1, coded);   // the rings' second halves (requested with the first, start-up comment)
             // period boundary: land the round requested 16 symbols ago, request the next one
 #ifdef TRC_DEC_ABL_NOPERIOD
             si.lbytes = si.rpos + TRC_SRING;
 #else
+            PROF_T(qa);
             si.period(coded && p0 < len, k & 1);
+            PROF_T(qb); PROF_ACC(acc_p, qa, qb);
 #endif
 #if TRC_DEC_LATE_FLUSH && !defined(TRC_DEC_ABL_NOFLUSH)
             if (k == 0 && s > 0) tout.flush(wc, (s - 1u) * TRC_SEG);   // the segment before: behind this period's commit (header comment)
 #endif
+            PROF_T(qc); PROF_ACC(acc_f, qb, qc);
             if (coded && p0 + 16u <= len) {
                 u32 w[4];
                 u32 hc = si.rpos >> 1;
@@ -426,6 +477,7 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
                 }
                 si.rpos = hc << 1;
                 tout.put((u32)k, make_uint4(w[0], w[1], w[2], w[3]));
+                PROF_T(qd); PROF_ACC(acc_s, qc, qd);
             } else if (coded && p0 < len) {                    // last chunk's final partial piece
                 for (u32 pos = p0; pos < len; pos++)
                     dst[pos] = (u8)((pos >= body4 || !(pos & 1u)) ? ans_get(sb, si) : ans_get(sa, si));
@@ -440,6 +492,21 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
 #endif
     // chunks stored raw (clen == len): the whole wave copies them, one after the other
     trc_wave_copy_raw(__ballot(alive && cl == len && len != 0), off, len, out + (u64)wc.c0 * chunk, chunk, payload);
+#ifdef TRC_DEC_PROF
+    if (lane == 0) {
+#ifdef TRC_DEC_PROF_LIGHT
+        const u64 pt3 = 0;
+#else
+        const u64 pt3 = clock64();
+#endif
+#ifndef TRC_DEC_PROF_LIGHT
+        atomicAdd(&trc_dec_prof[0], pt1 - pt0); atomicAdd(&trc_dec_prof[1], pt2 - pt1); atomicAdd(&trc_dec_prof[2], acc_p);
+        atomicAdd(&trc_dec_prof[3], acc_f); atomicAdd(&trc_dec_prof[4], acc_s); atomicAdd(&trc_dec_prof[5], pt3 - pt0); atomicAdd(&trc_dec_prof[6], 1ull);
+#endif
+        const u32 wid = (blockIdx.x * (BLOCK / 64) + wv) & 4095u;
+        trc_dec_wall[2 * wid] = wall0; trc_dec_wall[2 * wid + 1] = wall_clock64();
+    }
+#endif
 }
 
 // ---------------------------------------------------------------- decode, two LANES per chunk ---
@@ -597,9 +664,9 @@ static void ans4s_enc_launch(u32 wpb, const uint8_t *d_in, size_t n, uint32_t ch
 {
     const uint4 *etab = (const uint4 *)(w.tables + TRC_TAB_ENC);
     const u32 nwaves = w.ngroups;
-    const size_t sm = 4096u * REP + wpb * ENC_WAVE_LDS;
+    const size_t sm = 4096u * REP + ENC_PACE_LDS + wpb * ENC_WAVE_LDS;
 #define TRC_ENC_CASE(W)                                                                                              \
-    case W: TRC_RAISE_LDS_ONCE((trc_ans4s_enc_kernel<64 * W, REP>), 4096u * REP + W * ENC_WAVE_LDS);                 \
+    case W: TRC_RAISE_LDS_ONCE((trc_ans4s_enc_kernel<64 * W, REP>), 4096u * REP + ENC_PACE_LDS + W * ENC_WAVE_LDS);  \
             TRC_LAUNCH_TIMED((trc_ans4s_enc_kernel<64 * W, REP>), dim3((nwaves + W - 1) / W), dim3(64 * W), sm, s,   \
                              d_in, (u64)n, chunk, w.nchunks, etab, w.scratch, w.stride, d_clen, w.gsum); break;
     switch (wpb) {
@@ -616,6 +683,10 @@ void trc_launch_ans4s_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const T
     static const int env_wpb = getenv("TRC_ENC_WPB") ? atoi(getenv("TRC_ENC_WPB")) : 0;
     int rep = env_rep ? env_rep : TRC_ENC_REP_DEFAULT;
     u32 wpb = rep == 8 ? 12u : 4u;
+    // one residency round (at most twelve waves per CU): one workgroup of twelve waves per CU, whose waves keep each other's pace
+    // (TrcPace: they share SIMDs by construction); more than a round: workgroups of four, sixteen waves per CU, new ones moving in
+    // as old ones end
+    if (TRC_ENC_BALANCE && nwaves <= 12u * 256u) wpb = 12u;
     if (env_wpb == 1 || env_wpb == 4 || env_wpb == 12) wpb = (u32)env_wpb;
     if (nwaves < 2048) { rep = 1; wpb = 1; }                 // few waves: one per workgroup so they spread over all CUs (12.4 KiB -> 12 per CU)
     if (rep == 8) ans4s_enc_launch<8>(wpb, d_in, n, chunk, w, d_clen, s);
@@ -645,6 +716,38 @@ void trc_launch_ans4s_dec(const uint8_t *d_payload, const uint32_t *d_clen, size
     wpb = wpb < 1u ? 1u : wpb > 14u ? 14u : wpb;               // 34 KiB + 14 x 8.3 KiB = 150 KiB of the CU's 160
     if (const char *e = getenv("TRC_DEC_WPB")) { const u32 v = (u32)atoi(e); if (v >= 1 && v <= 14) wpb = v; }   // tuning aid
     const size_t sm = DEC_LDS_WAVES + wpb * DEC_WAVE_LDS;
+#ifdef TRC_DEC_PROF
+#endif
     TRC_LAUNCH_TIMED(trc_ans4s_dec_kernel, dim3((nwaves + wpb - 1) / wpb), dim3(64 * wpb), sm, s,
                        d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, lut, dtab, d_out);
+#ifdef TRC_DEC_PROF
+    {
+        static int calls = 0;
+        if (++calls % 64 == 0) {
+            unsigned long long h[8];
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(trc_dec_prof), sizeof h);
+            const double wv = (double)h[6];
+            fprintf(stderr, "[dec prof] waves %.0f  cycles per wave: fill %.0f  dir+prime %.0f  periods %.0f  flushes %.0f  symbols %.0f  total %.0f\n",
+                    wv, h[0] / wv, h[1] / wv, h[2] / wv, h[3] / wv, h[4] / wv, h[5] / wv);
+            memset(h, 0, sizeof h);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(trc_dec_prof), h, sizeof h);
+            static unsigned long long wl[2 * 4096];
+            (void)hipMemcpyFromSymbol(wl, HIP_SYMBOL(trc_dec_wall), sizeof wl);
+            const unsigned nw = nwaves < 4096u ? nwaves : 4096u;
+            unsigned long long t0 = ~0ull;
+            for (unsigned i = 0; i < nw; i++) if (wl[2 * i] && wl[2 * i] < t0) t0 = wl[2 * i];
+            // end times by the wave's place in its workgroup (waves k, k + 4, k + 8 of a workgroup share SIMD k: age order on the SIMD)
+            double sum[3] = { 0, 0, 0 }, mx[3] = { 0, 0, 0 }, mn[3] = { 1e9, 1e9, 1e9 }; unsigned cnt[3] = { 0, 0, 0 };
+            double smax = 0;
+            for (unsigned i = 0; i < nw; i++) {
+                const unsigned age = (i % wpb) / 4u; if (age > 2 || !wl[2 * i]) continue;
+                const double e = (wl[2 * i + 1] - t0) * 0.01, st = (wl[2 * i] - t0) * 0.01;
+                sum[age] += e; cnt[age]++; if (e > mx[age]) mx[age] = e; if (e < mn[age]) mn[age] = e; if (st > smax) smax = st;
+            }
+            fprintf(stderr, "[dec wall, us since the first wave's start] last start %.2f; wave ends by age on the SIMD (min / mean / max): first %.1f / %.1f / %.1f, second %.1f / %.1f / %.1f, third %.1f / %.1f / %.1f\n",
+                    smax, mn[0], sum[0] / (cnt[0] ? cnt[0] : 1), mx[0], mn[1], sum[1] / (cnt[1] ? cnt[1] : 1), mx[1], mn[2], sum[2] / (cnt[2] ? cnt[2] : 1), mx[2]);
+        }
+    }
+#endif
 }

@@ -82,6 +82,35 @@ __device__ __forceinline__ void trc_lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// ---- pace-keeping among the waves of a SIMD (round 5) -------------------------------------------------------------------
+// The SIMD's arbiter serves its OLDEST wave first.  In a launch that is one residency round (100 MB at the bench chunk: every wave
+// starts within 0.6 us of the first) the three waves of a SIMD therefore do not advance together: wall clocks per wave of the
+// static rANS decoder (profiles/r05_notes.md) -- the first ends at 48 us, the second at 54, the third at 63; for the last 9 us of
+// the launch every SIMD runs ONE wave, at a lone wave's issue rate (6-7 cycles per instruction against ~4 per SIMD with three).
+// Here every wave publishes a progress counter in LDS ([SIMD][age], 64 bytes per workgroup) at a wave-uniform point of its main
+// loop and reads the counters of its SIMD: behind the furthest -> s_setprio 3, in front -> s_setprio 0.  They end together:
+// decoder 67 -> 62-63 us.  A workgroup's own waves k, k + 4, k + 8 ... share SIMD k (scripts/probe/residency.hip), so this needs
+// workgroups of 8 and more waves; with four or fewer it does nothing.
+typedef __attribute__((address_space(3))) u32 trc_lds_u32_t;
+struct TrcPace {
+    u32 mine, simd;
+    // `prog` = LDS byte address of 64 bytes nobody else uses; call before a workgroup barrier
+    __device__ __forceinline__ void init(u32 prog, u32 tid, u32 wv)
+    {
+        if (tid < 16u) *(trc_lds_u32_t *)(uintptr_t)(prog + tid * 4u) = 0u;
+        mine = prog + ((wv & 3u) * 4u + ((wv >> 2) & 3u)) * 4u; simd = prog + (wv & 3u) * 16u;
+    }
+    // `progress` counts up, wave-uniform
+    __device__ __forceinline__ void step(u32 progress)
+    {
+        *(trc_lds_u32_t *)(uintptr_t)mine = progress;
+        const uint4 pr = trc_ldsr128(simd);
+        const u32 a = pr.x > pr.y ? pr.x : pr.y, b = pr.z > pr.w ? pr.z : pr.w;
+        const u32 lead = (u32)__builtin_amdgcn_readfirstlane((int)(a > b ? a : b));
+        if (lead > progress) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+    }
+};
+
 // (a & m) | (b & ~m) as the one instruction it is.  From the C form the compiler builds and / and-or pairs, compares and selects
 // or -- for a group of selects on one condition -- a divergent if / else; in the one-wave-per-SIMD kernels every one of those is slower.
 __device__ __forceinline__ u32 trc_bfi(u32 m, u32 a, u32 b)

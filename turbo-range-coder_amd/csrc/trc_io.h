@@ -95,41 +95,53 @@ __device__ __forceinline__ u32 trc_quad_xor2(u32 v) { return (u32)__builtin_amdg
 // (quad base + j) held (an involution, used in both directions).
 // Round 3: the DPP lane swap folded into the select (v_cndmask_b32_dpp: D = VCC ? src1 : quad_perm(src0)) -- one VALU per
 // dword and stage, 32 per 64 bytes, where the C form below costs 64 (select the word to send, v_mov_dpp, two selects).
-// VCC holds the lane-parity mask of the half-stage; four half-stages, each one asm block over the four columns.  A DPP
-// source must have been written at least two instructions earlier and the compiler cannot see DPP inside an asm block:
-// every block starts with s_mov vcc + s_nop.
 #ifndef TRC_QUAD_DPP
 #define TRC_QUAD_DPP 1
 #endif
-#define TRC_QT_HALF(PERM, MASK, D0, D1, D2, D3, D4, D5, D6, D7, S0, T0, S1, T1, S2, T2, S3, T3, S4, T4, S5, T5, S6, T6, S7, T7)      \
-    asm volatile("s_mov_b64 vcc, %[mk]\n\ts_nop 0\n\t"                                                                              \
-        "v_cndmask_b32_dpp %[d0], %[s0], %[t0], vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                                        \
-        "v_cndmask_b32_dpp %[d1], %[s1], %[t1], vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                                        \
-        "v_cndmask_b32_dpp %[d2], %[s2], %[t2], vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                                        \
-        "v_cndmask_b32_dpp %[d3], %[s3], %[t3], vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                                        \
-        "v_cndmask_b32_dpp %[d4], %[s4], %[t4], vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                                        \
-        "v_cndmask_b32_dpp %[d5], %[s5], %[t5], vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                                        \
-        "v_cndmask_b32_dpp %[d6], %[s6], %[t6], vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                                        \
-        "v_cndmask_b32_dpp %[d7], %[s7], %[t7], vcc " PERM " row_mask:0xf bank_mask:0xf"                                             \
-        : [d0] "=&v"(D0), [d1] "=&v"(D1), [d2] "=&v"(D2), [d3] "=&v"(D3), [d4] "=&v"(D4), [d5] "=&v"(D5), [d6] "=&v"(D6), [d7] "=&v"(D7) \
-        : [mk] "s"(MASK), [s0] "v"(S0), [t0] "v"(T0), [s1] "v"(S1), [t1] "v"(T1), [s2] "v"(S2), [t2] "v"(T2), [s3] "v"(S3), [t3] "v"(T3), \
-          [s4] "v"(S4), [t4] "v"(T4), [s5] "v"(S5), [t5] "v"(T5), [s6] "v"(S6), [t6] "v"(T6), [s7] "v"(S7), [t7] "v"(T7) : "vcc")
+// Round 5: runs of v_cndmask_b32 in the encodings that read VCC implicitly (VOP2, DPP, SDWA) are pathological on gfx950 -- from the
+// third one on EACH occupies the SIMD for ~22.7 cycles whatever else is resident (scripts/probe/valu_occ.hip, profiles/r05_valu_rates.txt:
+// "cnd_dpp vcc b2b" 22.7 cycles per instruction at 1..8 waves per SIMD; an s_nop or a scalar instruction between them changes
+// nothing, a plain vector instruction does: "cnd_dpp,v_mov" 4.4-5.5).  Rounds 3-4 ran EIGHT of them back to back per half-stage:
+// 32 x 22.7 = 727 SIMD cycles per 64 bytes and wave, ~11 % of the static decoder.  Now every v_cndmask_b32_dpp is followed by
+// two instructions that do not read VCC: of a pair of rows (X, Y) that swap halves with the partner lane, the X side is
+//     new X = keep ? X : dpp(Y)            one v_cndmask_b32_dpp (VCC = the lanes that keep X)
+// and the Y side
+//     new Y = dpp(X); new Y = keepY ? Y : new Y    v_mov_b32_dpp + v_cndmask_b32_e64 on an SGPR-pair mask (VOP3: no such penalty)
+// 48 vector instructions of the 4-cycle class per 64 bytes instead of 32 of the 22.7-cycle kind.  One block = one pair of rows
+// (4 columns); a DPP source must have been written at least two instructions earlier and the compiler cannot see DPP inside an
+// asm block: every block starts with s_mov vcc + s_nop.
+#define TRC_QT_PAIR(PERM, KEEPX, KEEPY, A0, A1, A2, A3, B0, B1, B2, B3, X0, X1, X2, X3, Y0, Y1, Y2, Y3)                             \
+    asm volatile("s_mov_b64 vcc, %[kx]\n\ts_nop 0\n\t"                                                                              \
+        "v_cndmask_b32_dpp %[a0], %[y0], %[x0], vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                                        \
+        "v_mov_b32_dpp %[b0], %[x0] " PERM " row_mask:0xf bank_mask:0xf\n\t"                                                        \
+        "v_cndmask_b32_e64 %[b0], %[b0], %[y0], %[ky]\n\t"                                                                          \
+        "v_cndmask_b32_dpp %[a1], %[y1], %[x1], vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                                        \
+        "v_mov_b32_dpp %[b1], %[x1] " PERM " row_mask:0xf bank_mask:0xf\n\t"                                                        \
+        "v_cndmask_b32_e64 %[b1], %[b1], %[y1], %[ky]\n\t"                                                                          \
+        "v_cndmask_b32_dpp %[a2], %[y2], %[x2], vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                                        \
+        "v_mov_b32_dpp %[b2], %[x2] " PERM " row_mask:0xf bank_mask:0xf\n\t"                                                        \
+        "v_cndmask_b32_e64 %[b2], %[b2], %[y2], %[ky]\n\t"                                                                          \
+        "v_cndmask_b32_dpp %[a3], %[y3], %[x3], vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                                        \
+        "v_mov_b32_dpp %[b3], %[x3] " PERM " row_mask:0xf bank_mask:0xf\n\t"                                                        \
+        "v_cndmask_b32_e64 %[b3], %[b3], %[y3], %[ky]"                                                                              \
+        : [a0] "=&v"(A0), [a1] "=&v"(A1), [a2] "=&v"(A2), [a3] "=&v"(A3), [b0] "=&v"(B0), [b1] "=&v"(B1), [b2] "=&v"(B2), [b3] "=&v"(B3) \
+        : [kx] "s"(KEEPX), [ky] "s"(KEEPY), [x0] "v"(X0), [x1] "v"(X1), [x2] "v"(X2), [x3] "v"(X3),                                 \
+          [y0] "v"(Y0), [y1] "v"(Y1), [y2] "v"(Y2), [y3] "v"(Y3) : "vcc")
 __device__ __forceinline__ void trc_quad_transpose_dpp(u32 (&m)[4][4])
 {
     const u64 even = 0x5555555555555555ull, odd = 0xAAAAAAAAAAAAAAAAull, lo2 = 0x3333333333333333ull, hi2 = 0xCCCCCCCCCCCCCCCCull;
     u32 a[4][4];
-    // stage 1, lane ^ 1: even lanes keep m[k] and take the partner's m[k] as m[k+1]; odd lanes take the partner's m[k+1] as m[k]
-    //   new m[k]   = even ? m[k]   : dpp(m[k+1])        (k = 0, 2)
-    //   new m[k+1] = odd  ? m[k+1] : dpp(m[k])
-    TRC_QT_HALF("quad_perm:[1,0,3,2]", even, a[0][0], a[0][1], a[0][2], a[0][3], a[2][0], a[2][1], a[2][2], a[2][3],
-                m[1][0], m[0][0], m[1][1], m[0][1], m[1][2], m[0][2], m[1][3], m[0][3], m[3][0], m[2][0], m[3][1], m[2][1], m[3][2], m[2][2], m[3][3], m[2][3]);
-    TRC_QT_HALF("quad_perm:[1,0,3,2]", odd, a[1][0], a[1][1], a[1][2], a[1][3], a[3][0], a[3][1], a[3][2], a[3][3],
-                m[0][0], m[1][0], m[0][1], m[1][1], m[0][2], m[1][2], m[0][3], m[1][3], m[2][0], m[3][0], m[2][1], m[3][1], m[2][2], m[3][2], m[2][3], m[3][3]);
-    // stage 2, lane ^ 2 on (k, k+2), k = 0, 1
-    TRC_QT_HALF("quad_perm:[2,3,0,1]", lo2, m[0][0], m[0][1], m[0][2], m[0][3], m[1][0], m[1][1], m[1][2], m[1][3],
-                a[2][0], a[0][0], a[2][1], a[0][1], a[2][2], a[0][2], a[2][3], a[0][3], a[3][0], a[1][0], a[3][1], a[1][1], a[3][2], a[1][2], a[3][3], a[1][3]);
-    TRC_QT_HALF("quad_perm:[2,3,0,1]", hi2, m[2][0], m[2][1], m[2][2], m[2][3], m[3][0], m[3][1], m[3][2], m[3][3],
-                a[0][0], a[2][0], a[0][1], a[2][1], a[0][2], a[2][2], a[0][3], a[2][3], a[1][0], a[3][0], a[1][1], a[3][1], a[1][2], a[3][2], a[1][3], a[3][3]);
+    // stage 1, lane ^ 1 on rows (k, k + 1), k = 0, 2: even lanes keep m[k] and take the partner's m[k] as m[k+1]; odd lanes keep
+    // m[k+1] and take the partner's m[k+1] as m[k]
+    TRC_QT_PAIR("quad_perm:[1,0,3,2]", even, odd, a[0][0], a[0][1], a[0][2], a[0][3], a[1][0], a[1][1], a[1][2], a[1][3],
+                m[0][0], m[0][1], m[0][2], m[0][3], m[1][0], m[1][1], m[1][2], m[1][3]);
+    TRC_QT_PAIR("quad_perm:[1,0,3,2]", even, odd, a[2][0], a[2][1], a[2][2], a[2][3], a[3][0], a[3][1], a[3][2], a[3][3],
+                m[2][0], m[2][1], m[2][2], m[2][3], m[3][0], m[3][1], m[3][2], m[3][3]);
+    // stage 2, lane ^ 2 on rows (k, k + 2), k = 0, 1
+    TRC_QT_PAIR("quad_perm:[2,3,0,1]", lo2, hi2, m[0][0], m[0][1], m[0][2], m[0][3], m[2][0], m[2][1], m[2][2], m[2][3],
+                a[0][0], a[0][1], a[0][2], a[0][3], a[2][0], a[2][1], a[2][2], a[2][3]);
+    TRC_QT_PAIR("quad_perm:[2,3,0,1]", lo2, hi2, m[1][0], m[1][1], m[1][2], m[1][3], m[3][0], m[3][1], m[3][2], m[3][3],
+                a[1][0], a[1][1], a[1][2], a[1][3], a[3][0], a[3][1], a[3][2], a[3][3]);
 }
 __device__ __forceinline__ void trc_quad_transpose_c(u32 (&m)[4][4]);
 __device__ __forceinline__ void trc_quad_transpose(u32 (&m)[4][4])
@@ -435,6 +447,50 @@ struct StreamInT {
                 put_piece(at[g] + (ra(0, TRC_SEG) - ra(0, 0)), v[2 * g + 1]);      // ring offset 64
             }
         if (alive) lbytes = TRC_SRING;
+    }
+    // Round 5: the first fill in two steps.  At the start of a decoder all waves of the launch ask for the first 128 bytes of all
+    // their streams at once -- 100 MB at chunk 512: 25 MB in one burst -- and, in-kernel clocks say (profiles/r05_notes.md), wait
+    // ~8 us for it.  prime_issue() requests the FIRST halves of all rings, then the second halves (loads return in order), and
+    // lands nothing; prime_land(P, 0) needs only the first four to be back, the wave decodes its first period on 64 bytes per ring
+    // (<= 32 are consumed), prime_land(P, 1) lands the rest.  Between the two the second half counts as a segment in flight
+    // (infl = 1), so the refill protocol neither asks for it again nor takes its ring slot.
+    struct Prime { uint4 v[8]; u32 at[4]; };
+    __device__ __forceinline__ void prime_issue(bool alive, Prime &P)
+    {
+        rpos = 0; lbytes = 0; infl = 0; mineA = mineB = false; hokA = hokB = false;
+        rw = trc_lds_addr(rings);
+        {
+            const u32 blo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)soff), bhi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(soff >> 32));
+            wbase = ((u64)bhi << 32) | blo;
+            srel = (u32)(soff - wbase);
+        }
+        hvA = hvB = make_uint4(0, 0, 0, 0); hdA = hdB = 0;
+        const u64 amask = __ballot(alive);
+        const u32 lane = trc_lane(), q = lane >> 2, part = lane & 3u;
+        const u8 *src[4];
+#pragma unroll
+        for (u32 g = 0; g < 4; g++) {
+            const u32 j = g * 16u + q;                          // the lane this quad serves in turn g
+            const u32 sr = (u32)__shfl((int)srel, (int)j, 64);
+            const bool on = (amask >> j) & 1u;
+            P.at[g] = on ? rw + ra(j, 0) + part * PIECE_STEP : ~0u;
+            src[g] = gbase + wbase + (on ? sr : 0u) + (part << 4);      // (a turn with nobody to serve re-reads the wave's first stream: every load is issued, the compiler counts them)
+        }
+#pragma unroll
+        for (u32 g = 0; g < 4; g++) P.v[2 * g] = trc_ld16_a2(src[g]);
+#pragma unroll
+        for (u32 g = 0; g < 4; g++) P.v[2 * g + 1] = trc_ld16_a2(src[g] + TRC_SEG);
+    }
+    __device__ __forceinline__ void prime_land(const Prime &P, int half, bool alive)
+    {
+        const u32 part = trc_lane() & 3u;
+#pragma unroll
+        for (u32 g = 0; g < 4; g++)
+            if (P.at[g] != ~0u) {
+                if (half == 0) put_piece(P.at[g] | (part == 0u ? 1u : 0u), P.v[2 * g]);      // ring offset 0: its first dword is mirrored behind the ring
+                else put_piece(P.at[g] + (ra(0, TRC_SEG) - ra(0, 0)), P.v[2 * g + 1]);       // ring offset 64
+            }
+        if (alive) { if (half == 0) { lbytes = TRC_SEG; infl = 1; } else { lbytes = TRC_SRING; infl -= 1; } }
     }
     // Round 3: a refill round costs ONE cross-lane round trip and the landing of a piece one address operation.
     //   * the up to 16 lanes picked in a round PUSH what their helpers need -- the source offset of the segment and the LDS

@@ -164,7 +164,9 @@ struct LaneInWide {
 
 // Round 4, the rANS byte decoders (four renormalisation points per group of two bytes, in stream order): the next FOUR 16-bit units
 // of the lane's stream ride in two registers (l0 = units 0-1, l1 = units 2-3).  A point takes the low half of l0 and moves the rest
-// down where it fires -- mask and count come off the carry chain of `state - 2^15`, the moves are bit-selects, and a point only
+// down where it fires -- mask and count come off the SIGN of `state - 2^15` (a state is below 2^31: v_subrev, v_ashrrev 31, v_sub; round 4 took
+// them off a carry chain, v_subrev_co / v_subb / v_addc back to back -- three instructions as well, but a VALU read of VCC straight behind
+// the VALU write of it, where the compiler keeps two wait states on gfx950: scripts/check_isa_hazards.py), the moves are bit-selects, and a point only
 // moves what the points behind it can still reach (point 3 moves nothing).  One 16-byte load per group, from the stream position at
 // the START of the group (units 0-7): the group consumes cnt <= 4 units, so the next look-ahead is units cnt .. cnt + 3 of it, taken
 // out at the end of the group with a three-level bit-select.  LaneInWide's peek (a three-level select of a 32-byte register window
@@ -189,41 +191,41 @@ struct LaneLook16 {
         u32 m, t;
         const u32 sel = 0x05040100u;                            // v_perm: { st.b1, st.b0, l0.b1, l0.b0 } = st << 16 | unit
         if (J == 0)
-            asm("v_subrev_co_u32_e32 %1, vcc, 0x8000, %2\n\t"
-                "v_subb_co_u32_e64 %0, vcc, 0, 0, vcc\n\t"
-                "v_addc_co_u32_e32 %3, vcc, 0, %3, vcc\n\t"
+            asm("v_subrev_u32_e32 %1, 0x8000, %2\n\t"
+                "v_ashrrev_i32_e32 %0, 31, %1\n\t"
+                "v_sub_u32_e32 %3, %3, %0\n\t"
                 "v_perm_b32 %1, %2, %4, %6\n\t"
                 "v_bfi_b32 %2, %0, %1, %2\n\t"
                 "v_alignbit_b32 %1, %5, %4, 16\n\t"
                 "v_bfi_b32 %4, %0, %1, %4\n\t"
                 "v_lshrrev_b32_e32 %1, 16, %5\n\t"
                 "v_bfi_b32 %5, %0, %1, %5"
-                : "=&v"(m), "=&v"(t), "+v"(st), "+v"(cnt), "+v"(l0), "+v"(l1) : "s"(sel) : "vcc");
+                : "=&v"(m), "=&v"(t), "+v"(st), "+v"(cnt), "+v"(l0), "+v"(l1) : "s"(sel));
         else if (J == 1)
-            asm("v_subrev_co_u32_e32 %1, vcc, 0x8000, %2\n\t"
-                "v_subb_co_u32_e64 %0, vcc, 0, 0, vcc\n\t"
-                "v_addc_co_u32_e32 %3, vcc, 0, %3, vcc\n\t"
+            asm("v_subrev_u32_e32 %1, 0x8000, %2\n\t"
+                "v_ashrrev_i32_e32 %0, 31, %1\n\t"
+                "v_sub_u32_e32 %3, %3, %0\n\t"
                 "v_perm_b32 %1, %2, %4, %6\n\t"
                 "v_bfi_b32 %2, %0, %1, %2\n\t"
                 "v_alignbit_b32 %1, %5, %4, 16\n\t"
                 "v_bfi_b32 %4, %0, %1, %4"
-                : "=&v"(m), "=&v"(t), "+v"(st), "+v"(cnt), "+v"(l0) : "v"(l1), "s"(sel) : "vcc");
+                : "=&v"(m), "=&v"(t), "+v"(st), "+v"(cnt), "+v"(l0) : "v"(l1), "s"(sel));
         else if (J == 2)
-            asm("v_subrev_co_u32_e32 %1, vcc, 0x8000, %2\n\t"
-                "v_subb_co_u32_e64 %0, vcc, 0, 0, vcc\n\t"
-                "v_addc_co_u32_e32 %3, vcc, 0, %3, vcc\n\t"
+            asm("v_subrev_u32_e32 %1, 0x8000, %2\n\t"
+                "v_ashrrev_i32_e32 %0, 31, %1\n\t"
+                "v_sub_u32_e32 %3, %3, %0\n\t"
                 "v_perm_b32 %1, %2, %4, %5\n\t"
                 "v_bfi_b32 %2, %0, %1, %2\n\t"
                 "v_lshrrev_b32_e32 %1, 16, %4\n\t"
                 "v_bfi_b32 %4, %0, %1, %4"
-                : "=&v"(m), "=&v"(t), "+v"(st), "+v"(cnt), "+v"(l0) : "s"(sel) : "vcc");
+                : "=&v"(m), "=&v"(t), "+v"(st), "+v"(cnt), "+v"(l0) : "s"(sel));
         else
-            asm("v_subrev_co_u32_e32 %1, vcc, 0x8000, %2\n\t"
-                "v_subb_co_u32_e64 %0, vcc, 0, 0, vcc\n\t"
-                "v_addc_co_u32_e32 %3, vcc, 0, %3, vcc\n\t"
+            asm("v_subrev_u32_e32 %1, 0x8000, %2\n\t"
+                "v_ashrrev_i32_e32 %0, 31, %1\n\t"
+                "v_sub_u32_e32 %3, %3, %0\n\t"
                 "v_perm_b32 %1, %2, %4, %5\n\t"
                 "v_bfi_b32 %2, %0, %1, %2"
-                : "=&v"(m), "=&v"(t), "+v"(st), "+v"(cnt) : "v"(l0), "s"(sel) : "vcc");
+                : "=&v"(m), "=&v"(t), "+v"(st), "+v"(cnt) : "v"(l0), "s"(sel));
     }
     // the group took cnt (0..4) units; W = fetch() of the group's start
     __device__ __forceinline__ void end_group(u32 cnt, const uint4 W)

@@ -336,22 +336,25 @@ __global__ __launch_bounds__(128 * TRC_WPG) void trc_rcb_enc_mc_kernel(
     // ran the encoder in 0.91 instead of 1.33 ms: a third of the coder wave was mask algebra in SGPRs -- two / pend / carry flags,
     // each a VALU -> SALU -> VALU round trip -- and one emit per byte; profiles/r04_notes.md):
     //  * the carry of `low +=` is a third limb `lx` (0 / 1) fed by the add's carry-out (v_addc), not an ORed lane mask;
-    //  * a renormalisation point shifts the state and pushes one bit into `rnb` ("there is a word") and one into `cyb` ("it carries
+    //  * a renormalisation point shifts the state and pushes one bit into `nrnb` ("there is NO word": complemented, round 5) and one into `cyb` ("it carries
     //    into the words before it"), keeps the word in `pw` (and every point's word in pwj[] for the rare several-words case);
     //  * the emit logic runs ONCE PER PERIOD of two bytes (a lane emits a word every ~6 bytes): popcount(rnb) >= 2 in some lane is
     //    the wave-uniform rare path that replays the points in order.
-    auto code_byte = [&](const uint4 rec, u32 &rnb, u32 &cyb, u32 &pw, u32 (&pwj)[4]) __attribute__((always_inline)) {
+    auto code_byte = [&](const uint4 rec, u32 &nrnb, u32 &cyb, u32 &pw, u32 (&pwj)[4]) __attribute__((always_inline)) {
         const u32 R[4] = { rec.x, rec.y, rec.z, rec.w };
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             {
-                // rn = (rhi == 0) as the borrow of rhi - 1; everything that hangs on it is carry chain or bit-select (hand-written:
-                // the compiler's form is a compare into an SGPR pair, ten selects on it and the wait states between them)
+                // rn = (rhi == 0): t = min(rhi, 1) is its complement as a number, mr = t - 1 its mask; everything that hangs on it is
+                // arithmetic or bit-select (hand-written: the compiler's form is a compare into an SGPR pair, ten selects on it and the
+                // wait states between them).  No VCC: round 4 took mask and count off a carry chain (v_subrev_co / v_subb / v_addc back
+                // to back), a VALU read of VCC straight behind the VALU write of it -- the compiler keeps two wait states there on
+                // gfx950 (scripts/check_isa_hazards.py).  The point's flag goes into `nrnb` COMPLEMENTED (bit = "no word here").
                 u32 mr, t, lhin;
                 pwj[j] = lhi;
-                asm("v_subrev_co_u32_e32 %1, vcc, 1, %7\n\t"
-                    "v_subb_co_u32_e64 %0, vcc, 0, 0, vcc\n\t"        // mr = -rn, VCC = rn
-                    "v_addc_co_u32_e32 %3, vcc, %3, %3, vcc\n\t"      // rnb = 2 rnb + rn
+                asm("v_min_u32_e32 %1, 1, %7\n\t"
+                    "v_add_u32_e32 %0, -1, %1\n\t"                   // mr = -rn
+                    "v_lshl_add_u32 %3, %3, 1, %1\n\t"               // nrnb = 2 nrnb + !rn
                     "v_and_b32_e32 %1, %0, %6\n\t"
                     "v_lshl_add_u32 %4, %4, 1, %1\n\t"                // cyb = 2 cyb + (rn ? lx : 0)
                     "v_bfi_b32 %5, %0, %10, %5\n\t"                   // pw = rn ? lhi : pw
@@ -360,8 +363,8 @@ __global__ __launch_bounds__(128 * TRC_WPG) void trc_rcb_enc_mc_kernel(
                     "v_bfi_b32 %9, %0, 0, %9\n\t"                     // llo = rn ? 0 : llo
                     "v_bfi_b32 %7, %0, %8, %7\n\t"                    // rhi = rn ? rlo : rhi
                     "v_bfi_b32 %8, %0, 0, %8"                           // rlo = rn ? 0 : rlo
-                    : "=&v"(mr), "=&v"(t), "=&v"(lhin), "+v"(rnb), "+v"(cyb), "+v"(pw), "+v"(lx), "+v"(rhi), "+v"(rlo), "+v"(llo)
-                    : "v"(lhi) : "vcc");
+                    : "=&v"(mr), "=&v"(t), "=&v"(lhin), "+v"(nrnb), "+v"(cyb), "+v"(pw), "+v"(lx), "+v"(rhi), "+v"(rlo), "+v"(llo)
+                    : "v"(lhi));
                 lhi = lhin;
             }
 #pragma unroll
@@ -372,19 +375,24 @@ __global__ __launch_bounds__(128 * TRC_WPG) void trc_rcb_enc_mc_kernel(
                 const u64 c64 = (u64)slo * prob;
                 const u32 clo = (u32)c64, chi = __umul24(shi, prob) + (u32)(c64 >> 32);
                 // low += bit ? 0 : cut (carry into lx: at most one between two renormalisations), range = bit ? cut : range - cut;
-                // one block, the carry chains back to back (the compiler keeps an s_nop between its own v_add_co and v_addc)
-                u32 t0, t1;
-                asm("v_bfi_b32 %0, %7, 0, %8\n\t"
-                    "v_bfi_b32 %1, %7, 0, %9\n\t"
-                    "v_add_co_u32_e32 %2, vcc, %2, %0\n\t"
-                    "v_addc_co_u32_e32 %3, vcc, %3, %1, vcc\n\t"
-                    "v_addc_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
-                    "v_sub_co_u32_e32 %0, vcc, %5, %8\n\t"
-                    "v_subb_co_u32_e32 %1, vcc, %6, %9, vcc\n\t"
-                    "v_bfi_b32 %5, %7, %8, %0\n\t"
-                    "v_bfi_b32 %6, %7, %9, %1"
-                    : "=&v"(t0), "=&v"(t1), "+v"(llo), "+v"(lhi), "+v"(lx), "+v"(rlo), "+v"(rhi)
-                    : "v"(m), "v"(clo), "v"(chi) : "vcc");
+                // one block.  The two carry chains run on two carry registers (VCC for `low +=`, an SGPR pair for `range -`) and are
+                // interleaved with the bit-selects so that two instructions sit between every VALU write of a carry and the VALU read
+                // of it -- the wait states the compiler keeps on gfx950 (its own v_add_co / v_addc carry an s_nop 1), here filled
+                // with the block's own work: same nine instructions as the back-to-back form of round 4.
+                u32 t0, t1, u0, u1;
+                u64 sb;
+                asm("v_bfi_b32 %[t0], %[m], 0, %[clo]\n\t"
+                    "v_add_co_u32_e32 %[llo], vcc, %[llo], %[t0]\n\t"
+                    "v_sub_co_u32_e64 %[u0], %[sb], %[rlo], %[clo]\n\t"
+                    "v_bfi_b32 %[t1], %[m], 0, %[chi]\n\t"
+                    "v_addc_co_u32_e32 %[lhi], vcc, %[lhi], %[t1], vcc\n\t"
+                    "v_subb_co_u32_e64 %[u1], %[sb], %[rhi], %[chi], %[sb]\n\t"
+                    "v_bfi_b32 %[rlo], %[m], %[clo], %[u0]\n\t"
+                    "v_addc_co_u32_e32 %[lx], vcc, 0, %[lx], vcc\n\t"
+                    "v_bfi_b32 %[rhi], %[m], %[chi], %[u1]"
+                    : [t0] "=&v"(t0), [t1] "=&v"(t1), [u0] "=&v"(u0), [u1] "=&v"(u1), [sb] "=&s"(sb),
+                      [llo] "+v"(llo), [lhi] "+v"(lhi), [lx] "+v"(lx), [rlo] "+v"(rlo), [rhi] "+v"(rhi)
+                    : [m] "v"(m), [clo] "v"(clo), [chi] "v"(chi) : "vcc");
             }
         }
     };
@@ -426,18 +434,18 @@ __global__ __launch_bounds__(128 * TRC_WPG) void trc_rcb_enc_mc_kernel(
         so.wpos += r0.x & r1.y & 4u; return;
 #endif
         const bool ends = __ballot(live && len - q0 < 2u) != 0;        // a short last chunk ends inside this period (once per grid)
-        u32 rnb = 0, cyb = 0, pw = 0, pa[4], pb[4] = { 0, 0, 0, 0 };
+        u32 nrnb = 0, cyb = 0, pw = 0, pa[4], pb[4] = { 0, 0, 0, 0 };        // nrnb: one bit per point, SET where the point emits nothing
         if (ends && live && q0 == len) { if ((int)(4u * cw.nwords) < lim) { finish(); out_len = so.wpos; } live = false; }
-        code_byte(r0, rnb, cyb, pw, pa);
+        code_byte(r0, nrnb, cyb, pw, pa);
         if (ends) {                                             // (wave-uniform) the chunk may end between the two bytes: emit what byte 0 left first
-            emit_points(rnb, cyb, pw, pa, pb, 4);
-            rnb = cyb = 0;
+            emit_points(~nrnb & 0xfu, cyb, pw, pa, pb, 4);
+            nrnb = cyb = 0;
             if (live && q0 + 1u == len) { if ((int)(4u * cw.nwords) < lim) { finish(); out_len = so.wpos; } live = false; }
-            code_byte(r1, rnb, cyb, pw, pa);
-            emit_points(rnb, cyb, pw, pa, pb, 4);
+            code_byte(r1, nrnb, cyb, pw, pa);
+            emit_points(~nrnb & 0xfu, cyb, pw, pa, pb, 4);
         } else {
-            code_byte(r1, rnb, cyb, pw, pb);
-            emit_points(rnb, cyb, pw, pa, pb, 8);
+            code_byte(r1, nrnb, cyb, pw, pb);
+            emit_points(~nrnb & 0xffu, cyb, pw, pa, pb, 8);
         }
         ovf = ovf || (live && (int)(4u * cw.nwords) >= lim);           // OVERFLOW, monotone
         live = live && !ovf;
@@ -514,49 +522,56 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_rcb_dec_kernel(
                 // (no predication on `act`: a lane that is not decoding -- raw chunk, dead lane, past the end of a short last chunk -- runs
                 // along on its own registers, its own model column and whatever its clamped stream window holds, statistically like any
                 // other lane; nothing of it is observable.  An `act &&` here is a mask operation between the compare and five selects.)
-                // rn = (rhi == 0) as the borrow of rhi - 1: mask and count from the carry chain, five bit-selects -- no SGPR mask
-                // (v_cmp + v_cndmask needs two wait states between them on gfx950 and the compiler made a branch of some of these)
+                // rn = (rhi == 0): t = min(rhi, 1), mask = t - 1, count -= mask, five bit-selects -- no SGPR mask (v_cmp + v_cndmask needs
+                // two wait states between them on gfx950 and the compiler made a branch of some of these) and, since round 5, no
+                // VCC either: round 4's v_subrev_co / v_subb / v_addc read VCC straight behind the VALU write of it.
                 u32 mr, t;
-                asm("v_subrev_co_u32_e32 %1, vcc, 1, %2\n\t"
-                    "v_subb_co_u32_e64 %0, vcc, 0, 0, vcc\n\t"
-                    "v_addc_co_u32_e32 %7, vcc, 0, %7, vcc\n\t"
+                asm("v_min_u32_e32 %1, 1, %2\n\t"
+                    "v_add_u32_e32 %0, -1, %1\n\t"
+                    "v_sub_u32_e32 %7, %7, %0\n\t"
                     "v_bfi_b32 %2, %0, %3, %2\n\t"
                     "v_bfi_b32 %3, %0, 0, %3\n\t"
                     "v_bfi_b32 %4, %0, %5, %4\n\t"
                     "v_bfi_b32 %5, %0, %6, %5\n\t"
                     "v_bfi_b32 %6, %0, %8, %6"
-                    : "=&v"(mr), "=&v"(t), "+v"(rhi), "+v"(rlo), "+v"(chi), "+v"(clo), "+v"(w0), "+v"(cnt) : "v"(w1) : "vcc");
+                    : "=&v"(mr), "=&v"(t), "+v"(rhi), "+v"(rlo), "+v"(chi), "+v"(clo), "+v"(w0), "+v"(cnt) : "v"(w1));
             }
             // both children (row c0 = 2*ctx) are requested before this bit is known (not below the last level)
             u32 pl = 0, pr = 0;
             if (k < 7) { pl = trc_ldsr16(RCB_A(c0)); pr = trc_ldsr16(RCB_A(c0) + 128u); }
             const u32 slo = __builtin_amdgcn_alignbit(rhi, rlo, TRC_PROB_BITS), shi = rhi >> TRC_PROB_BITS;
             const u64 c64 = (u64)slo * p;
-            const u32 cl = (u32)c64, ch = __umul24(shi, p) + (u32)(c64 >> 32);
+            const u32 cl = (u32)c64, hh = (u32)(c64 >> 32);          // cut = ch:cl, ch = shi * p + hh (inside the block: it fills a wait state)
             // The bit is the borrow of code - cut.  It stays on the vector side: m = 0 - 0 - borrow (all ones for a 1) leaves the
-            // borrow in VCC, the adapted probability p - ((p | m & ~0x7fff) >> 5) - bit takes it from there, the child is
+            // borrow in VCC, the adapted probability p - ((p >> 5) | m & (~0x7fff >> 5)) - bit takes it from there, the child is
             // c0 | (m & 128), the next row 2 * child.  Left to the compiler the borrow became an SGPR mask read by nine selects
             // (v_cndmask), each group behind the wait states a vector-written mask needs on gfx950.
-            // The rest of the step sits in the same block: range - cut, the four bit-selects of the state.  (Between a compiler-made
-            // v_sub_co and its v_subb there is an s_nop -- the compiler keeps two wait states between a vector write of VCC and
-            // any vector read of it; the carry chain does not need them: parity tests on back-to-back pairs.)
-            u32 m, t5, t6, np, an, cn;
-            asm("v_sub_co_u32_e32 %0, vcc, %8, %10\n\t"             // code - cut
-                "v_subb_co_u32_e32 %1, vcc, %9, %11, vcc\n\t"
-                "v_subb_co_u32_e64 %2, vcc, 0, 0, vcc\n\t"          // m = -bit, VCC = bit
-                "v_bfi_b32 %8, %2, %8, %0\n\t"                      // code = bit ? code : code - cut
-                "v_bfi_b32 %9, %2, %9, %1\n\t"
-                "v_and_or_b32 %0, %2, %13, %12\n\t"
-                "v_lshrrev_b32_e32 %0, 5, %0\n\t"
-                "v_subb_co_u32_e32 %3, vcc, %12, %0, vcc\n\t"       // p - ((p | m & ~0x7fff) >> 5) - bit
-                "v_and_or_b32 %4, %2, %14, %15\n\t"                 // child
-                "v_lshl_add_u32 %5, %4, 1, %16\n\t"                 // its children's row
-                "v_sub_co_u32_e32 %0, vcc, %6, %10\n\t"             // range - cut
-                "v_subb_co_u32_e32 %1, vcc, %7, %11, vcc\n\t"
-                "v_bfi_b32 %6, %2, %10, %0\n\t"                     // range = bit ? cut : range - cut
-                "v_bfi_b32 %7, %2, %11, %1"
-                : "=&v"(t5), "=&v"(t6), "=&v"(m), "=&v"(np), "=&v"(an), "=&v"(cn), "+v"(rlo), "+v"(rhi), "+v"(clo), "+v"(chi)
-                : "v"(cl), "v"(ch), "v"(p), "s"(0xffff8000u), "s"(128u), "v"(c0), "v"(negm) : "vcc");
+            // The rest of the step sits in the same block: range - cut, the four bit-selects of the state.
+            // Round 5, the wait states: a VALU read of VCC / an SGPR pair needs two instructions between it and the VALU write
+            // (the compiler keeps an s_nop 1 between its own v_sub_co and v_subb; round 4 ran the chains back to back).  The two
+            // subtractions run on two carry registers (code - cut: VCC, range - cut: an SGPR pair) and are interleaved with each
+            // other, with the high product and with p >> 5, so that every such pair has its two states filled with the step's own
+            // work: the same 15 + 3 instructions per bit as before (scripts/check_isa_hazards.py finds no site in the library).
+            u32 m, t5, t6, r5, r6, ch, tt, np, an, cn;
+            u64 sb;
+            asm("v_sub_co_u32_e32 %[t5], vcc, %[clo], %[cl]\n\t"              // code - cut, low
+                "v_mad_u32_u24 %[ch], %[shi], %[p], %[hh]\n\t"
+                "v_sub_co_u32_e64 %[r5], %[sb], %[rlo], %[cl]\n\t"            // range - cut, low
+                "v_subb_co_u32_e32 %[t6], vcc, %[chi], %[ch], vcc\n\t"
+                "v_lshrrev_b32_e32 %[tt], 5, %[p]\n\t"
+                "v_subb_co_u32_e64 %[r6], %[sb], %[rhi], %[ch], %[sb]\n\t"
+                "v_subb_co_u32_e64 %[m], vcc, 0, 0, vcc\n\t"                  // m = -bit, VCC = bit
+                "v_bfi_b32 %[clo], %[m], %[clo], %[t5]\n\t"                   // code = bit ? code : code - cut
+                "v_bfi_b32 %[chi], %[m], %[chi], %[t6]\n\t"
+                "v_and_or_b32 %[tt], %[m], %[k5], %[tt]\n\t"
+                "v_subb_co_u32_e32 %[np], vcc, %[p], %[tt], vcc\n\t"          // p - ((p | m & ~0x7fff) >> 5) - bit
+                "v_and_or_b32 %[an], %[m], %[k128], %[c0]\n\t"                // child
+                "v_lshl_add_u32 %[cn], %[an], 1, %[negm]\n\t"                 // its children's row
+                "v_bfi_b32 %[rlo], %[m], %[cl], %[r5]\n\t"                    // range = bit ? cut : range - cut
+                "v_bfi_b32 %[rhi], %[m], %[ch], %[r6]"
+                : [t5] "=&v"(t5), [t6] "=&v"(t6), [r5] "=&v"(r5), [r6] "=&v"(r6), [ch] "=&v"(ch), [tt] "=&v"(tt), [m] "=&v"(m), [np] "=&v"(np),
+                  [an] "=&v"(an), [cn] "=&v"(cn), [sb] "=&s"(sb), [rlo] "+v"(rlo), [rhi] "+v"(rhi), [clo] "+v"(clo), [chi] "+v"(chi)
+                : [cl] "v"(cl), [hh] "v"(hh), [shi] "v"(shi), [p] "v"(p), [k5] "s"(0xffff8000u >> 5), [k128] "s"(128u), [c0] "v"(c0), [negm] "v"(negm) : "vcc");
             trc_ldsw16(RCB_A(a), np);                          // rcb_adapt: p - (t5 + bit), 16 bits kept by the store
             a = an; c0 = cn;                                   // child 2*ctx + bit (bit 7 of c0 is clear) and its children's row
             p = rcb_bfi(m, pr, pl);
