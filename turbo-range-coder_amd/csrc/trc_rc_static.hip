@@ -25,22 +25,27 @@ template <int GEO> struct RcGeo;
 template <> struct RcGeo<0> { typedef RcEncV Enc; typedef RcDec Dec; };      // (RcEncV: the state on 32-bit halves with a carry limb, trc_rc.h)
 template <> struct RcGeo<1> { typedef RcEncSm Enc; typedef RcDecSm Dec; };
 
-template <int NS, int GEO>
-__global__ __launch_bounds__(64) void trc_rcs_enc_kernel(
+// WPB waves per workgroup: 1 (rounds 1-4; more than one residency round: small workgroups move in as old ones end) or 12 with
+// TrcPace (round 5: a launch that is ONE round -- the waves of a SIMD then sit in one workgroup and keep each other's pace)
+#define RCS_ENC_FIXED (1024u + 64u)                           // symbol table, TrcPace's progress counters
+template <int NS, int GEO, int WPB>
+__global__ __launch_bounds__(64 * WPB) void trc_rcs_enc_kernel(
     const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks, const u32 *__restrict__ tab_g,
     u8 *__restrict__ scrA, u32 strideA, u8 *__restrict__ scrB, u32 strideB,
     u32 *__restrict__ clen, u32 *__restrict__ gsum)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     u32 *tab = (u32 *)smem;                                    // 256 x {f<<16 | c0}
-    const u32 lane = threadIdx.x;
-    u8 *wbase = smem + 1024;
-    for (u32 i = lane; i < 256; i += 64) tab[i] = tab_g[i];
+    const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    u8 *wbase = smem + RCS_ENC_FIXED + wv * RCS_WAVE_LDS(NS);
+    for (u32 i = tid; i < 256; i += 64 * WPB) tab[i] = tab_g[i];
+    TrcPace pace; pace.init(trc_lds_addr(smem) + 1024u, tid, wv);
     __syncthreads();
 
     WaveChunks wc;
-    wc.c0 = blockIdx.x * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
+    wc.c0 = (blockIdx.x * WPB + wv) * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
     wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
+    if (wc.c0 >= nchunks) return;
     wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
     const bool alive = lane < wc.rows;
     const u32 c = wc.c0 + lane;
@@ -63,6 +68,7 @@ __global__ __launch_bounds__(64) void trc_rcs_enc_kernel(
     const u32 S = chunk / TRC_SEG;
     tin.issue(wc, 0);
     for (u32 s = 0; s < S; s++) {
+        if (WPB > 4) pace.step(s + 1u);
         tin.commit();
         if (s + 1 < S) tin.issue(wc, (s + 1) * TRC_SEG);
         // The piece and dword loops are kept as loops (registers rotate instead of being indexed): fully unrolled, the
@@ -134,6 +140,7 @@ __global__ __launch_bounds__(64) void trc_rcs_enc_kernel(
     if (lane == 0) gsum[wc.c0 >> 6] = gs;
 }
 
+#define RCS_DEC_FIXED (32768u + 1024u + 64u)                 // slot -> symbol LUT, symbol table, TrcPace's progress counters (trc_dev.h)
 template <int NS, int GEO>
 __global__ __launch_bounds__(896) void trc_rcs_dec_kernel(
     const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(896) void trc_rcs_dec_kernel(
     u32 *tab = (u32 *)(smem + 32768);                          // 256 x {f<<16 | c0}
     if (trc_lds_addr(smem) != 0u) __builtin_trap();            // (RCS_LUT: absolute LDS offsets)
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, BLOCK = blockDim.x;
-    u8 *wbase = smem + 32768 + 1024 + wv * RCS_WAVE_LDS(NS);
+    u8 *wbase = smem + RCS_DEC_FIXED + wv * RCS_WAVE_LDS(NS);
     if (BLOCK >= 704u) {                                        // one batch of loads (a copy loop waits for each load before the next: trc_ans_static.hip)
         uint4 t0 = ((const uint4 *)lut_g)[tid], t1 = ((const uint4 *)lut_g)[tid + BLOCK], t2 = make_uint4(0, 0, 0, 0);
         u32 td = 0;
@@ -157,6 +164,7 @@ __global__ __launch_bounds__(896) void trc_rcs_dec_kernel(
         for (u32 i = tid; i < 2048; i += BLOCK) ((uint4 *)lut)[i] = ((const uint4 *)lut_g)[i];
         for (u32 i = tid; i < 256; i += BLOCK) tab[i] = tab_g[i];
     }
+    TrcPace pace; pace.init(32768u + 1024u, tid, wv);          // the waves of a SIMD keep each other's pace (trc_dev.h)
     __syncthreads();
 
     WaveChunks wc;
@@ -223,6 +231,7 @@ __global__ __launch_bounds__(896) void trc_rcs_dec_kernel(
     const u32 pairs = len & ~1u;
     u8 *dst = out + (u64)c * chunk;
     for (u32 s = 0; s < S; s++) {
+        pace.step(s + 1u);
         // rolled like the encoder's loops (the refill protocol wants the period parity as a literal: pieces go in pairs)
         uint4 pc0 = make_uint4(0, 0, 0, 0), pc1 = pc0, pc2 = pc0, pc3 = pc0;
 #pragma nounroll
@@ -262,21 +271,24 @@ __global__ __launch_bounds__(896) void trc_rcs_dec_kernel(
 // step is the one-stream coder's.  The streams meet only in the overflow tests (word counts exchanged by DPP once per
 // period) and at the end (lengths); the decoder merges the two lanes' bytes by DPP before the output transpose.
 // A workgroup is two waves = one group of 64 chunks, so that gsum keeps its meaning.
-__global__ __launch_bounds__(128) void trc_rcs2p_enc_kernel(
+// GPW groups of 64 chunks (= pairs of waves) per workgroup: 1, or 6 with TrcPace when the launch is one residency round (round 5)
+template <int GPW>
+__global__ __launch_bounds__(128 * GPW) void trc_rcs2p_enc_kernel(
     const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks, const u32 *__restrict__ tab_g,
     u8 *__restrict__ scrA, u32 strideA, u8 *__restrict__ scrB, u32 strideB,
     u32 *__restrict__ clen, u32 *__restrict__ gsum)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     u32 *tab = (u32 *)smem;                                    // 256 x {f<<16 | c0}
-    u32 *wsum = (u32 *)(smem + 1024);                          // the two waves' byte counts
+    u32 *wsum = (u32 *)(smem + 1024);                          // the waves' byte counts (a group = two waves)
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    u8 *wbase = smem + 1024 + 64 + wv * RCS_WAVE_LDS(1);
-    for (u32 i = tid; i < 256; i += 128) tab[i] = tab_g[i];
+    u8 *wbase = smem + 1024 + 64 + 64 + wv * RCS_WAVE_LDS(1);
+    for (u32 i = tid; i < 256; i += 128 * GPW) tab[i] = tab_g[i];
+    TrcPace pace; pace.init(trc_lds_addr(smem) + 1024u + 64u, tid, wv);
     __syncthreads();
 
     WaveChunks wc;
-    wc.c0 = blockIdx.x * 64u + wv * 32u; wc.chunk = chunk; wc.nchunks = nchunks;
+    wc.c0 = (blockIdx.x * GPW) * 64u + wv * 32u; wc.chunk = chunk; wc.nchunks = nchunks;
     wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
     wc.rows = wc.c0 >= nchunks ? 0u : nchunks - wc.c0 < 32u ? nchunks - wc.c0 : 32u;
     u32 gs = 0;
@@ -305,6 +317,7 @@ __global__ __launch_bounds__(128) void trc_rcs2p_enc_kernel(
         const u32 S = chunk / TRC_SEG, sh0 = 8u * b, sh1 = 16u + 8u * b;
         tin.issue(wc, 0, true);
         for (u32 s = 0; s < S; s++) {
+            if (GPW > 2) pace.step(s + 1u);
             tin.commit();
             if (s + 1 < S) tin.issue(wc, (s + 1) * TRC_SEG, true);
             uint4 pc0 = tin.read(0), pc1 = tin.read(1), pc2 = tin.read(2), pc3 = tin.read(3);
@@ -352,7 +365,7 @@ __global__ __launch_bounds__(128) void trc_rcs2p_enc_kernel(
     }
     if (lane == 0) wsum[wv] = gs;
     __syncthreads();
-    if (tid == 0) gsum[blockIdx.x] = wsum[0] + wsum[1];
+    if (lane == 0 && !(wv & 1u) && (blockIdx.x * GPW + (wv >> 1)) * 64u < nchunks) gsum[blockIdx.x * GPW + (wv >> 1)] = wsum[wv] + wsum[wv + 1];
 }
 
 __global__ __launch_bounds__(896) void trc_rcs2p_dec_kernel(
@@ -364,7 +377,7 @@ __global__ __launch_bounds__(896) void trc_rcs2p_dec_kernel(
     u32 *tab = (u32 *)(smem + 32768);                          // 256 x {f<<16 | c0}
     if (trc_lds_addr(smem) != 0u) __builtin_trap();            // (RCS_LUT: absolute LDS offsets)
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, BLOCK = blockDim.x;
-    u8 *wbase = smem + 32768 + 1024 + wv * RCS_WAVE_LDS(1);
+    u8 *wbase = smem + RCS_DEC_FIXED + wv * RCS_WAVE_LDS(1);
     if (BLOCK >= 704u) {
         uint4 t0 = ((const uint4 *)lut_g)[tid], t1 = ((const uint4 *)lut_g)[tid + BLOCK], t2 = make_uint4(0, 0, 0, 0);
         u32 td = 0;
@@ -377,6 +390,7 @@ __global__ __launch_bounds__(896) void trc_rcs2p_dec_kernel(
         for (u32 i = tid; i < 2048; i += BLOCK) ((uint4 *)lut)[i] = ((const uint4 *)lut_g)[i];
         for (u32 i = tid; i < 256; i += BLOCK) tab[i] = tab_g[i];
     }
+    TrcPace pace; pace.init(32768u + 1024u, tid, wv);
     __syncthreads();
 
     WaveChunks wc;
@@ -412,6 +426,7 @@ __global__ __launch_bounds__(896) void trc_rcs2p_dec_kernel(
     const u32 pairs = len & ~1u;
     u8 *dst = out + (u64)c * chunk;
     for (u32 s = 0; s < S; s++) {
+        pace.step(s + 1u);
         uint4 pc0 = make_uint4(0, 0, 0, 0), pc1 = pc0, pc2 = pc0, pc3 = pc0;
 #pragma nounroll
         for (u32 kk = 0; kk < 2; kk++) {
@@ -474,18 +489,39 @@ void trc_launch_rcs_enc(int nstreams, const uint8_t *d_in, size_t n, uint32_t ch
                         uint32_t *d_clen, hipStream_t s)
 {
     const u32 *tab = (const u32 *)(w.tables + TRC_TAB_DEC);
-    if (nstreams == 1)
-        TRC_LAUNCH_TIMED((trc_rcs_enc_kernel<1, 0>), dim3(w.ngroups), dim3(64), 1024 + RCS_WAVE_LDS(1), s,
-                           d_in, (u64)n, chunk, w.nchunks, tab, w.scratch, w.stride, w.scratch, w.stride, d_clen, w.gsum);
+    // one residency round (at most twelve waves per CU): workgroups of twelve waves that keep each other's pace (TrcPace)
+    static const int env_wpb = getenv("TRC_RCS_ENC_WPB") ? atoi(getenv("TRC_RCS_ENC_WPB")) : 0;      // tuning aid: 1 / 12 force the form
+    const bool big = env_wpb ? env_wpb == 12 : (w.ngroups >= 2048u && w.ngroups <= 12u * 256u);
+#define RCS_ENC_LAUNCH(NS, GEO, SB, STB)                                                                                             \
+    do {                                                                                                                             \
+        if (big) {                                                                                                                   \
+            TRC_RAISE_LDS_ONCE((trc_rcs_enc_kernel<NS, GEO, 12>), RCS_ENC_FIXED + 12 * RCS_WAVE_LDS(NS));                            \
+            TRC_LAUNCH_TIMED((trc_rcs_enc_kernel<NS, GEO, 12>), dim3((w.ngroups + 11u) / 12u), dim3(64 * 12), RCS_ENC_FIXED + 12 * RCS_WAVE_LDS(NS), s, \
+                               d_in, (u64)n, chunk, w.nchunks, tab, w.scratch, w.stride, SB, STB, d_clen, w.gsum);                   \
+        } else                                                                                                                       \
+            TRC_LAUNCH_TIMED((trc_rcs_enc_kernel<NS, GEO, 1>), dim3(w.ngroups), dim3(64), RCS_ENC_FIXED + RCS_WAVE_LDS(NS), s,       \
+                               d_in, (u64)n, chunk, w.nchunks, tab, w.scratch, w.stride, SB, STB, d_clen, w.gsum);                   \
+    } while (0)
+    if (nstreams == 1) RCS_ENC_LAUNCH(1, 0, w.scratch, w.stride);
     else if (nstreams == 2 && rcs2_pair())
-        TRC_LAUNCH_TIMED(trc_rcs2p_enc_kernel, dim3(w.ngroups), dim3(128), 1024 + 64 + 2 * RCS_WAVE_LDS(1), s,
+    {
+        // (a group of 64 chunks is two waves here: 2 x ngroups waves in the launch)
+        const bool big2 = env_wpb ? env_wpb == 12 : (w.ngroups >= 1024u && w.ngroups <= 6u * 256u);
+        if (big2) {
+            TRC_RAISE_LDS_ONCE(trc_rcs2p_enc_kernel<6>, 1024 + 128 + 12 * RCS_WAVE_LDS(1));
+            TRC_LAUNCH_TIMED(trc_rcs2p_enc_kernel<6>, dim3((w.ngroups + 5u) / 6u), dim3(128 * 6), 1024 + 128 + 12 * RCS_WAVE_LDS(1), s,
+                               d_in, (u64)n, chunk, w.nchunks, tab, w.scratch, w.stride, w.scratch2, w.stride2, d_clen, w.gsum);
+        } else
+            TRC_LAUNCH_TIMED(trc_rcs2p_enc_kernel<1>, dim3(w.ngroups), dim3(128), 1024 + 128 + 2 * RCS_WAVE_LDS(1), s,
+                               d_in, (u64)n, chunk, w.nchunks, tab, w.scratch, w.stride, w.scratch2, w.stride2, d_clen, w.gsum);
+    }
+    else if (nstreams == 2) {
+        const bool big2 = false;                               // (two rings per wave: six waves per workgroup would fit; not measured)
+        (void)big2;
+        TRC_LAUNCH_TIMED((trc_rcs_enc_kernel<2, 0, 1>), dim3(w.ngroups), dim3(64), RCS_ENC_FIXED + RCS_WAVE_LDS(2), s,
                            d_in, (u64)n, chunk, w.nchunks, tab, w.scratch, w.stride, w.scratch2, w.stride2, d_clen, w.gsum);
-    else if (nstreams == 2)
-        TRC_LAUNCH_TIMED((trc_rcs_enc_kernel<2, 0>), dim3(w.ngroups), dim3(64), 1024 + RCS_WAVE_LDS(2), s,
-                           d_in, (u64)n, chunk, w.nchunks, tab, w.scratch, w.stride, w.scratch2, w.stride2, d_clen, w.gsum);
-    else                                                       // nstreams == -1: one stream, 32-bit range / 16-bit words (RCSM)
-        TRC_LAUNCH_TIMED((trc_rcs_enc_kernel<1, 1>), dim3(w.ngroups), dim3(64), 1024 + RCS_WAVE_LDS(1), s,
-                           d_in, (u64)n, chunk, w.nchunks, tab, w.scratch, w.stride, w.scratch, w.stride, d_clen, w.gsum);
+    } else RCS_ENC_LAUNCH(1, 1, w.scratch, w.stride);          // nstreams == -1: one stream, 32-bit range / 16-bit words (RCSM)
+#undef RCS_ENC_LAUNCH
 }
 
 template <int NS, int GEO>
@@ -493,10 +529,10 @@ static void launch_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t 
                        const TrcWork &w, uint8_t *d_out, hipStream_t s)
 {
     const u32 maxw = NS == 1 ? 14u : 7u;                       // 34 KiB tables + waves x (NS rings) must fit 160 KiB
-    TRC_RAISE_LDS_ONCE((trc_rcs_dec_kernel<NS, GEO>), 32768 + 1024 + maxw * RCS_WAVE_LDS(NS));
+    TRC_RAISE_LDS_ONCE((trc_rcs_dec_kernel<NS, GEO>), RCS_DEC_FIXED + maxw * RCS_WAVE_LDS(NS));
     u32 wpb = (w.ngroups + 255u) / 256u;                       // just enough waves per workgroup to give every CU one
     wpb = wpb < 1u ? 1u : wpb > maxw ? maxw : wpb;
-    const size_t sm = 32768 + 1024 + wpb * RCS_WAVE_LDS(NS);
+    const size_t sm = RCS_DEC_FIXED + wpb * RCS_WAVE_LDS(NS);
     TRC_LAUNCH_TIMED((trc_rcs_dec_kernel<NS, GEO>), dim3((w.ngroups + wpb - 1) / wpb), dim3(64 * wpb), sm, s,
                        d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, w.tables + TRC_TAB_LUT,
                        (const u32 *)(w.tables + TRC_TAB_DEC), d_out);
@@ -507,10 +543,10 @@ void trc_launch_rcs_dec(int nstreams, const uint8_t *d_payload, const uint32_t *
     if (nstreams == 1)      launch_dec<1, 0>(d_payload, d_clen, n, chunk, w, d_out, s);
     else if (nstreams == 2 && rcs2_pair()) {
         const u32 nwaves = (w.nchunks + 31u) / 32u;
-        TRC_RAISE_LDS_ONCE(trc_rcs2p_dec_kernel, 32768 + 1024 + 14u * RCS_WAVE_LDS(1));
+        TRC_RAISE_LDS_ONCE(trc_rcs2p_dec_kernel, RCS_DEC_FIXED + 14u * RCS_WAVE_LDS(1));
         u32 wpb = (nwaves + 255u) / 256u;
         wpb = wpb < 1u ? 1u : wpb > 14u ? 14u : wpb;
-        TRC_LAUNCH_TIMED(trc_rcs2p_dec_kernel, dim3((nwaves + wpb - 1) / wpb), dim3(64 * wpb), 32768 + 1024 + wpb * RCS_WAVE_LDS(1), s,
+        TRC_LAUNCH_TIMED(trc_rcs2p_dec_kernel, dim3((nwaves + wpb - 1) / wpb), dim3(64 * wpb), RCS_DEC_FIXED + wpb * RCS_WAVE_LDS(1), s,
                            d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, w.tables + TRC_TAB_LUT,
                            (const u32 *)(w.tables + TRC_TAB_DEC), d_out);
     }
