@@ -349,8 +349,11 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_ansa_code_planar_kernel(
 #define ANSQ_ROW        144u                                   // tile row: one block (64 B hi + 64 B lo records) + 16 B (bank spread)
 #define ANSQ_TILE       (16u * ANSQ_ROW)
 #define ANSQ_WAVE_LDS   (ANSQ_TILE + 16u * TRC_SRING_STRIDE)   // + 16 rings
-#define ANSQ_LDS        (4u * ANSQ_WAVE_LDS + 16u)
-__global__ __launch_bounds__(256) void trc_ansa_codeq_kernel(
+#define ANSQ_LDS(GPW)   (4u * (GPW) * ANSQ_WAVE_LDS + 64u + 64u)               // + the waves' byte counts + TrcPace's progress counters
+// GPW groups of 64 chunks (four waves each) per workgroup: 1, or 4 with TrcPace (round 5) when the launch is one residency round
+// of sixteen waves per CU -- the waves of a SIMD then sit in one workgroup and keep each other's pace (trc_dev.h)
+template <int GPW>
+__global__ __launch_bounds__(256 * GPW) void trc_ansa_codeq_kernel(
     const u8 *__restrict__ recs, u64 n, u32 chunk, u32 nchunks,
     u8 *__restrict__ scratch, u32 stride, u32 *__restrict__ clen, u32 *__restrict__ gsum)
 {
@@ -359,8 +362,10 @@ __global__ __launch_bounds__(256) void trc_ansa_codeq_kernel(
     const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const u32 lane = trc_lane(), s = lane & 3u, ci = lane >> 2;
     u8 *const smem = smem_wg_ + wv * ANSQ_WAVE_LDS;
-    u32 *const wsum = (u32 *)(smem_wg_ + 4u * ANSQ_WAVE_LDS);
-    const u32 cw0 = blockIdx.x * 64u + wv * 16u;               // this wave's first chunk
+    u32 *const wsum = (u32 *)(smem_wg_ + 4u * GPW * ANSQ_WAVE_LDS);
+    TrcPace pace; pace.init(trc_lds_addr(smem_wg_) + 4u * GPW * ANSQ_WAVE_LDS + 64u, threadIdx.x, wv);
+    if (GPW > 1) __syncthreads();
+    const u32 cw0 = blockIdx.x * (64u * GPW) + wv * 16u;       // this wave's first chunk
     const u32 c = cw0 + ci;
     const bool alive = c < nchunks;
     const u32 lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
@@ -386,6 +391,7 @@ __global__ __launch_bounds__(256) void trc_ansa_codeq_kernel(
     uint4 nh = make_uint4(0, 0, 0, 0), nl = nh;
     if (alive && nrec && T - 1u <= top) { nh = trc_ld16_nt(rbase + (T - 1u) * 128u + 16u * s); nl = trc_ld16_nt(rbase + (T - 1u) * 128u + 64u + 16u * s); }
     for (u32 t = T - 1u;; t--) {
+        if (GPW > 1 && !(t & 3u)) pace.step(T - t);
         trc_ldsw128(tw, nh); trc_ldsw128(tw + 64u, nl);
         if (t && alive && nrec && t - 1u <= top) { nh = trc_ld16_nt(rbase + (t - 1u) * 128u + 16u * s); nl = trc_ld16_nt(rbase + (t - 1u) * 128u + 64u + 16u * s); }
         const bool act = alive && nrec != 0u && t <= top;
@@ -436,7 +442,7 @@ __global__ __launch_bounds__(256) void trc_ansa_codeq_kernel(
     const u32 ws = trc_wave_sum(s == 0u ? out_len : 0u);
     if (lane == 0) wsum[wv] = ws;
     __syncthreads();
-    if (threadIdx.x == 0 && blockIdx.x * 64u < nchunks) gsum[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (lane == 0 && !(wv & 3u) && (blockIdx.x * GPW + (wv >> 2)) * 64u < nchunks) gsum[blockIdx.x * GPW + (wv >> 2)] = wsum[wv] + wsum[wv + 1] + wsum[wv + 2] + wsum[wv + 3];
 }
 
 // ------------------------------------------------------------------------------------- decode ---
@@ -731,8 +737,14 @@ static void launch_ansa_dec(const uint8_t *d_payload, const uint32_t *d_clen, si
 void trc_launch_ansa_code_planar(size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
 {
     static const int codeq = getenv("TRC_ANSA_CODEQ") ? atoi(getenv("TRC_ANSA_CODEQ")) : 1;     // 0: one lane per chunk (rounds 1-3)
-    if (codeq)
-        TRC_LAUNCH_TIMED(trc_ansa_codeq_kernel, dim3(w.ngroups), dim3(256), ANSQ_LDS, s,
+    static const int gpw_env = getenv("TRC_CODEQ_GPW") ? atoi(getenv("TRC_CODEQ_GPW")) : 0;     // tuning aid: 1 / 4 force the workgroup shape
+    const bool big = gpw_env ? gpw_env == 4 : (w.ngroups >= 512u && w.ngroups <= 4u * 256u);
+    if (codeq && big) {
+        TRC_RAISE_LDS_ONCE(trc_ansa_codeq_kernel<4>, ANSQ_LDS(4));
+        TRC_LAUNCH_TIMED(trc_ansa_codeq_kernel<4>, dim3((w.ngroups + 3u) / 4u), dim3(1024), ANSQ_LDS(4), s,
+                           (const u8 *)w.scratch2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
+    } else if (codeq)
+        TRC_LAUNCH_TIMED(trc_ansa_codeq_kernel<1>, dim3(w.ngroups), dim3(256), ANSQ_LDS(1), s,
                            (const u8 *)w.scratch2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
     else {
         TRC_RAISE_LDS_ONCE(trc_ansa_code_planar_kernel, TRC_WPG * ANSA_CODE_PLANAR_LDS);

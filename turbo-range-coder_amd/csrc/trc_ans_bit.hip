@@ -113,8 +113,10 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_ansb_model_kernel(
 // different every bit: f32 estimate + exact correction (st < 2^31).  Raw rule: words + 16 >= len (the reference has no test
 // before the end of a block; the words only grow, so a chunk that is there already stops coding).
 #define ANSBQ_WAVE_LDS  (16u * TRC_SRING_STRIDE + 256u)        // 16 rings + 16 x 4 dummy slots
-#define ANSBQ_LDS       (4u * ANSBQ_WAVE_LDS + 16u)
-__global__ __launch_bounds__(256) void trc_ansb_codeq_kernel(
+#define ANSBQ_LDS(GPW)  (4u * (GPW) * ANSBQ_WAVE_LDS + 64u + 64u)              // + the waves' byte counts + TrcPace's progress counters
+// GPW groups of 64 chunks per workgroup: 1, or 4 with TrcPace when the launch is one residency round (trc_ansa_codeq_kernel)
+template <int GPW>
+__global__ __launch_bounds__(256 * GPW) void trc_ansb_codeq_kernel(
     const u8 *__restrict__ recs, u64 n, u32 chunk, u32 nchunks,
     u8 *__restrict__ scratch, u32 stride, u32 *__restrict__ clen, u32 *__restrict__ gsum)
 {
@@ -122,8 +124,10 @@ __global__ __launch_bounds__(256) void trc_ansb_codeq_kernel(
     const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const u32 lane = trc_lane(), s = lane & 3u, ci = lane >> 2;
     u8 *const smem = smem_wg_ + wv * ANSBQ_WAVE_LDS;
-    u32 *const wsum = (u32 *)(smem_wg_ + 4u * ANSBQ_WAVE_LDS);
-    const u32 cw0 = blockIdx.x * 64u + wv * 16u;               // this wave's first chunk
+    u32 *const wsum = (u32 *)(smem_wg_ + 4u * GPW * ANSBQ_WAVE_LDS);
+    TrcPace pace; pace.init(trc_lds_addr(smem_wg_) + 4u * GPW * ANSBQ_WAVE_LDS + 64u, threadIdx.x, wv);
+    if (GPW > 1) __syncthreads();
+    const u32 cw0 = blockIdx.x * (64u * GPW) + wv * 16u;       // this wave's first chunk
     const u32 c = cw0 + ci;
     const bool alive = c < nchunks;
     const u32 lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
@@ -145,6 +149,7 @@ __global__ __launch_bounds__(256) void trc_ansb_codeq_kernel(
     uint4 nx = make_uint4(0, 0, 0, 0);
     if (alive && len && T - 1u <= top) nx = trc_ld16_nt(rbase + (size_t)(T - 1u) * 64u);
     for (u32 t = T - 1u;; t--) {
+        if (GPW > 1 && !(t & 15u)) pace.step(T - t);           // (every 64 input bytes)
         const uint4 q = nx;
         if (t && alive && len && t - 1u <= top) nx = trc_ld16_nt(rbase + (size_t)(t - 1u) * 64u);
         const bool act = alive && len != 0u && t <= top;
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(256) void trc_ansb_codeq_kernel(
     const u32 ws = trc_wave_sum(s == 0u ? out_len : 0u);
     if (lane == 0) wsum[wv] = ws;
     __syncthreads();
-    if (threadIdx.x == 0 && blockIdx.x * 64u < nchunks) gsum[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (lane == 0 && !(wv & 3u) && (blockIdx.x * GPW + (wv >> 2)) * 64u < nchunks) gsum[blockIdx.x * GPW + (wv >> 2)] = wsum[wv] + wsum[wv + 1] + wsum[wv + 2] + wsum[wv + 3];
 }
 
 // ------------------------------------------------------------------------------------- decode ---
@@ -288,8 +293,14 @@ void trc_launch_ansb_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const Tr
 {
     TRC_RAISE_LDS_ONCE(trc_ansb_model_kernel, TRC_WPG * ANSB_MODEL_BYTES);
     TRC_LAUNCH_TIMED(trc_ansb_model_kernel, TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (ANSB_MODEL_BYTES), s, d_in, (u64)n, chunk, w.nchunks, w.scratch2);
-    TRC_LAUNCH_TIMED(trc_ansb_codeq_kernel, dim3(w.ngroups), dim3(256), ANSBQ_LDS, s,
-                       (const u8 *)w.scratch2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
+    static const int gpw_env = getenv("TRC_CODEQ_GPW") ? atoi(getenv("TRC_CODEQ_GPW")) : 0;     // tuning aid: 1 / 4 force the workgroup shape
+    if (gpw_env ? gpw_env == 4 : (w.ngroups >= 512u && w.ngroups <= 4u * 256u)) {
+        TRC_RAISE_LDS_ONCE(trc_ansb_codeq_kernel<4>, ANSBQ_LDS(4));
+        TRC_LAUNCH_TIMED(trc_ansb_codeq_kernel<4>, dim3((w.ngroups + 3u) / 4u), dim3(1024), ANSBQ_LDS(4), s,
+                           (const u8 *)w.scratch2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
+    } else
+        TRC_LAUNCH_TIMED(trc_ansb_codeq_kernel<1>, dim3(w.ngroups), dim3(256), ANSBQ_LDS(1), s,
+                           (const u8 *)w.scratch2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
 }
 void trc_launch_ansb_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                          const TrcWork &w, uint8_t *d_out, hipStream_t s)
