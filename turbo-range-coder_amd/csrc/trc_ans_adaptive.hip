@@ -132,6 +132,11 @@ __global__ __launch_bounds__(128 * TRC_WPG) void trc_ansa_model2_kernel(
     const u32 wv_ = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const bool lo_wave = wv_ >= TRC_WPG;
     const u32 grp_ = blockIdx.x * TRC_WPG + (wv_ & (TRC_WPG - 1u));
+    // round 5: the pair keeps one pace (TrcPace, trc_dev.h) -- the hi wave is the older of the two and has less to do per byte; left
+    // alone it ends early and the lo wave finishes the chunk at a lone wave's issue rate.  Walking together they also ask for the
+    // same input lines at the same time (the second request finds the line in the L2).
+    TrcPace pace; pace.init(trc_lds_addr(smem_wg_) + TRC_WPG * ANSA_MODEL_LDS(false), threadIdx.x, wv_);
+    __syncthreads();
     if (grp_ >= (nchunks + 63u) / 64u) return;
     u8 *const smem = smem_wg_ + (wv_ & (TRC_WPG - 1u)) * ANSA_MODEL_LDS(false);
     const u32 lane = trc_lane();
@@ -153,6 +158,9 @@ __global__ __launch_bounds__(128 * TRC_WPG) void trc_ansa_model2_kernel(
     const u32 S = chunk / TRC_SEG;
     qin.issue(wc, 0);
     for (u32 s = 0; s < S; s++) {
+#ifndef TRC_ANSA_M2_NOPACE
+        pace.step(s + 1u);
+#endif
         qin.commit();
         if (s + 1 < S) qin.issue(wc, (s + 1) * TRC_SEG);
         uint4 pc0 = qin.read(0), pc1 = qin.read(1), pc2 = qin.read(2), pc3 = qin.read(3);
@@ -702,9 +710,9 @@ template <bool NIB>
 static void launch_ansa_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
 {
     if (!NIB && ansa_mc_enabled()) {
-        TRC_RAISE_LDS_ONCE(trc_ansa_model2_kernel, TRC_WPG * ANSA_MODEL_LDS(false));
+        TRC_RAISE_LDS_ONCE(trc_ansa_model2_kernel, TRC_WPG * ANSA_MODEL_LDS(false) + 64u);
         TRC_RAISE_LDS_ONCE(trc_ansa_code_planar_kernel, TRC_WPG * ANSA_CODE_PLANAR_LDS);
-        TRC_LAUNCH_TIMED(trc_ansa_model2_kernel, TRC_QUAD_GRID(w.ngroups), dim3(128 * TRC_WPG), TRC_WPG * ANSA_MODEL_LDS(false), s, d_in, (u64)n, chunk, w.nchunks, w.scratch2);
+        TRC_LAUNCH_TIMED(trc_ansa_model2_kernel, TRC_QUAD_GRID(w.ngroups), dim3(128 * TRC_WPG), TRC_WPG * ANSA_MODEL_LDS(false) + 64u, s, d_in, (u64)n, chunk, w.nchunks, w.scratch2);
         trc_launch_ansa_code_planar(n, chunk, w, d_clen, s);
         return;
     }
