@@ -42,6 +42,7 @@ Extra objects on the JSON line:
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -220,6 +221,37 @@ def beyond_cache_leg(torch, trc, T, codec, chunk, dev, steps=5, warmup=2, n=1000
             "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4)}
 
 
+# BASELINE.json's other single-GPU configurations, so that the driver's BENCH record carries a driver-timed number for each of them
+# (VERDICT r4 #7): config 3 = adaptive-CDF byte coders (rccdf = -e46 literal, anscdf = -e56), config 4 = rcs (-e1), and rccdfs2 =
+# what configs 1 / 2 literally name (-e45).  Each is THIS script run once more in its own process on the coder's own workload and the
+# library's chunk, short (10 timed steps after a 100 ms clock preamble), no CPU leg; the sub-object keeps the fields a reader needs.
+OTHER_CONFIGS = ("rccdfs2", "rccdf", "anscdf", "rcs")
+
+
+def other_configs():
+    out = {}
+    for name in OTHER_CONFIGS:
+        cmd = [sys.executable, os.path.abspath(__file__), "--codec", name, "--steps", "10", "--warmup", "2", "--clock-warmup-ms", "100",
+               "--no-cpu", "--no-beyond", "--no-cold", "--no-configs"]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=180)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+            j = json.loads(line)
+            rf = j["roofline"]
+            out[name] = {"metric": j["metric"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"],
+                         "workload": j["config"]["workload"], "chunk": j["config"]["chunk"],
+                         "enc_kernel_ms": rf["enc_kernel_ms"], "dec_kernel_ms": rf["dec_kernel_ms"],
+                         "roofline": {"kernel": rf["kernel"], "achieved": rf["achieved"], "peak": rf["peak"], "unit": rf["unit"], "frac": rf["frac"],
+                                      "traffic": rf["traffic"], "traffic_source": rf["traffic_source"]},
+                         "ratio_container": j["config"]["ratio_container"], "ratio_reference_whole_buffer": j["config"]["ratio_reference_whole_buffer"],
+                         "payload_matches_reference_sha256": j.get("payload_matches_reference_sha256"),
+                         "wall_s": round(time.perf_counter() - t0, 1)}
+        except Exception as e:                                 # a failed leg must not take the headline line with it
+            out[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    return out
+
+
 def launch_command(ngpus, argv, env=None):
     """`python bench.py --gpus N` started by hand (no WORLD_SIZE in the environment) starts its own N ranks: the command and
     the environment additions of that launch -- one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1
@@ -302,6 +334,8 @@ def main():
                          "+9 %% at chunk 512, +31 %% at chunk 1024, profiles/r02_notes.md -- with longer per-kernel times)")
     ap.add_argument("--no-beyond", action="store_true", help="default workload, N = 1: skip the beyond-cache leg (the same step on 1 GB generated on the device)")
     ap.add_argument("--dry-launch", action="store_true", help="with --gpus N > 1 and no WORLD_SIZE: print the launch (command, environment) as JSON and exit")
+    ap.add_argument("--no-configs", action="store_true", help="default line, N = 1: skip the `configs` sub-objects (BASELINE configs 3 / 4 and the -e45 literal, "
+                    "each a short run of this script in its own process after the headline leg)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:       # started by hand: start the N ranks ourselves
         sys.exit(self_launch(args))
@@ -607,6 +641,8 @@ def main():
             res["beyond_cache"] = beyond_cache_leg(torch, trc, T, codec, chunk, dev)
             res["roofline"]["frac_beyond_l3"] = res["beyond_cache"]["frac"]
             res["roofline"]["note_l3"] = "frac is measured on the 100 MB workload, which (with its 64.5 MB payload) fits the 256 MiB Infinity Cache; frac_beyond_l3 is the same kernel on 1 GB"
+        if world == 1 and default_metric and not args.no_configs and inflight == 1:
+            res["configs"] = other_configs()
         if world == 1 and not args.no_cpu:
             if d is None:                                      # device-only workload: time the CPU on the first bytes of the same stream
                 d = T.table_bytes_range(0, min(n, 100 * 1000 * 1000), T.zipf_weights(1.1, 256), 1000 + rank)
