@@ -59,6 +59,11 @@ def main():
                 e["whole_buffer_bytes"] = whole_buffer(cfg)
                 print(e["name"], "whole buffer", e["whole_buffer_bytes"])
             res.append(e); continue
+        if cfg["chunk"] is None:                     # whole-buffer size only (1 GB inputs)
+            ent = dict(name=cfg["name"], codec=T.CODEC_NAMES[cfg["codec"]], kind=cfg["kind"], seed=cfg["seed"], n=cfg["n"], chunk=None,
+                       whole_buffer_bytes=whole_buffer(cfg))
+            print(ent["name"], "whole buffer", ent["whole_buffer_bytes"])
+            res.append(ent); continue
         key = (cfg["kind"], cfg["n"], cfg["seed"])
         d, cdf, cdfnum = load(key)
         n, chunk, codec = cfg["n"], cfg["chunk"], cfg["codec"]

@@ -73,17 +73,19 @@ def test_config_calls_work_without_gpu(lib):
     lib.trc_round_chunk.restype = ctypes.c_uint32
     lib.trc_round_chunk.argtypes = [ctypes.c_int, ctypes.c_size_t]
     MB = 10**6
-    assert [lib.trc_round_chunk(1, n) for n in (1, 70 * MB, 100 * MB, 120 * MB, 333 * MB, 10**9)] == [512, 512, 512, 640, 1728, 2560]       # static rANS: 196 608 lanes
+    assert [lib.trc_round_chunk(1, n) for n in (1, 70 * MB, 100 * MB, 120 * MB, 333 * MB, 10**9)] == [512, 512, 512, 640, 1728, 5120]       # static rANS: 196 608 lanes
     assert [lib.trc_round_chunk(3, n) for n in (100 * MB,)] == [1024]                                                                       # -e45: two lanes per chunk
-    assert [lib.trc_round_chunk(4, n) for n in (1, 70 * MB, 100 * MB, 120 * MB, 150 * MB, 333 * MB, 10**9)] == [512, 1088, 1536, 1856, 2304, 2560, 3840]   # 65 536 lanes
+    assert [lib.trc_round_chunk(4, n) for n in (1, 70 * MB, 100 * MB, 120 * MB, 150 * MB, 333 * MB, 10**9)] == [512, 1088, 1536, 1856, 2304, 5120, 15296]   # 65 536 lanes (round 5: one round up to 16 KiB, not four of 3840)
+    assert [lib.trc_round_chunk(13, n) for n in (100 * MB, 10**9)] == [1536, 7680]                                                           # bitwise rANS: within one reference block
     for codec in (1, 4, 5, 6, 7):
         for n in (70 * MB, 100 * MB, 120 * MB, 150 * MB, 333 * MB, 10**9, 8 * 10**9):
             c = lib.trc_round_chunk(codec, n)
             rc = {1: 196608, 4: 65536, 5: 65536, 6: 65536, 7: 65536}[codec]
             rounds = -(-(-(-n // c)) // rc)
-            assert c % 64 == 0 and 512 <= c <= 4096
+            assert c % 64 == 0 and 512 <= c <= 16384
             assert c == 512 or -(-n // c) > 0.93 * rounds * rc, (codec, n, c)      # the last round is (nearly) full: 64-byte steps of the chunk
-            assert c == 4096 or c == 512 or -(-n // (c - 64)) > rounds * rc       # ... and no smaller chunk is: c is the largest that fits
+            assert c == 512 or -(-n // (c - 64)) > rounds * rc                    # ... and no smaller chunk is: c is the largest that fits
+            assert rounds == 1 or -(-n // rc) > 16384                             # more than one round only when one round would need a chunk above the cap
     if "TRC_CHUNK" not in os.environ:
         assert lib.trc_get_chunk() == 0                                   # automatic by default
     assert lib.trc_set_chunk(2048) == 0 and lib.trc_get_chunk() == 2048

@@ -39,24 +39,23 @@ def _step_ms(torch, dc, d_in, d_out, n, reps=4):
     return best
 
 
-@pytest.mark.parametrize("name", ["anscdf4s", "rccdf", "rcs"])
-def test_round_chunk_is_no_cliff(torch_cuda, name):
-    torch = torch_cuda
+def _sweep(torch, name, sizes, gen_weights=None, nmax=None, reps=4):
     codec = {v: k for k, v in trc.CODEC_NAMES.items()}[name]
     dev = torch.device("cuda:0")
-    nmax = 333 * MB
+    nmax = nmax or max(sizes)
     d_in = torch.zeros(nmax + 512, dtype=torch.uint8, device=dev)
-    T.table_bytes_device(torch, dev, nmax, T.text_weights(), 7, out=d_in)       # any prefix of it is the same kind of data
+    T.table_bytes_device(torch, dev, nmax, gen_weights if gen_weights is not None else T.text_weights(), 7, out=d_in)       # any prefix of it is the same kind of data
     d_out = torch.zeros(nmax + 512, dtype=torch.uint8, device=dev)
+    cap = 8192 if name == "ansb" else 16384
     report = []
-    for n in (70 * MB, 100 * MB, 120 * MB, 150 * MB, 333 * MB):
+    for n in sizes:
         pick = int(trc.lib().trc_round_chunk(codec, n))
         times = {}
-        for c in range(max(AUTO_MIN, pick - 256), min(4096, pick + 256) + 1, 64):
+        for c in range(max(AUTO_MIN, pick - 256), min(cap, pick + 256) + 1, 64):
             dc = trc.DeviceCoder(codec, n, c, dev)
             if codec in trc.STATIC:
                 dc.cdfini(d_in, n, 256)
-            times[c] = _step_ms(torch, dc, d_in, d_out, n)
+            times[c] = _step_ms(torch, dc, d_in, d_out, n, reps)
             if c == pick:
                 assert torch.equal(d_out[:n], d_in[:n]), "round trip failed"
             del dc
@@ -65,3 +64,33 @@ def test_round_chunk_is_no_cliff(torch_cuda, name):
                       (name, n // MB, pick, times[pick], best, times[best], max(times, key=times.get), max(times.values())))
         assert times[pick] <= 1.25 * times[best], report[-1] + "  all: %s" % {k: round(v, 3) for k, v in times.items()}
     print("\n".join(report))
+
+
+@pytest.mark.parametrize("name", ["anscdf4s", "rccdf", "rcs", "rccdfs2", "anscdf", "ansb"])
+def test_round_chunk_is_no_cliff(torch_cuda, name):
+    _sweep(torch_cuda, name, (70 * MB, 100 * MB, 120 * MB, 150 * MB, 333 * MB))
+
+
+@pytest.mark.parametrize("name", ["rccdf", "anscdf", "rcs"])
+def test_round_chunk_is_no_cliff_large_inputs(torch_cuda, name):
+    """Round 5: from one residency round x 4096 bytes up, the rule used to take k > 1 rounds under a 4096 cap; it now lets
+    the chunk grow to one round (cap 16 384).  0.5 / 1 / 2 GB: the pick against its +-256-byte neighbourhood (one 64-byte step
+    below it the input needs a second, nearly empty round), and -- what the change is for -- against the chunk the 4096 cap gave:
+    the same step time within 10 %, at the larger chunk's ratio."""
+    torch = torch_cuda
+    _sweep(torch, name, (500 * MB, 1000 * MB, 2000 * MB), reps=2)
+    codec = {v: k for k, v in trc.CODEC_NAMES.items()}[name]
+    dev = torch.device("cuda:0")
+    n = 1000 * MB
+    d_in = torch.zeros(n + 512, dtype=torch.uint8, device=dev)
+    T.table_bytes_device(torch, dev, n, T.text_weights(), 7, out=d_in)
+    d_out = torch.zeros(n + 512, dtype=torch.uint8, device=dev)
+    res = {}
+    for c in (3840, int(trc.lib().trc_round_chunk(codec, n))):          # 3840 = four rounds under the old cap
+        dc = trc.DeviceCoder(codec, n, c, dev)
+        ms = _step_ms(torch, dc, d_in, d_out, n, 3)
+        res[c] = (ms, int(dc.total[0].item()))
+        del dc
+    (c0, (ms0, tot0)), (c1, (ms1, tot1)) = sorted(res.items())
+    print("%s 1 GB: chunk %d %.2f ms %d B | chunk %d %.2f ms %d B" % (name, c0, ms0, tot0, c1, ms1, tot1))
+    assert c1 > 12000 and ms1 <= 1.10 * ms0 and tot1 < tot0

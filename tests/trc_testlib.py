@@ -185,15 +185,23 @@ def drift_bytes(n, seed=3, mean_seg=768.0, kmax=8, decay=0.6, alpha=1.3):
     sl = (np.floor(np.log1p(-u) / np.log1p(-1.0 / mean_seg)) + 1).astype(np.int64)
     while sl.sum() < n:
         sl = np.concatenate([sl, sl])
-    nseg = int(np.searchsorted(np.cumsum(sl), n) + 1)
-    sl = sl[:nseg]
+    cs = np.cumsum(sl)
+    nseg = int(np.searchsorted(cs, n) + 1)
+    sl = sl[:nseg]; cs = cs[:nseg]
     k = (splitmix64(nseg, seed + 102) % np.uint64(kmax - 1)).astype(np.int64) + 2                  # symbols in use: 2..kmax
     syms = np.stack([table_bytes(nseg, zipf_weights(alpha, 256), seed + 110 + j) for j in range(kmax)], axis=1)
-    seg = np.repeat(np.arange(nseg, dtype=np.int64), sl)[:n]
-    v = (splitmix64(n, seed) >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
-    # rank j with probability (1 - decay) * decay^j, the tail mass on the segment's last symbol
-    j = np.minimum(np.floor(np.log(np.maximum(1.0 - v, 1e-300)) / np.log(decay)).astype(np.int64), k[seg] - 1)
-    return syms[seg, j].astype(np.uint8)
+    # (round 5: the bytes themselves in blocks -- every byte depends on its own index and its segment only, and 1 GB of the
+    # whole-array form needs ~50 GB of temporaries; the output is the same)
+    out = np.empty(n, dtype=np.uint8)
+    BLK = 32 * 1000 * 1000
+    for lo in range(0, n, BLK):
+        cnt = min(BLK, n - lo)
+        seg = np.searchsorted(cs, np.arange(lo, lo + cnt, dtype=np.int64), side="right")
+        v = (splitmix64_range(lo, cnt, seed) >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+        # rank j with probability (1 - decay) * decay^j, the tail mass on the segment's last symbol
+        j = np.minimum(np.floor(np.log(np.maximum(1.0 - v, 1e-300)) / np.log(decay)).astype(np.int64), k[seg] - 1)
+        out[lo:lo + cnt] = syms[seg, j]
+    return out
 
 
 def nibble_bytes(n, seed=5, kind="geo"):
@@ -389,6 +397,11 @@ BENCH_CONFIGS = [
     dict(name="anscdf-drift100m-1536", codec=ANSA, kind="drift", seed=3, n=100 * 1000 * 1000, chunk=1536),
     dict(name="rccdf-drift100m-4096", codec=RCA, kind="drift", seed=3, n=100 * 1000 * 1000, chunk=4096),
     dict(name="anscdf-drift100m-4096", codec=ANSA, kind="drift", seed=3, n=100 * 1000 * 1000, chunk=4096),
+    # round 5: 1 GB inputs (`bench.py --codec X --size 1000000000`), where trc_round_chunk now lets the chunk grow to one residency
+    # round (~15 KiB): only the size ONE whole-buffer call of the reference returns is recorded (chunk None: no per-chunk hashes)
+    dict(name="rccdf-drift1g-whole", codec=RCA, kind="drift", seed=3, n=1000 * 1000 * 1000, chunk=None),
+    dict(name="anscdf-drift1g-whole", codec=ANSA, kind="drift", seed=3, n=1000 * 1000 * 1000, chunk=None),
+    dict(name="rcs-text1g-whole", codec=RCB, kind="text", seed=7, n=1000 * 1000 * 1000, chunk=None),
 ]
 
 

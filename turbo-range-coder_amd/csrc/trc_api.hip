@@ -74,11 +74,17 @@ extern "C" uint32_t trc_auto_chunk_codec(int codec, size_t n)
 }
 // The chunk for a DEVICE-RESIDENT call of n bytes (one launch over the whole input: trc_encode_dev, bench.py).  A launch lasts
 // (residency rounds) x (one wave's time, proportional to its chunk), so the input should be a whole number of rounds of the
-// coder's resident lanes, barely: the LARGEST chunk (multiple of 64, at most 4096: the ratio has nothing left to gain above)
-// with ceil(n / chunk) <= k rounds for the smallest k that allows it.  Lanes per round: static coders 12 waves per CU
-// (196 608 chunks; the two-lanes-per-chunk `-e45` coder 98 304), a model per lane in LDS 4 waves per CU (65 536), the
-// small-model coders (nibble, vnibble, Turbo-VLC) ~20 (327 680).  100 MB: 512 / 1024 / 1536 / 512 as measured best in round 3
-// (profiles/r03_notes.md section 7: 1280 instead of 1536 is a factor 1.9); 70 / 120 / 150 / 333 MB: tests/test_gpu_chunk_policy.py.
+// coder's resident lanes, barely: the LARGEST chunk (multiple of 64) with ceil(n / chunk) <= k rounds for the smallest k that
+// allows it.  Lanes per round: static coders 12 waves per CU (196 608 chunks; the two-lanes-per-chunk `-e45` coder 98 304), a
+// model per lane in LDS 4 waves per CU (65 536), the small-model coders (nibble, vnibble, Turbo-VLC) ~20 (327 680).  100 MB:
+// 512 / 1024 / 1536 / 512 as measured best in round 3 (profiles/r03_notes.md section 7: 1280 instead of 1536 is a factor 1.9);
+// 70 / 120 / 150 / 333 MB: tests/test_gpu_chunk_policy.py.
+// Round 5: the cap is TRC_ROUND_CHUNK_MAX = 16 384 bytes, not 4096.  Rounds pack (profiles/r04_notes.md 1): k rounds of chunk c
+// cost what ONE round of chunk k c costs -- and the larger chunk pays the model's learning phase and the coder's flush bytes k
+// times less often.  1 GB of `rccdf` took four rounds of chunk 3840 (28.0 % stored; one whole-buffer call of the reference:
+// 26.7 %); it now takes one round of chunk 15 296.  The kernels take chunks up to 65 536; above 16 KiB the
+// ratio has nothing left to gain.  (The bitwise rANS stays within one reference block, the order-1 coder at 4096.)
+#define TRC_ROUND_CHUNK_MAX 16384u
 static inline bool is_static(int codec);
 static size_t round_chunks(int codec)
 {
@@ -91,10 +97,11 @@ extern "C" uint32_t trc_round_chunk(int codec, size_t n)
 {
     if (codec == TRC_ANSO1) return 4096u;                     // (see trc_auto_chunk_codec)
     const size_t rc = round_chunks(codec);
+    const size_t cap = codec == TRC_ANSB ? TRC_ANSB_CHUNK_MAX : TRC_ROUND_CHUNK_MAX;
     for (size_t k = 1;; k++) {
         size_t c = (n + rc * k - 1) / (rc * k);               // ceil(n / c) <= rc * k
         c = (c + 63u) & ~(size_t)63u;
-        if (c <= 4096u) return c < TRC_CHUNK_AUTO_MIN ? TRC_CHUNK_AUTO_MIN : (uint32_t)c;
+        if (c <= cap) return c < TRC_CHUNK_AUTO_MIN ? TRC_CHUNK_AUTO_MIN : (uint32_t)c;
     }
 }
 extern "C" uint32_t trc_get_chunk(void)
