@@ -327,6 +327,14 @@ __global__ __launch_bounds__(128 * W) void trc_o1_model2_kernel(
 }
 
 // ------------------------------------------------------------------------------------- decode ---
+// Round 5: R chunks per wave (lanes 0 .. R - 1; 64 / R waves per group of 64 chunks).  These kernels are chains of table round trips:
+// a wave makes one per nibble as long as ANY of its lanes needs a table it does not hold, so with 64 chunks per wave (some lane always
+// misses) a 4096-byte chunk is 8192 round trips of ~0.8 us, and at 100 MB / 4096 there are 382 such waves -- 0.37 per SIMD, the chip
+// idle.  With R = 16 there are four times the waves: 5.88 -> 5.36 ms, NOT the factor the idle SIMDs promised -- a wave of 16 lanes
+// still has some lane missing at almost every nibble (a lane misses on 61-70 % of them), so every wave still walks the same
+// chain of two dependent ~0.7 us round trips per byte; only its other costs shrink.  R = 8: 6.8 ms (every wave-instruction then
+// serves 8 lanes: issue-bound).  profiles/r05_notes.md.
+template <u32 R>
 __global__ __launch_bounds__(64) void trc_o1_dec_kernel(
     const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
     u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ model, u8 *__restrict__ out)
@@ -336,16 +344,26 @@ __global__ __launch_bounds__(64) void trc_o1_dec_kernel(
     const u32 lane = threadIdx.x;
     o1_init_k(kb);
 
+    constexpr u32 WPG = 64u / R;                               // waves per group of 64 chunks
+    const u32 g0 = (blockIdx.x / WPG) * 64u, wq = blockIdx.x % WPG;
     WaveChunks wc;
-    wc.c0 = blockIdx.x * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
+    wc.c0 = g0 + wq * R; wc.chunk = chunk; wc.nchunks = nchunks;
     wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
-    wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
+    wc.rows = wc.c0 >= nchunks ? 0u : nchunks - wc.c0 < R ? nchunks - wc.c0 : R;
+    // the directory of the whole group (payload offsets are per group of 64 chunks): lane L reads chunk g0 + L, the wave's own R
+    // chunks take their numbers from lanes wq R ..
+    const u32 cg = g0 + lane;
+    const u32 lenL = cg < nchunks ? ((cg == nchunks - 1u) ? wc.lastlen : chunk) : 0u;
+    const u32 clL = cg < nchunks ? trc_min(clen[cg], lenL) : 0u;   // a directory entry above the chunk length (corrupt input) reads as raw
+    const u32 exL = trc_wave_incl_scan(clL) - clL;
+    const u32 srcl = (wq * R + lane) & 63u;
+    const u32 cl_s = (u32)__shfl((int)clL, (int)srcl, 64), ex_s = (u32)__shfl((int)exL, (int)srcl, 64), len_s = (u32)__shfl((int)lenL, (int)srcl, 64);
     const bool alive = lane < wc.rows;
     const u32 c = wc.c0 + lane;
-    const u32 len = alive ? wc.len_of(lane) : 0u;
-    const u32 cl = alive ? trc_min(clen[c], len) : 0u;        // a directory entry above the chunk length (corrupt input) reads as raw
-    const u32 ex = trc_wave_incl_scan(cl) - cl;
-    const u64 off = trc_group_base(goff, gsum, wc.c0 >> 6) + ex;
+    const u32 len = alive ? len_s : 0u;
+    const u32 cl = alive ? cl_s : 0u;
+    const u32 ex = ex_s;
+    const u64 off = trc_group_base(goff, gsum, g0 >> 6) + ex;
     const bool coded = alive && cl != len;
     O1Cache tc;
     tc.init(model + (u64)(wc.c0 + (alive ? lane : 0u)) * O1_MODEL_BYTES, seen);
@@ -439,6 +457,14 @@ bool trc_launch_anso1_model(const uint8_t *d_in, size_t n, uint32_t chunk, const
 void trc_launch_anso1_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                           const TrcWork &w, uint8_t *d_out, hipStream_t s)
 {
-    TRC_LAUNCH_TIMED(trc_o1_dec_kernel, dim3(w.ngroups), dim3(64), 0, s,
-                       d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, w.model, d_out);
+    static const int env_rows = getenv("TRC_O1_ROWS") ? atoi(getenv("TRC_O1_ROWS")) : 0;       // tuning aid: 64 / 16 / 8 force the form
+    // sparse waves where the chip is nearly empty (100 MB at chunk 4096: 382 groups -- 5.88 -> 5.36 ms; at 763 groups and up the
+    // 64-chunk waves are as fast or faster: profiles/r05j_ab.txt)
+    const int rows = env_rows ? env_rows : (w.ngroups <= 512u ? 16 : 64);
+    if (rows == 16)
+        TRC_LAUNCH_TIMED(trc_o1_dec_kernel<16>, dim3(w.ngroups * 4u), dim3(64), 0, s, d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, w.model, d_out);
+    else if (rows == 8)
+        TRC_LAUNCH_TIMED(trc_o1_dec_kernel<8>, dim3(w.ngroups * 8u), dim3(64), 0, s, d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, w.model, d_out);
+    else
+        TRC_LAUNCH_TIMED(trc_o1_dec_kernel<64>, dim3(w.ngroups), dim3(64), 0, s, d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, w.model, d_out);
 }
