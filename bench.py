@@ -641,8 +641,8 @@ def main():
             res["beyond_cache"] = beyond_cache_leg(torch, trc, T, codec, chunk, dev)
             res["roofline"]["frac_beyond_l3"] = res["beyond_cache"]["frac"]
             res["roofline"]["note_l3"] = "frac is measured on the 100 MB workload, which (with its 64.5 MB payload) fits the 256 MiB Infinity Cache; frac_beyond_l3 is the same kernel on 1 GB"
-        if world == 1 and default_metric and not args.no_configs and inflight == 1:
-            res["configs"] = other_configs()
+        if world == 1 and default_metric and not args.no_configs and not args.no_cpu and not args.no_beyond and inflight == 1:
+            res["configs"] = other_configs()                   # (the full default line only: the measuring scripts pass --no-cpu / --no-beyond)
         if world == 1 and not args.no_cpu:
             if d is None:                                      # device-only workload: time the CPU on the first bytes of the same stream
                 d = T.table_bytes_range(0, min(n, 100 * 1000 * 1000), T.zipf_weights(1.1, 256), 1000 + rank)

@@ -347,6 +347,49 @@ def test_round4_kernel_forms(torch_cuda):
         assert r.returncode == 0 and "ok" in r.stdout, (env, r.stdout[-2000:] + r.stderr[-3000:])
 
 
+def test_round5_workgroup_shapes(torch_cuda):
+    """round 5: the launch code picks between two workgroup shapes by the size of the launch -- small workgroups (rounds 1-4), or
+    one large workgroup per CU whose waves keep each other's pace (TrcPace, csrc/trc_dev.h) when the launch is one residency round:
+    static rANS / range-coder encoders (1 / 4 vs 12 waves), the two-stream pair encoder (2 vs 12), the four-lanes-per-chunk rANS
+    coding passes (4 vs 16), the order-1 decoder (64 / 16 / 8 chunks per wave).  The pace-keeping itself only moves wave priorities.
+    Every shape is FORCED in a process of its own (the switches are read once) on inputs of a few groups -- which the automatic
+    rule would never give the large shape: ragged tails, a short last workgroup, raw chunks -- per-chunk parity with the oracle
+    and round trip."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np, torch
+        sys.path[:0] = [%r, %r]
+        import trc, trc_testlib as T
+        from golden.make_golden import gen
+        for codec in (trc.ANS4S, trc.RCS1, trc.RCS2, trc.RCSM, trc.ANSA, trc.ANSB, trc.ANSO1):
+            for kind, n, chunk in (("text", 300001, 512), ("runs", 64 * 1024 * 13 + 5, 1024), ("uniform", 40000, 256), ("zipf", 270001, 4096), ("text", 701, 256),
+                                   ("text", 64 * 256 * 25 + 77, 256)):
+                if codec == trc.ANSO1 and chunk < 1024:
+                    continue
+                d = gen(kind, n, 8)
+                _, cdf, cdfnum = T.orc_cdfini(d)
+                dc = trc.DeviceCoder(codec, n, chunk, "cuda:0")
+                if codec in trc.STATIC:
+                    dc.set_cdf(cdf, cdfnum)
+                d_in = torch.from_numpy(np.concatenate([d, np.zeros(512, np.uint8)])).to("cuda:0")
+                dc.encode(d_in, n)
+                clen, payload = dc.result(n)
+                ep, ec, _ = T.orc_chunked_enc(codec, d, chunk, cdf, cdfnum)
+                assert np.array_equal(clen, ec) and np.array_equal(payload, ep), (trc.CODEC_NAMES[codec], kind, n, chunk)
+                out = torch.full((n + 512,), 0xA5, dtype=torch.uint8, device="cuda:0")
+                dc.decode(out, n, dir_ready=True); torch.cuda.synchronize()
+                o = out.cpu().numpy()
+                assert np.array_equal(o[:n], d) and (o[n:] == 0xA5).all(), (trc.CODEC_NAMES[codec], kind, n, chunk)
+        print("ok")
+    """) % (os.path.dirname(os.path.abspath(trc.__file__)), os.path.dirname(os.path.abspath(__file__)))
+    forms = (dict(TRC_ENC_WPB="12", TRC_RCS_ENC_WPB="12", TRC_CODEQ_GPW="4", TRC_O1_ROWS="16"),             # the large shapes, on small inputs
+             dict(TRC_ENC_WPB="4", TRC_RCS_ENC_WPB="1", TRC_CODEQ_GPW="1", TRC_O1_ROWS="64"),               # the small shapes
+             dict(TRC_O1_ROWS="8"))
+    for env in forms:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+        assert r.returncode == 0 and "ok" in r.stdout, (env, r.stdout[-2000:] + r.stderr[-3000:])
+
+
 def test_bounded_host_decoder(torch_cuda):
     """trc_decode_host: the decoder that is told how long its input really is.  A valid container round-trips; a truncated
     buffer, a header that claims more payload than the buffer holds and a directory that does not add up are REJECTED

@@ -156,13 +156,24 @@ __global__ __launch_bounds__(128 * TRC_WPG) void trc_ansa_model2_kernel(
     NibTable T0 = m.load(m.table(0));                          // (hi wave)
 
     const u32 S = chunk / TRC_SEG;
+    // (TRC_ANSA_M2_PAIR: both 64-byte halves of a 128-byte input line requested together, QuadIn::take_fwd -- the pass then reads 200 MB
+    // from the fabric for its two walks of 100 MB instead of ~1.8 x that, and runs 6 % SLOWER (encode 0.587 -> 0.623 ms,
+    // profiles/r05k_ab.txt): the pass is not bound by its traffic.  Off.)
+#ifndef TRC_ANSA_M2_PAIR
     qin.issue(wc, 0);
+#else
+    qin.start_fwd(wc, S);
+#endif
     for (u32 s = 0; s < S; s++) {
 #ifndef TRC_ANSA_M2_NOPACE
         pace.step(s + 1u);
 #endif
+#ifndef TRC_ANSA_M2_PAIR
         qin.commit();
         if (s + 1 < S) qin.issue(wc, (s + 1) * TRC_SEG);
+#else
+        qin.take_fwd(wc, s, S);
+#endif
         uint4 pc0 = qin.read(0), pc1 = qin.read(1), pc2 = qin.read(2), pc3 = qin.read(3);
 #pragma nounroll
         for (u32 k = 0; k < 4; k++) {

@@ -687,8 +687,8 @@ void trc_launch_ans4s_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const T
     // (TrcPace: they share SIMDs by construction); more than a round: workgroups of four, sixteen waves per CU, new ones moving in
     // as old ones end
     if (TRC_ENC_BALANCE && nwaves <= 12u * 256u) wpb = 12u;
-    if (env_wpb == 1 || env_wpb == 4 || env_wpb == 12) wpb = (u32)env_wpb;
     if (nwaves < 2048) { rep = 1; wpb = 1; }                 // few waves: one per workgroup so they spread over all CUs (12.4 KiB -> 12 per CU)
+    if (env_wpb == 1 || env_wpb == 4 || env_wpb == 12) wpb = (u32)env_wpb;      // (tuning aid / tests: forces the shape whatever the size)
     if (rep == 8) ans4s_enc_launch<8>(wpb, d_in, n, chunk, w, d_clen, s);
     else ans4s_enc_launch<1>(wpb, d_in, n, chunk, w, d_clen, s);
 }

@@ -236,6 +236,22 @@ struct QuadIn {
 #pragma unroll
         for (int k = 0; k < 4; k++) p[k] = make_uint4(m[k][0], m[k][1], m[k][2], m[k][3]);
     }
+    // The same for kernels that walk their chunks UPWARD (round 5: the model passes of the adaptive coders read 1.8 x their input
+    // from the fabric -- each nontemporal 64-byte request pulled its 128-byte line, and the line's other half was asked for one
+    // segment-time later, when it was gone).  Segments s (even) and s + 1 are requested together, one segment ahead of their use:
+    //   start_fwd(w, S);   every s: take_fwd(w, s, S); code segment s (read(k))
+    __device__ __forceinline__ void start_fwd(const WaveChunks &w, u32 S)
+    {
+        issue_slot<0>(w, 0);
+        if (S > 1u) issue_slot<1>(w, 1);
+    }
+    __device__ __forceinline__ void take_fwd(const WaveChunks &w, u32 s, u32 S)
+    {
+        if (s & 1u) {
+            commit_slot<1>();
+            if (s + 1u < S) { issue_slot<0>(w, s + 1u); if (s + 2u < S) issue_slot<1>(w, s + 2u); }     // both register sets are free now
+        } else commit_slot<0>();
+    }
 };
 
 struct QuadOut {
