@@ -11,8 +11,9 @@
 //
 // MI355X mapping: symbol tables in LDS (encoder: 256 x 16 B {reciprocal, 2^15-f | shift<<24,
 // f<<16, c0}; decoder: 32 KiB slot->symbol LUT + 256 x 8 B {f, -c0}); all HBM traffic in 64-byte
-// quad segments through the LDS tiles/rings of trc_io.h.  No MFMA: integer work, bounded by VALU
-// issue (4 cycles per wave64 op) and LDS, not by HBM (DESIGN.md has the arithmetic).
+// quad segments through the LDS tiles/rings of trc_io.h.  No MFMA: integer work, bounded by instruction
+// issue (measured in round 5: 2.3 cycles per plain VOP2 wave64 operation, 4.2-4.6 for the three-operand / multiply / SDWA /
+// DPP / compare kind these loops are made of, profiles/r05_valu_rates.txt) and LDS, not by HBM (DESIGN.md has the arithmetic).
 #include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
@@ -380,8 +381,9 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
     // dependent round trips (tables -> barrier -> clen -> group base -> states and first ring fill), the last of them a burst of
     // 128 bytes per stream from every wave of the launch at once.  Now: the directory entry and the group base are requested
     // FIRST, together with the tables (nothing of them depends on the tables); the states and the ring fill are requested before
-    // the barrier, which waits for LDS only (__syncthreads() would sit out every load in flight); the rings' second halves land
-    // one period later (StreamInT::prime_issue / prime_land).
+    // the barrier, which waits for LDS only (__syncthreads() would sit out every load in flight).  (The rings' second halves landing
+    // one period later -- StreamInT::prime_land(P, 1) behind the first 16 symbols -- was built too: no change, and it does not go
+    // with the aligned segments below, whose first half may hold as little as two bytes of the stream.)
     const u32 cl_raw = alive ? clen[c] : 0u;
     const u64 gbase0 = valid ? trc_group_base(goff, gsum, wc.c0 >> 6) : 0ull;
     // the table fill as one batch of loads (a plain copy loop waits for each of its three loads before it issues the next:
@@ -415,7 +417,13 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
     QuadOut tout; tout.base = out + (u64)wc.c0 * chunk;        // output leaves through an in-register quad transpose
     AnsStreamIn si;
     si.rings = wbase;
+    // Round 5: the stream is read in segments aligned to 64 bytes of the PAYLOAD, not of the stream: the ring's "stream" starts at the
+    // 64-byte boundary below the first word (r0 bytes of it are somebody else's and are skipped by starting the cursor at r0), so
+    // every 64-byte refill request is one 64-byte sector of one line.  Stream-relative segments (rounds 1-4) straddled two
+    // sectors at 2-byte alignment: the payload was fetched 2.7 times (profiles/r04_pmc_traffic.txt), the first ring fill of a launch
+    // -- 128 bytes per stream from every wave at once -- took three sectors per stream where two do.
     si.gbase = payload; si.soff = off + 8; si.lim = trc_sub_sat(cl, 8u);   // words follow the two states
+    const u32 r0 = si.align_start(coded);
     u32 sa = 0, sb = 0;
     if (coded) { sa = trc_ld32_a2(payload + off); sb = trc_ld32_a2(payload + off + 4); }   // sa = enc state 1, sb = enc state 0
     AnsStreamIn::Prime P;
@@ -426,6 +434,8 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
     return;
 #endif
     si.prime_land(P, 0, coded);
+    si.prime_land(P, 1, coded);                                // (both halves before the first period: of the first one up to 62 bytes are skipped)
+    si.rpos = r0;
 
     const u32 S = chunk / TRC_SEG;
     const u32 body4 = len & ~3u;
@@ -446,7 +456,6 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
             // priorities 63, laggards 3 / leader 1: 63; off: 67)
             if (TRC_DEC_BALANCE == 1 || k == 0 || (TRC_DEC_BALANCE == 3 && k == 2)) pace.step(s * 4u + (u32)k + 1u);
 #endif
-            if (k == 1 && s == 0) si.prime_land(P, 1, coded);   // the rings' second halves (requested with the first, start-up comment)
             // period boundary: land the round requested 16 symbols ago, request the next one
 #ifdef TRC_DEC_ABL_NOPERIOD
             si.lbytes = si.rpos + TRC_SRING;

@@ -423,6 +423,21 @@ struct StreamInT {
     // helper side: this lane moves one 16-byte piece of some lane's segment, per register set
     uint4 hvA, hvB; u32 hdA, hdB; bool hokA, hokB;
 
+    // Round 5: segments aligned to 64 bytes of the PAYLOAD, not of the stream.  Call after gbase / soff / lim are set and before
+    // prime: the ring's "stream" then starts at the 64-byte boundary below the first byte; set rpos to the returned r0 after prime
+    // (r0 bytes of the first segment are somebody else's).  Every 64-byte refill request is then one 64-byte sector of one line;
+    // stream-relative segments at 2-byte alignment straddled two (the static rANS decoder fetched its payload 2.7 times,
+    // profiles/r04_pmc_traffic.txt).
+    __device__ __forceinline__ u32 align_start(bool on)
+    {
+#ifdef TRC_DEC_NOALIGN
+        return 0u;
+#else
+        const u32 r0 = on ? trc_min((u32)(((uintptr_t)gbase + soff) & 63u), soff < 62u ? (u32)soff : 62u) & ~1u : 0u;
+        soff -= r0; lim += r0;
+        return r0;
+#endif
+    }
     __device__ __forceinline__ u32 peek16() const { return *(const u16 *)(rings + ra(trc_lane(), rpos & (TRC_SRING - 1))); }
     __device__ __forceinline__ u32 peek32() const { return *(const u32 *)(rings + ra(trc_lane(), rpos & (TRC_SRING - 1))); }
     __device__ __forceinline__ u32 avail() const { return lbytes - rpos; }

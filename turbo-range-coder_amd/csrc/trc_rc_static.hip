@@ -190,8 +190,9 @@ __global__ __launch_bounds__(896) void trc_rcs_dec_kernel(
         s1.rings = s0.rings + TRC_SRING_BYTES;
         s1.soff = off + 4u + len0; s1.lim = trc_sub_sat(cl, 4u + len0);
     }
-    s0.prime(coded);
-    if (NS == 2) s1.prime(coded);
+    const u32 r00 = s0.align_start(coded), r01 = NS == 2 ? s1.align_start(coded) : 0u;      // segments aligned to the payload's 64-byte sectors (trc_io.h)
+    s0.prime(coded); s0.rpos = r00;
+    if (NS == 2) { s1.prime(coded); s1.rpos = r01; }
     typedef typename RcGeo<GEO>::Dec Dec;
     Dec d0, d1;
     d0.init(s0);
@@ -419,6 +420,8 @@ __global__ __launch_bounds__(896) void trc_rcs2p_dec_kernel(
     si.gbase = payload;
     si.soff = off + 4u + (b ? len0 : 0u);
     si.lim = b ? trc_sub_sat(cl, 4u + len0) : len0;
+    // (segments aligned to the payload's sectors, StreamInT::align_start: measured here and not taken -- with one lane per stream the
+    // streams are half as long, the skipped bytes of the first segment cost relatively more refills: 0.140 -> 0.143-0.145 ms)
     si.prime(coded);
     RcDec d; d.init(si);
 
