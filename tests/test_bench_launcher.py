@@ -31,7 +31,7 @@ def test_dry_launch_command_and_environment():
     # BASELINE config 5 on 8 GPUs: what one rank allocates (1 GB shard; two banks of 8 result sets, two banks of 7 receive
     # sets, the coder's scratch) must fit a 288 GB GPU with a wide margin
     b = j["hbm_bytes_per_rank"]
-    assert b["chunk"] == 2560 and b["receive_banks"] == 2 * 7 * (4 * 390625 + 10**9 + 1024)
+    assert b["chunk"] == 5120 and b["receive_banks"] == 2 * 7 * (4 * 195313 + 10**9 + 1024)      # (round 5: one residency round of chunk 5120, not two of 2560)
     assert 30e9 < b["total"] < 40e9, b
 
 
