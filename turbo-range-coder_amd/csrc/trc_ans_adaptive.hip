@@ -759,8 +759,11 @@ void trc_launch_ansa_code_planar(size_t n, uint32_t chunk, const TrcWork &w, uin
     static const int gpw_env = getenv("TRC_CODEQ_GPW") ? atoi(getenv("TRC_CODEQ_GPW")) : 0;     // tuning aid: 1 / 4 force the workgroup shape
     const bool big = gpw_env ? gpw_env == 4 : (w.ngroups >= 512u && w.ngroups <= 4u * 256u);
     if (codeq && big) {
-        TRC_RAISE_LDS_ONCE(trc_ansa_codeq_kernel<4>, ANSQ_LDS(4));
-        TRC_LAUNCH_TIMED(trc_ansa_codeq_kernel<4>, dim3((w.ngroups + 3u) / 4u), dim3(1024), ANSQ_LDS(4), s,
+        // (the LDS request is padded beyond half a CU's: one 16-wave workgroup per CU, four waves per SIMD.  At its real 71 KiB two fit,
+        // and where the dispatcher doubles up a CU runs eight waves per SIMD while another idles -- the pass was bimodal, 0.20 / 0.30 ms)
+        const size_t lds1 = ANSQ_LDS(4) > TRC_LDS_ONE_PER_CU ? ANSQ_LDS(4) : TRC_LDS_ONE_PER_CU;
+        TRC_RAISE_LDS_ONCE(trc_ansa_codeq_kernel<4>, lds1);
+        TRC_LAUNCH_TIMED(trc_ansa_codeq_kernel<4>, dim3((w.ngroups + 3u) / 4u), dim3(1024), lds1, s,
                            (const u8 *)w.scratch2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
     } else if (codeq)
         TRC_LAUNCH_TIMED(trc_ansa_codeq_kernel<1>, dim3(w.ngroups), dim3(256), ANSQ_LDS(1), s,

@@ -295,6 +295,8 @@ void trc_launch_ansb_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const Tr
     TRC_LAUNCH_TIMED(trc_ansb_model_kernel, TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (ANSB_MODEL_BYTES), s, d_in, (u64)n, chunk, w.nchunks, w.scratch2);
     static const int gpw_env = getenv("TRC_CODEQ_GPW") ? atoi(getenv("TRC_CODEQ_GPW")) : 0;     // tuning aid: 1 / 4 force the workgroup shape
     if (gpw_env ? gpw_env == 4 : (w.ngroups >= 512u && w.ngroups <= 4u * 256u)) {
+        // (not padded to one workgroup per CU as the anscdf pass is: this pass streams 16 bytes of records per input byte and runs no
+        // worse with whatever the dispatcher does -- 1.18-1.31 ms unpadded, 1.29-1.35 padded, profiles/r05_notes.md)
         TRC_RAISE_LDS_ONCE(trc_ansb_codeq_kernel<4>, ANSBQ_LDS(4));
         TRC_LAUNCH_TIMED(trc_ansb_codeq_kernel<4>, dim3((w.ngroups + 3u) / 4u), dim3(1024), ANSBQ_LDS(4), s,
                            (const u8 *)w.scratch2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);

@@ -379,7 +379,7 @@ __global__ __launch_bounds__(64) void trc_o1_dec_kernel(
     auto get_nibble = [&](u32 &s, NibTable &T) -> u32 {
         const u32 slot = s & (TRC_PROB_ONE - 1);
         u32 c0, c1;
-        const u32 x = trc_nib_find(T, slot, c0, c1);
+        const u32 x = trc_nib_find<true>(T, slot, c0, c1);    // (bit-select form: trc_nibmodel.h)
         s = __umul24(c1 - c0, s >> TRC_PROB_BITS) + slot - c0;
         o1_adapt(T, kb, x);
         return x;

@@ -28,6 +28,10 @@ bool trc_first_use_on_device(unsigned long long *mask);
             (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
     } while (0)
 
+// a dynamic-LDS request above half of a CU's 160 KiB: at most one such workgroup per CU (the large workgroups whose waves keep each
+// other's pace, TrcPace: their waves are meant to be the only ones on their SIMDs)
+#define TRC_LDS_ONE_PER_CU (82u * 1024u)
+
 // Workspace carve-up shared by encode and decode (all offsets 256-byte aligned).
 struct TrcWork {
     uint8_t  *tables;    // per-call coder tables derived from the CDF (static coders)

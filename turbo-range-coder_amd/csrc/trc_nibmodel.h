@@ -255,18 +255,16 @@ struct NibModel {
 // = 32768 appended).  `ge(e)` answers "q >= e" for a 16-bit table entry e: the rANS decoders compare the slot itself, the
 // range decoders compare code >= (range >> 15) * e -- the same predicate as floor(code / (range >> 15)) >= e without
 // the division (trc_rc.h).
-// Round 5: the twelve selects of a search are BIT-selects under a mask per level (v_bfi_b32, one mask instruction per level), not
-// v_cndmask on the compare's VCC.  The compiler emitted the latter as runs of three to five VOP2 v_cndmask_b32 -- the encoding that
-// reads VCC implicitly -- and a run of three or more of those costs a lone wave ~45 cycles per instruction beyond the second
-// (scripts/probe/valu_occ.hip "3cnd_e32,add" 16.0 cycles per instruction at one wave per SIMD against 4.7 for "2cnd_e32,2add";
-// profiles/r05_valu_rates.txt): eight such runs per byte pair in the `anscdf` decoder's loop (TRC_NIB_SEARCH_CND=1: that form).
-#ifndef TRC_NIB_SEARCH_CND
-#define TRC_NIB_SEARCH_CND 0
-#endif
-template <class GE>
+// Round 5, a negative result kept as a switch.  The compiler emits the twelve selects of a search as runs of three to five VOP2
+// v_cndmask_b32, the encoding the rate probe prices at 16-23 cycles per instruction in runs (profiles/r05_valu_rates.txt).  The same
+// search as BIT-selects under one mask per level (v_bfi_b32; BFI = true) has no such run -- and is SLOWER in every decoder that holds its
+// tables in registers (`anscdf` decode 0.540 -> 0.559 ms, `rccdf` 0.62 -> 0.67, `rccdf4` 0.269 -> 0.286, `rccdf8` 0.916 -> 0.97;
+// profiles/r05m_ab.txt): in these instruction streams the runs do not cost what the probe's steady state says, the four extra mask
+// instructions do.  Only the order-1 decoder, whose waves wait on memory, gains (5.36 -> 5.11 ms) and uses it.
+template <bool BFI = false, class GE>
 __device__ __forceinline__ u32 trc_nib_search(const NibTable &T, GE ge, u32 &c0, u32 &c1)
 {
-#if TRC_NIB_SEARCH_CND
+    if constexpr (!BFI) {
     const bool b3 = ge(T.d[4] & 0xffffu);
     const u32 e0 = b3 ? T.d[4] : T.d[0], e1 = b3 ? T.d[5] : T.d[1], e2 = b3 ? T.d[6] : T.d[2],
               e3 = b3 ? T.d[7] : T.d[3], e4 = b3 ? TRC_PROB_ONE : T.d[4];
@@ -282,7 +280,7 @@ __device__ __forceinline__ u32 trc_nib_search(const NibTable &T, GE ge, u32 &c0,
     u32 x = b3 ? 1u : 0u;
     x = x + x + (b2 ? 1u : 0u); x = x + x + (b1 ? 1u : 0u); x = x + x + (b0 ? 1u : 0u);
     return x;
-#else
+    } else {
     const u32 m3 = ge(T.d[4] & 0xffffu) ? ~0u : 0u;
     const u32 e0 = trc_bfi(m3, T.d[4], T.d[0]), e1 = trc_bfi(m3, T.d[5], T.d[1]), e2 = trc_bfi(m3, T.d[6], T.d[2]),
               e3 = trc_bfi(m3, T.d[7], T.d[3]), e4 = trc_bfi(m3, TRC_PROB_ONE, T.d[4]);
@@ -295,9 +293,10 @@ __device__ __forceinline__ u32 trc_nib_search(const NibTable &T, GE ge, u32 &c0,
     c0 = trc_bfi(m0, gh, g0 & 0xffffu);
     c1 = trc_bfi(m0, g1 & 0xffffu, gh);
     return (m3 & 8u) | (m2 & 4u) | (m1 & 2u) | (m0 & 1u);
-#endif
+    }
 }
+template <bool BFI = false>
 __device__ __forceinline__ u32 trc_nib_find(const NibTable &T, u32 q, u32 &c0, u32 &c1)
 {
-    return trc_nib_search(T, [q](u32 e) { return q >= e; }, c0, c1);
+    return trc_nib_search<BFI>(T, [q](u32 e) { return q >= e; }, c0, c1);
 }
