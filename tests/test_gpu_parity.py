@@ -347,6 +347,32 @@ def test_round4_kernel_forms(torch_cuda):
         assert r.returncode == 0 and "ok" in r.stdout, (env, r.stdout[-2000:] + r.stderr[-3000:])
 
 
+def test_decoders_take_payloads_at_any_legal_alignment(torch_cuda):
+    """round 5: the static decoders fetch their streams in segments aligned to 64 bytes of the PAYLOAD ADDRESS (StreamInT::align_start:
+    the ring's stream starts below the first word, the cursor skips the difference).  The device layer only asks for a 2-byte-aligned
+    payload pointer: the same container is decoded from payload copies at byte offsets 0 .. 126 of a 256-byte-aligned buffer (every
+    residue of the first stream's start modulo 64, the first chunk's `soff < 62` clamp included), raw chunks and a ragged tail among them."""
+    torch = torch_cuda
+    for codec in (trc.ANS4S, trc.RCS1, trc.RCSM, trc.RCS2):
+        n, chunk = 64 * 512 * 3 + 333, 512
+        d = gen("text", n, 77)
+        d[5 * chunk:6 * chunk] = gen("uniform", chunk, 3)                 # a raw chunk in the first group
+        _, cdf, cdfnum = T.orc_cdfini(d)
+        dc = trc.DeviceCoder(codec, n, chunk, "cuda:0")
+        dc.set_cdf(cdf, cdfnum)
+        d_in = to_dev(torch, d)
+        dc.encode(d_in, n)
+        clen, payload = dc.result(n)
+        for shift in (0, 2, 6, 8, 30, 54, 56, 62, 64, 66, 126):
+            buf = torch.zeros(payload.size + 1024, dtype=torch.uint8, device="cuda:0")
+            buf[shift:shift + payload.size] = torch.from_numpy(payload).to("cuda:0")
+            d_out = torch.full((n + 512,), 0xA5, dtype=torch.uint8, device="cuda:0")
+            dc.decode(d_out, n, clen=dc.clen, payload=buf[shift:])
+            torch.cuda.synchronize()
+            out = d_out.cpu().numpy()
+            assert np.array_equal(out[:n], d) and (out[n:] == 0xA5).all(), (trc.CODEC_NAMES[codec], shift)
+
+
 def test_round5_workgroup_shapes(torch_cuda):
     """round 5: the launch code picks between two workgroup shapes by the size of the launch -- small workgroups (rounds 1-4), or
     one large workgroup per CU whose waves keep each other's pace (TrcPace, csrc/trc_dev.h) when the launch is one residency round:
