@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256 * GPW) void trc_ansa_codeq_kernel(
     const u32 room = 2u + 4u * 4u;                             // mnflush: ep <= op + sizeof(io_t) + states * 4  ->  raw
     const u8 *rbase = recs + (u64)(alive ? c : 0u) * (8u * (u64)chunk);
 
-    StreamOut<true, false, true> so;
+    StreamOut<true, false, true, true> so;
     so.rings = smem + ANSQ_TILE;
     so.scratch = scratch; so.stride = stride; so.c0 = cw0; so.wpos = 0; so.nfl = 0;
     u32 st = TRC_ANS_LOW;

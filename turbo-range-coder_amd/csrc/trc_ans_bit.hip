@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256 * GPW) void trc_ansb_codeq_kernel(
     const u32 len = alive ? (c == nchunks - 1u ? lastlen : chunk) : 0u;
     const u8 *rbase = recs + (u64)(alive ? c : 0u) * (16u * (u64)chunk) + 16u * s;
 
-    StreamOut<true, false, true> so;
+    StreamOut<true, false, true, true> so;
     so.rings = smem;
     so.scratch = scratch; so.stride = stride; so.c0 = cw0; so.wpos = 0; so.nfl = 0;
     u32 st = TRC_ANS_LOW;

@@ -130,6 +130,9 @@ __device__ __forceinline__ void ans_fetch4(EncQuad &q, u32 w, u32 tbase, int shi
 #define ANS_WAIT4(q, pending)                                                                                        \
     asm volatile("s_waitcnt lgkmcnt(" #pending ")" : "+v"(q.e0), "+v"(q.e1), "+v"(q.e2), "+v"(q.e3) :: "memory")
 
+#ifdef TRC_ENC_PROF                                              // variant builds only: wall clock (100 MHz) per wave: start, first symbol, last symbol, end
+__device__ unsigned long long trc_enc_wall[4 * 4096];
+#endif
 template <int BLOCK, int REP>
 __global__ __launch_bounds__(BLOCK) void trc_ans4s_enc_kernel(
     const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks,
@@ -141,6 +144,9 @@ __global__ __launch_bounds__(BLOCK) void trc_ans4s_enc_kernel(
     constexpr int SH = REP == 16 ? 8 : REP == 8 ? 7 : REP == 4 ? 6 : 4;
     static_assert(REP == 1 || REP == 8 || REP == 16, "replica count");
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+#ifdef TRC_ENC_PROF
+    const u64 ew0 = wall_clock64();
+#endif
     u8 *wbase = smem + TAB + ENC_PACE_LDS + wv * ENC_WAVE_LDS;
     for (u32 i = tid; i < 256u * REP; i += BLOCK) ((uint4 *)smem)[i] = etab_g[i / REP];
     TrcPace pace; pace.init(trc_lds_addr(smem) + TAB, tid, wv);
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(BLOCK) void trc_ans4s_enc_kernel(
     const u32 c = wc.c0 + lane;
     const u32 len = alive ? wc.len_of(lane) : 0u;
     QuadIn tin; tin.base = in + (u64)wc.c0 * chunk;
-    StreamOut<true> so;
+    StreamOut<true, false, false, true> so;                   // (write-through drains: trc_io.h)
     so.rings = wbase;
     so.scratch = scratch; so.stride = stride; so.c0 = wc.c0; so.wpos = 0; so.nfl = 0;
     const u32 tbase = (lane & (u32)(REP - 1)) << 4;                              // this lane's replica (table at LDS offset 0)
@@ -182,6 +188,9 @@ __global__ __launch_bounds__(BLOCK) void trc_ans4s_enc_kernel(
         }
     };
     take(S - 1u);
+#ifdef TRC_ENC_PROF
+    const u64 ew1 = wall_clock64();
+#endif
     for (u32 s = S - 1u;; s--) {
         if (BLOCK > 256) pace.step(S - s);                     // (workgroups of more than four waves: some share a SIMD)
 #if !TRC_ENC_EARLY_COMMIT
@@ -234,6 +243,9 @@ __global__ __launch_bounds__(BLOCK) void trc_ans4s_enc_kernel(
         }
         if (s == 0) break;
     }
+#ifdef TRC_ENC_PROF
+    const u64 ew2 = wall_clock64();
+#endif
     u32 out_len = 0;
     if (alive) {
         if (!ovf) {
@@ -247,6 +259,9 @@ __global__ __launch_bounds__(BLOCK) void trc_ans4s_enc_kernel(
     if (alive) clen[c] = out_len;
     const u32 gs = trc_wave_sum(out_len);
     if (lane == 0) gsum[wc.c0 >> 6] = gs;
+#ifdef TRC_ENC_PROF
+    if (lane == 0) { const u32 wid = (wc.c0 >> 6) & 4095u; trc_enc_wall[4 * wid] = ew0; trc_enc_wall[4 * wid + 1] = ew1; trc_enc_wall[4 * wid + 2] = ew2; trc_enc_wall[4 * wid + 3] = wall_clock64(); }
+#endif
 }
 
 // ------------------------------------------------------------------------------------- decode ---
@@ -700,6 +715,28 @@ void trc_launch_ans4s_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const T
     if (env_wpb == 1 || env_wpb == 4 || env_wpb == 12) wpb = (u32)env_wpb;      // (tuning aid / tests: forces the shape whatever the size)
     if (rep == 8) ans4s_enc_launch<8>(wpb, d_in, n, chunk, w, d_clen, s);
     else ans4s_enc_launch<1>(wpb, d_in, n, chunk, w, d_clen, s);
+#ifdef TRC_ENC_PROF
+    {
+        static int calls = 0;
+        if (++calls % 64 == 0) {
+            static unsigned long long wl[4 * 4096];
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpyFromSymbol(wl, HIP_SYMBOL(trc_enc_wall), sizeof wl);
+            const unsigned nw = nwaves < 4096u ? nwaves : 4096u;
+            unsigned long long t0 = ~0ull;
+            for (unsigned i = 0; i < nw; i++) if (wl[4 * i] && wl[4 * i] < t0) t0 = wl[4 * i];
+            double s1[3] = { 0, 0, 0 }, s2[3] = { 0, 0, 0 }, s3[3] = { 0, 0, 0 }, mx[3] = { 0, 0, 0 }; unsigned cnt[3] = { 0, 0, 0 }; double smax = 0;
+            for (unsigned i = 0; i < nw; i++) {
+                const unsigned age = wpb >= 12 ? (i % wpb) / 4u : 0; if (age > 2 || !wl[4 * i]) continue;
+                const double a = (wl[4 * i] - t0) * 0.01, b = (wl[4 * i + 1] - t0) * 0.01, c2 = (wl[4 * i + 2] - t0) * 0.01, d = (wl[4 * i + 3] - t0) * 0.01;
+                s1[age] += b; s2[age] += c2; s3[age] += d; cnt[age]++; if (d > mx[age]) mx[age] = d; if (a > smax) smax = a;
+            }
+            fprintf(stderr, "[enc wall, us since the first wave's start] wpb %u, last start %.2f; by age on the SIMD: loop starts / loop ends / wave ends (mean; max end):", wpb, smax);
+            for (int a = 0; a < 3; a++) if (cnt[a]) fprintf(stderr, "  %.1f / %.1f / %.1f; %.1f", s1[a] / cnt[a], s2[a] / cnt[a], s3[a] / cnt[a], mx[a]);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
 }
 
 void trc_launch_ans4s_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,

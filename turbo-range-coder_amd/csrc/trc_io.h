@@ -286,7 +286,11 @@ struct QuadOut {
 // QUAD = true (round 4, the four-lanes-per-chunk rANS coding pass): lanes 4i .. 4i + 3 work on chunk c0 + i and share ONE ring
 // (row i) and one stream; wpos / nfl are kept equal across the quad by the caller, every lane writes its own units at
 // positions it computes itself (put16_at), the quad's first lane is the one that drains.
-template <bool DOWN, bool PAIR = false, bool QUAD = false>
+// WT (round 5): the drain's 64-byte stores go out write-through at agent scope (`global_store_dwordx4 ... sc1`) instead of staying
+// dirty in the L2: the kernel's end no longer writes back up to 32 MB of dirty lines at once (static rANS encoder 55.0 -> 53.2 us,
+// rocprofv3; the gather behind it unchanged at 29.8 -- unlike the nontemporal hint, which took the staged payload out of the L2 and
+// cost the gather 9 us).  Only for coders that never store into a drained segment again (no length header written afterwards).
+template <bool DOWN, bool PAIR = false, bool QUAD = false, bool WT = false>
 struct StreamOut {
     u8 *rings;           // this wave's ring array (LDS)
     u8 *scratch;         // global scratch, region of chunk c is [c*stride, (c+1)*stride)
@@ -382,7 +386,12 @@ struct StreamOut {
                 const u32 s0 = *(const lds_u32 *)(uintptr_t)a, s1 = *(const lds_u32 *)(uintptr_t)(a + 4u);
                 const u32 s2 = *(const lds_u32 *)(uintptr_t)(a + 8u), s3 = *(const lds_u32 *)(uintptr_t)(a + 12u);
                 u8 *base = (PAIR && (to_q & 1u)) ? scratch_b + (size_t)c0 * stride_b : scratch + (size_t)c0 * stride;
-                *(uint4 *)(base + (to_q & ~1u) + part) = make_uint4(s0, s1, s2, s3);
+if constexpr (WT) {                                // (an asm store is not in the compiler's vmcnt books: nothing in these kernels reads it back)
+                    const trc_v4u vv = { s0, s1, s2, s3 };
+                    u8 *pp = base + (to_q & ~1u) + part;
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(pp), "v"(vv) : "memory");
+                } else
+                    *(uint4 *)(base + (to_q & ~1u) + part) = make_uint4(s0, s1, s2, s3);
             }
             if (pick) { nfl++; ready = final ? (wpos > TRC_SEG * nfl) : pending() >= TRC_SEG; }
             mask = __ballot(ready);

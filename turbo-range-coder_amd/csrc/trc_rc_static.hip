@@ -53,7 +53,7 @@ __global__ __launch_bounds__(64 * WPB) void trc_rcs_enc_kernel(
     const int lim = trc_rc_limit(len);
 
     QuadIn tin; tin.base = in + (u64)wc.c0 * chunk;
-    StreamOut<false> so0, so1;
+    StreamOut<false, false, false, NS == 1> so0, so1;          // (one stream: no length header stored behind the drains -> write-through, trc_io.h)
     so0.rings = wbase;
     so0.scratch = scrA; so0.stride = strideA; so0.c0 = wc.c0; so0.wpos = (NS == 2) ? 4u : 0u; so0.nfl = 0;
     so1 = so0;
