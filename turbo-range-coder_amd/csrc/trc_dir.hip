@@ -193,7 +193,8 @@ __global__ __launch_bounds__(256) void trc_gather_kernel(const u8 *__restrict__ 
                 if (!ok[j]) continue;
                 const u32 sp = e1 - d[j];                       // bytes of this vector inside piece k (>= 16: all)
                 // (write-through stores here -- what took 2 us off the encoders' tails, StreamOut<.., WT> -- cost the gather 11 us:
-                // 29.9 -> 41.0, profiles/r05_notes.md; its stores stay plain)
+                // 29.9 -> 41.0; the nontemporal hint 29.8 -> 39.4 and the decoder behind it 60.4 -> 69.5, profiles/r05_notes.md; its
+                // stores stay plain)
                 if (sp >= 16u) { *(uint4 *)(dst0 + d[j]) = a[j]; continue; }
                 if (d[j] + 16u <= e2) {
                     const u32 aw[4] = { a[j].x, a[j].y, a[j].z, a[j].w }, bw[4] = { b[j].x, b[j].y, b[j].z, b[j].w };
