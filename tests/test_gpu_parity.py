@@ -387,12 +387,14 @@ def test_round5_workgroup_shapes(torch_cuda):
         sys.path[:0] = [%r, %r]
         import trc, trc_testlib as T
         from golden.make_golden import gen
-        for codec in (trc.ANS4S, trc.RCS1, trc.RCS2, trc.RCSM, trc.ANSA, trc.ANSB, trc.ANSO1):
+        for codec in (trc.ANS4S, trc.RCS1, trc.RCS2, trc.RCSM, trc.ANSA, trc.ANSB, trc.ANSO1, trc.RCA4, trc.RCAI4, trc.ANSA4):
             for kind, n, chunk in (("text", 300001, 512), ("runs", 64 * 1024 * 13 + 5, 1024), ("uniform", 40000, 256), ("zipf", 270001, 4096), ("text", 701, 256),
                                    ("text", 64 * 256 * 25 + 77, 256)):
                 if codec == trc.ANSO1 and chunk < 1024:
                     continue
                 d = gen(kind, n, 8)
+                if codec in trc.NIBBLE_CODECS:
+                    d = d & 15
                 _, cdf, cdfnum = T.orc_cdfini(d)
                 dc = trc.DeviceCoder(codec, n, chunk, "cuda:0")
                 if codec in trc.STATIC:
@@ -408,8 +410,8 @@ def test_round5_workgroup_shapes(torch_cuda):
                 assert np.array_equal(o[:n], d) and (o[n:] == 0xA5).all(), (trc.CODEC_NAMES[codec], kind, n, chunk)
         print("ok")
     """) % (os.path.dirname(os.path.abspath(trc.__file__)), os.path.dirname(os.path.abspath(__file__)))
-    forms = (dict(TRC_ENC_WPB="12", TRC_RCS_ENC_WPB="12", TRC_CODEQ_GPW="4", TRC_O1_ROWS="16"),             # the large shapes, on small inputs
-             dict(TRC_ENC_WPB="4", TRC_RCS_ENC_WPB="1", TRC_CODEQ_GPW="1", TRC_O1_ROWS="64"),               # the small shapes
+    forms = (dict(TRC_ENC_WPB="12", TRC_RCS_ENC_WPB="12", TRC_CODEQ_GPW="4", TRC_O1_ROWS="16", TRC_NIB_BIG="1"),    # the large shapes, on small inputs
+             dict(TRC_ENC_WPB="4", TRC_RCS_ENC_WPB="1", TRC_CODEQ_GPW="1", TRC_O1_ROWS="64", TRC_NIB_BIG="0"),      # the small shapes
              dict(TRC_O1_ROWS="8"))
     for env in forms:
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))

@@ -55,7 +55,7 @@ __device__ __forceinline__ WaveChunks ansa_record_space_planar(const WaveChunks 
 
 // ------------------------------------------------------------------------------ encode, pass 1 ---
 template <bool NIB>
-__global__ __launch_bounds__(64 * TRC_WPG) void trc_ansa_model_kernel(
+__global__ __launch_bounds__(64 * (NIB ? TRC_NIB_WPG : TRC_WPG)) void trc_ansa_model_kernel(
     const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ recs)
 {
     TRC_QUAD_PROLOGUE(ANSA_MODEL_LDS(NIB));
@@ -76,6 +76,7 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_ansa_model_kernel(
     const u32 S = chunk / TRC_SEG;
     qin.issue(wc, 0);
     for (u32 s = 0; s < S; s++) {
+        TRC_PACE_STEP(s + 1u);
         qin.commit();
         if (s + 1 < S) qin.issue(wc, (s + 1) * TRC_SEG);
         uint4 pc0 = qin.read(0), pc1 = qin.read(1), pc2 = qin.read(2), pc3 = qin.read(3);
@@ -526,6 +527,7 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_ansa_dec_kernel(
     u8 *dst = out + (u64)c * chunk;
     const u32 S = chunk / TRC_SEG;
     for (u32 s = 0; s < S; s++) {
+        TRC_PACE_STEP(s + 1u);
         uint4 pc0 = make_uint4(0, 0, 0, 0), pc1 = pc0, pc2 = pc0, pc3 = pc0;
 #pragma nounroll
         for (u32 k = 0; k < 4; k++) {
@@ -727,8 +729,13 @@ static void launch_ansa_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const
         trc_launch_ansa_code_planar(n, chunk, w, d_clen, s);
         return;
     }
-    TRC_RAISE_LDS_ONCE((trc_ansa_model_kernel<NIB>), TRC_WPG * ANSA_MODEL_LDS(NIB));
+    if (NIB && trc_nib_big(w.ngroups)) {                       // one 12-wave workgroup per CU, pace-keeping (trc_dev.h)
+        TRC_RAISE_LDS_ONCE((trc_ansa_model_kernel<NIB>), TRC_LDS_ONE_PER_CU);
+        TRC_LAUNCH_TIMED((trc_ansa_model_kernel<NIB>), dim3((w.ngroups + TRC_NIB_WPG - 1u) / TRC_NIB_WPG), dim3(64 * TRC_NIB_WPG), TRC_LDS_ONE_PER_CU, s, d_in, (u64)n, chunk, w.nchunks, w.scratch2);
+    } else {
+    TRC_RAISE_LDS_ONCE((trc_ansa_model_kernel<NIB>), NIB ? TRC_LDS_ONE_PER_CU : TRC_WPG * ANSA_MODEL_LDS(NIB));   // (one limit for both shapes of the nibble form: the attribute is set once per call site)
     TRC_LAUNCH_TIMED((trc_ansa_model_kernel<NIB>), TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (ANSA_MODEL_LDS(NIB)), s, d_in, (u64)n, chunk, w.nchunks, w.scratch2);
+    }
     TRC_LAUNCH_TIMED((trc_ansa_code_kernel<NIB>), TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (ANSA_CODE_LDS), s,
                        (const u8 *)w.scratch2, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
 }
@@ -748,6 +755,8 @@ static void launch_ansa_dec(const uint8_t *d_payload, const uint32_t *d_clen, si
                            d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, d_out);
         return;
     }
+    // (the nibble decoder in the 12-wave shape with TrcPace -- what the nibble range coders gained 8-10 % from -- measured 0.244 -> 0.322 ms:
+    // not taken, profiles/r05q_ab.txt)
     TRC_RAISE_LDS_ONCE((trc_ansa_dec_kernel<NIB>), TRC_WPG * ANSA_MODEL_LDS(NIB));
     TRC_LAUNCH_TIMED((trc_ansa_dec_kernel<NIB>), TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (ANSA_MODEL_LDS(NIB)), s,
                        d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, d_out);

@@ -138,13 +138,21 @@ __device__ __forceinline__ u32 trc_lane() { return threadIdx.x & 63u; }
 #define TRC_WPG 4u
 #define TRC_QUAD_GRID(ngroups) dim3(((ngroups) + TRC_WPG - 1u) / TRC_WPG)
 // kernel prologue: this wave's 64-chunk group `grp_`, its LDS slice `smem`, `lane`; waves without a group leave at once
+// Round 5: the workgroup may also be LARGER than TRC_WPG waves (the nibble coders in a one-round launch: twelve waves, so that the
+// waves of a SIMD sit in one workgroup and keep each other's pace: TrcPace below; the launch then asks for 64 bytes behind the
+// waves' slices) -- the prologue takes the shape from blockDim; TRC_PACE_STEP(p) at a wave-uniform point of the main loop.
 #define TRC_QUAD_PROLOGUE(WAVE_LDS_BYTES)                                                               \
     extern __shared__ __attribute__((aligned(16))) u8 smem_wg_[];                                      \
     const u32 wv_ = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));                      \
-    const u32 grp_ = blockIdx.x * TRC_WPG + wv_;                                                        \
+    const u32 wpg_ = blockDim.x >> 6;                                                                   \
+    TrcPace pace_;                                                                                      \
+    if (wpg_ > TRC_WPG) { pace_.init(trc_lds_addr(smem_wg_) + wpg_ * (u32)(WAVE_LDS_BYTES), threadIdx.x, wv_); __syncthreads(); } \
+    const u32 grp_ = blockIdx.x * wpg_ + wv_;                                                           \
     if (grp_ >= (nchunks + 63u) / 64u) return;                                                          \
     u8 *const smem = smem_wg_ + wv_ * (u32)(WAVE_LDS_BYTES);                                            \
     const u32 lane = trc_lane()
+#define TRC_PACE_STEP(p) do { if (wpg_ > TRC_WPG) pace_.step(p); } while (0)
+#define TRC_NIB_WPG 12u                                        // the nibble coders' large workgroup
 // orders a wave's own LDS stores before its later loads of what OTHER lanes stored (the hardware executes a wave's LDS
 // instructions in order; this keeps the compiler from moving them)
 __device__ __forceinline__ void trc_wave_lds_fence()

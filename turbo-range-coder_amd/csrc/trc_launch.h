@@ -4,6 +4,7 @@
 #include <hip/hip_ext.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 // Optional timing of the coder kernels of a call: while the API layer has timing armed for the calling thread, every
 // coder launch of the call (both passes of the two-pass rANS encoders, the order-1 model fill) carries its own event
@@ -31,6 +32,13 @@ bool trc_first_use_on_device(unsigned long long *mask);
 // a dynamic-LDS request above half of a CU's 160 KiB: at most one such workgroup per CU (the large workgroups whose waves keep each
 // other's pace, TrcPace: their waves are meant to be the only ones on their SIMDs)
 #define TRC_LDS_ONE_PER_CU (82u * 1024u)
+// the nibble coders (48-byte model rows: many waves per CU) take the large workgroup shape when the launch is one residency round of
+// twelve waves per CU (TRC_NIB_WPG, trc_dev.h); TRC_NIB_BIG=0 / 1 forces the shape (tuning aid, tests)
+static inline bool trc_nib_big(uint32_t ngroups)
+{
+    static const int env = getenv("TRC_NIB_BIG") ? atoi(getenv("TRC_NIB_BIG")) : -1;
+    return env >= 0 ? env != 0 : (ngroups >= 2048u && ngroups <= 12u * 256u);
+}
 
 // Workspace carve-up shared by encode and decode (all offsets 256-byte aligned).
 struct TrcWork {

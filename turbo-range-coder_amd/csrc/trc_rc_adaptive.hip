@@ -31,7 +31,7 @@
 #define RCA_WAVE_LDS(NIB) ((NIB) ? TRC_NIB1_BYTES : TRC_NIB_BYTES)
 
 template <int NS, bool NIB>
-__global__ __launch_bounds__(64 * TRC_WPG) void trc_rca_enc_kernel(
+__global__ __launch_bounds__(64 * (NIB ? TRC_NIB_WPG : TRC_WPG)) void trc_rca_enc_kernel(
     const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks,
     u8 *__restrict__ scratch, u32 stride, u8 *__restrict__ scratch2, u32 stride2,
     u32 *__restrict__ clen, u32 *__restrict__ gsum)
@@ -60,6 +60,7 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_rca_enc_kernel(
     const u32 S = chunk / TRC_SEG;
     qin.issue(wc, 0);
     for (u32 s = 0; s < S; s++) {
+        TRC_PACE_STEP(s + 1u);
         qin.commit();
         if (s + 1 < S) qin.issue(wc, (s + 1) * TRC_SEG);
         uint4 pc0 = qin.read(0), pc1 = qin.read(1), pc2 = qin.read(2), pc3 = qin.read(3);
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(192 * TRC_WPG) void trc_rca_enc_mc_kernel(
 }
 
 template <int NS, bool NIB>
-__global__ __launch_bounds__(64 * TRC_WPG) void trc_rca_dec_kernel(
+__global__ __launch_bounds__(64 * (NIB ? TRC_NIB_WPG : TRC_WPG)) void trc_rca_dec_kernel(
     const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
     u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ out)
 {
@@ -378,6 +379,7 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_rca_dec_kernel(
     u8 *dst = out + (u64)c * chunk;
     const u32 S = chunk / TRC_SEG;
     for (u32 s = 0; s < S; s++) {
+        TRC_PACE_STEP(s + 1u);
         uint4 pc0 = make_uint4(0, 0, 0, 0), pc1 = pc0, pc2 = pc0, pc3 = pc0;
 #pragma nounroll
         for (u32 k = 0; k < 4; k++) {
@@ -614,7 +616,13 @@ __global__ __launch_bounds__(128 * TRC_WPG) void trc_rca_dec_mc_kernel(
 template <int NS, bool NIB>
 static void launch_rca_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
 {
-    TRC_RAISE_LDS_ONCE((trc_rca_enc_kernel<NS, NIB>), TRC_WPG * RCA_WAVE_LDS(NIB));
+    if (NIB && trc_nib_big(w.ngroups)) {                       // one 12-wave workgroup per CU, pace-keeping (trc_dev.h)
+        TRC_RAISE_LDS_ONCE((trc_rca_enc_kernel<NS, NIB>), TRC_LDS_ONE_PER_CU);
+        TRC_LAUNCH_TIMED((trc_rca_enc_kernel<NS, NIB>), dim3((w.ngroups + TRC_NIB_WPG - 1u) / TRC_NIB_WPG), dim3(64 * TRC_NIB_WPG), TRC_LDS_ONE_PER_CU, s,
+                           d_in, (u64)n, chunk, w.nchunks, w.scratch, w.stride, w.scratch2, w.stride2, d_clen, w.gsum);
+        return;
+    }
+    TRC_RAISE_LDS_ONCE((trc_rca_enc_kernel<NS, NIB>), NIB ? TRC_LDS_ONE_PER_CU : TRC_WPG * RCA_WAVE_LDS(NIB));   // (one limit for both shapes of the nibble form: the attribute is set once per call site)
     TRC_LAUNCH_TIMED((trc_rca_enc_kernel<NS, NIB>), TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (RCA_WAVE_LDS(NIB)), s,
                        d_in, (u64)n, chunk, w.nchunks, w.scratch, w.stride, w.scratch2, w.stride2, d_clen, w.gsum);
 }
@@ -622,7 +630,13 @@ template <int NS, bool NIB>
 static void launch_rca_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                            const TrcWork &w, uint8_t *d_out, hipStream_t s)
 {
-    TRC_RAISE_LDS_ONCE((trc_rca_dec_kernel<NS, NIB>), TRC_WPG * RCA_WAVE_LDS(NIB));
+    if (NIB && trc_nib_big(w.ngroups)) {
+        TRC_RAISE_LDS_ONCE((trc_rca_dec_kernel<NS, NIB>), TRC_LDS_ONE_PER_CU);
+        TRC_LAUNCH_TIMED((trc_rca_dec_kernel<NS, NIB>), dim3((w.ngroups + TRC_NIB_WPG - 1u) / TRC_NIB_WPG), dim3(64 * TRC_NIB_WPG), TRC_LDS_ONE_PER_CU, s,
+                           d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, d_out);
+        return;
+    }
+    TRC_RAISE_LDS_ONCE((trc_rca_dec_kernel<NS, NIB>), NIB ? TRC_LDS_ONE_PER_CU : TRC_WPG * RCA_WAVE_LDS(NIB));   // (one limit for both shapes of the nibble form: the attribute is set once per call site)
     TRC_LAUNCH_TIMED((trc_rca_dec_kernel<NS, NIB>), TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (RCA_WAVE_LDS(NIB)), s,
                        d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, d_out);
 }
