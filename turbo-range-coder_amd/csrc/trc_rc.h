@@ -220,6 +220,39 @@ struct RcDec {
         t = dn ? t - 1u : up ? t + 1u : t;
         return t > TRC_PROB_ONE - 1 ? TRC_PROB_ONE - 1 : t;              // corrupt input: stay inside the table
     }
+    // Round 5: the static decoders do not need the exact quotient either -- only the SYMBOL it falls into, and whether a symbol is the
+    // right one can be read off the two products the state update needs anyway: x is the symbol iff r c0 <= code < r c1.  So: look the
+    // symbol up from the f32 ESTIMATE (within +-1 of the quotient: wrong symbol only when the estimate is off AND the true slot is a
+    // symbol's first or last), form rp = r c0, range2 = r (c1 - c0), code2 = code - rp, and accept if code >= rp and code2 < range2;
+    // where some lane of the wave fails (a few percent of the wave-steps) the wave repeats the step with the exact quotient.  The
+    // correction of quotient15 -- r * t on halves, two 64-bit compares, a 64-bit subtraction, three selects: a quarter of the step --
+    // is off the common path (static range decoders: profiles/r05_notes.md).
+    __device__ __forceinline__ u32 estimate15() const
+    {
+        const u32 rh = (u32)(range >> 32), ch = (u32)(code >> 32);
+        const u32 slo = __builtin_amdgcn_alignbit(rh, (u32)range, TRC_PROB_BITS), shi = rh >> TRC_PROB_BITS;
+        const float rf = __builtin_fmaf(trc_u2f(shi), 4294967296.0f, trc_u2f(slo));
+        const float cf = __builtin_fmaf(trc_u2f(ch), 4294967296.0f, trc_u2f((u32)code));
+        const u32 t = (u32)(cf * __builtin_amdgcn_rcpf(rf));
+        return t > TRC_PROB_ONE - 1 ? TRC_PROB_ONE - 1 : t;
+    }
+    struct Probe { u64 range2, code2; bool fits; };
+    __device__ __forceinline__ Probe probe(u32 c0, u32 c1) const
+    {
+        const u64 r = range >> TRC_PROB_BITS;
+        const u64 rp = r * c0;
+        Probe q;
+        q.range2 = r * (u32)(c1 - c0); q.code2 = code - rp;
+        q.fits = code >= rp && q.code2 < q.range2;
+        return q;
+    }
+    __device__ __forceinline__ bool commit(const Probe &q, u32 w)       // consume_w's second half
+    {
+        const bool rn = q.range2 < TRC_TOP32;
+        range = rn ? q.range2 << 32 : q.range2;
+        code = rn ? (q.code2 << 32) | w : q.code2;
+        return rn;
+    }
     // The adaptive decoders do not need the quotient itself, only the table entry it falls behind: with r = range >> 15,
     // floor(code / r) >= e  <=>  code >= r * e, so the reference's search over code / r (cdflget16, turborc_.h:172-190) is a
     // binary search with four 49 x 16-bit products instead of a division and four compares (r * e < 2^64: e <= 2^15).

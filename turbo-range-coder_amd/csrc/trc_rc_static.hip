@@ -21,6 +21,31 @@
 // the segment base, a relocated 0, to every index); the kernels trap at entry if the dynamic segment does not start at 0
 #define RCS_LUT(t) ((u32)*(const trc_lds_u8 *)(uintptr_t)(t))
 
+#ifndef TRC_RCS_EXACT_Q
+#define TRC_RCS_EXACT_Q 0       // 1: every step through the exact quotient (rounds 2-4)
+#endif
+// one symbol of the 64-bit static range decoder against the look-ahead word w: symbol from the estimated quotient, verified against
+// its own bounds (RcDec::probe); the exact quotient only where some lane of the wave fails.  Returns the symbol, `rn` = renormalised.
+__device__ __forceinline__ u32 rcs_step(RcDec &d, const u32 *tab, u32 w, bool &rn)
+{
+#if TRC_RCS_EXACT_Q
+    const u32 x = RCS_LUT(d.quotient15());
+    const u32 t = tab[x];
+    rn = d.consume_w(true, t & 0xffffu, (t & 0xffffu) + (t >> 16), w);
+    return x;
+#else
+    u32 x = RCS_LUT(d.estimate15());
+    u32 t = tab[x];
+    RcDec::Probe q = d.probe(t & 0xffffu, (t & 0xffffu) + (t >> 16));
+    if (__ballot(!q.fits)) {                                   // rare, wave-uniform (and every step of a corrupt stream: the exact quotient is clamped into the table)
+        x = RCS_LUT(d.quotient15());
+        t = tab[x];
+        q = d.probe(t & 0xffffu, (t & 0xffffu) + (t >> 16));
+    }
+    rn = d.commit(q, w);
+    return x;
+#endif
+}
 template <int GEO> struct RcGeo;
 template <> struct RcGeo<0> { typedef RcEncV Enc; typedef RcDec Dec; };      // (RcEncV: the state on 32-bit halves with a carry limb, trc_rc.h)
 template <> struct RcGeo<1> { typedef RcEncSm Enc; typedef RcDecSm Dec; };
@@ -218,12 +243,9 @@ __global__ __launch_bounds__(896) void trc_rcs_dec_kernel(
     auto get2 = [&](Dec &d, StreamIn &si, u32 &xa, u32 &xb) {
         if constexpr (GEO == 0) {
             const u32 w = si.peek32();
-            xa = RCS_LUT(d.quotient15());
-            const u32 ta = tab[xa];
-            const bool ra = d.consume_w(true, ta & 0xffffu, (ta & 0xffffu) + (ta >> 16), w);
-            xb = RCS_LUT(d.quotient15());
-            const u32 tb = tab[xb];
-            const bool rb = d.consume_w(true, tb & 0xffffu, (tb & 0xffffu) + (tb >> 16), w);
+            bool ra, rb;
+            xa = rcs_step(d, tab, w, ra);
+            xb = rcs_step(d, tab, w, rb);
             si.skip_if(ra || rb);
         } else { xa = get(d, si); xb = get(d, si); }
     };
@@ -445,12 +467,9 @@ __global__ __launch_bounds__(896) void trc_rcs2p_dec_kernel(
                     if (full) {
                         // two symbols of one stream: at most one of them renormalises (trc_rc.h RcEncD), one look-ahead word
                         const u32 w = si.peek32();
-                        const u32 xa = RCS_LUT(d.quotient15());
-                        const u32 ta = tab[xa];
-                        const bool ra = d.consume_w(true, ta & 0xffffu, (ta & 0xffffu) + (ta >> 16), w);
-                        const u32 xb = RCS_LUT(d.quotient15());
-                        const u32 tb = tab[xb];
-                        const bool rb = d.consume_w(true, tb & 0xffffu, (tb & 0xffffu) + (tb >> 16), w);
+                        bool ra, rb;
+                        const u32 xa = rcs_step(d, tab, w, ra);
+                        const u32 xb = rcs_step(d, tab, w, rb);
                         si.skip_if(ra || rb);
                         m = (xa | (xb << 16)) << (8u * b);
                     }
