@@ -358,6 +358,28 @@ struct RcDecSm {
         if ((u64)code - p >= range) t++;
         return t > TRC_PROB_ONE - 1 ? TRC_PROB_ONE - 1 : t;
     }
+    // round 5, as RcDec::estimate15 / probe: the symbol from the ESTIMATED quotient, accepted where code lies inside its bounds (the
+    // two products the update needs anyway); slot_exact() only where some lane of the wave fails -- which includes every step whose
+    // true quotient is 2^15 or more (range >> 15 truncates): no symbol's bounds hold such a code, the exact path clamps.
+    __device__ __forceinline__ void scale() { range >>= TRC_PROB_BITS; }
+    __device__ __forceinline__ u32 slot_estimate() const
+    {
+        const u32 t = (u32)((float)code * __builtin_amdgcn_rcpf((float)range));
+        return t > TRC_PROB_ONE - 1 ? TRC_PROB_ONE - 1 : t;
+    }
+    __device__ __forceinline__ u32 slot_exact() const                   // (range already scaled)
+    {
+        u32 t = (u32)((float)code * __builtin_amdgcn_rcpf((float)range));
+        u64 p = (u64)t * range;
+        if (p > code) { t--; p -= range; }
+        if ((u64)code - p >= range) t++;
+        return t > TRC_PROB_ONE - 1 ? TRC_PROB_ONE - 1 : t;
+    }
+    __device__ __forceinline__ bool fits(u32 c0, u32 c1) const
+    {
+        const u64 rp = (u64)range * c0, top = (u64)range * c1;           // (range < 2^17, c <= 2^15: the products may reach 2^32)
+        return code >= rp && code < top;
+    }
     template <class SI>
     __device__ __forceinline__ void consume(SI &si, u32 c0, u32 c1)
     {
