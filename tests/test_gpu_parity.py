@@ -698,6 +698,47 @@ def test_bench_config_total_parity(torch_cuda, cfg):
     assert torch.equal(d_out[:n], d_in[:n]), "round trip failed"
 
 
+@pytest.mark.parametrize("name", ["rcs-text100m-1536", "anscdf-drift100m-1536"])
+def test_model_coders_next_to_another_coder_on_a_second_stream(torch_cuda, name):
+    """the hand-written carry chains of `rcs` / `anscdf` were only ever exercised with their kernel alone on the
+    device (one wave per SIMD).  Here the coder encodes and decodes its 100 MB bench configuration on one stream while a second stream
+    keeps the static rANS coder (three waves per SIMD wherever it lands) and the bitwise rANS busy on the same device: every payload
+    must hash to the committed SHA-256 of the reference's per-chunk outputs, every decode must return the input."""
+    import hashlib
+    torch = torch_cuda
+    cfg = [c for c in T.BENCH_CONFIGS if c["name"] == name][0]
+    g = BENCH_GOLD[name]
+    n, chunk, codec = cfg["n"], cfg["chunk"], cfg["codec"]
+    d = T.bench_input(cfg["kind"], n, cfg["seed"])
+    d_in = to_dev(torch, d)
+    dc = trc.DeviceCoder(codec, n, chunk, "cuda:0")
+    d_out = torch.zeros(n + 512, dtype=torch.uint8, device="cuda:0")
+    # the neighbours: static rANS on 64 MB of text, bitwise rANS on 32 MB
+    nb = 64 * 10**6
+    t_in = to_dev(torch, gen("text", nb, 5))
+    _, cdf, cdfnum = T.orc_cdfini(t_in[:nb].cpu().numpy())
+    n1 = trc.DeviceCoder(trc.ANS4S, nb, 512, "cuda:0"); n1.set_cdf(cdf, cdfnum)
+    n2 = trc.DeviceCoder(trc.ANSB, nb // 2, 1536, "cuda:0")
+    t_out = torch.zeros(nb + 512, dtype=torch.uint8, device="cuda:0")
+    t_out2 = torch.zeros(nb // 2 + 512, dtype=torch.uint8, device="cuda:0")
+    side = torch.cuda.Stream(device="cuda:0")
+    torch.cuda.synchronize()
+    for rep in range(4):
+        with torch.cuda.stream(side):
+            for _ in range(12):
+                n1.encode(t_in, nb); n1.decode(t_out, nb, dir_ready=True)
+            n2.encode(t_in, nb // 2); n2.decode(t_out2, nb // 2, dir_ready=True)
+        dc.encode(d_in, n)
+        d_out.zero_()
+        dc.decode(d_out, n, dir_ready=True)
+        torch.cuda.synchronize()
+        clen, payload = dc.result(n)
+        assert hashlib.sha256(clen.astype("<u4").tobytes()).hexdigest() == g["clen_sha256"], "length directory differs from the reference (rep %d)" % rep
+        assert hashlib.sha256(payload.tobytes()).hexdigest() == g["payload_sha256"], "payload differs from the reference (rep %d)" % rep
+        assert torch.equal(d_out[:n], d_in[:n]), "round trip failed next to a busy second stream (rep %d)" % rep
+        assert torch.equal(t_out[:nb], t_in[:nb]) and torch.equal(t_out2[:nb // 2], t_in[:nb // 2]), "the neighbours' round trips failed"
+
+
 ALIASES = {
     trc.RCS1: [("rccdfsenc", d) for d in ("rccdfsldec", "rccdfsbdec", "rccdfsvldec", "rccdfsvbdec")],
     trc.RCS2: [("rccdfs2enc", "rccdfsl2dec"), ("rccdfs2enc", "rccdfsb2dec")],
