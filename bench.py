@@ -635,6 +635,10 @@ def main():
                         res["config"]["ratio_reference_whole_buffer"] = round(e["whole_buffer_bytes"] / n, 5)
                     if e["chunk"] == chunk:
                         res["payload_matches_reference_sha256"] = bool(e["payload_sha256"] == sha and e["clen_sha256"] == clen_sha)
+            if "payload_matches_reference_sha256" not in res:
+                res["golden"] = "no committed reference hash for this coder / workload / chunk (tests/golden/bench_configs.json)"
+        if kind == "drift":
+            res["config"]["workload_since"] = "round 4 (rounds 1-3 quoted these coders on bwt100m at chunk 512: --input bwt --chunk 512); chunk from trc_round_chunk since round 3"
         if world == 1 and default_metric and not args.no_beyond and inflight == 1:
             del d_out
             torch.cuda.empty_cache()

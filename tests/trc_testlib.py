@@ -402,6 +402,12 @@ BENCH_CONFIGS = [
     dict(name="rccdf-drift1g-whole", codec=RCA, kind="drift", seed=3, n=1000 * 1000 * 1000, chunk=None),
     dict(name="anscdf-drift1g-whole", codec=ANSA, kind="drift", seed=3, n=1000 * 1000 * 1000, chunk=None),
     dict(name="rcs-text1g-whole", codec=RCB, kind="text", seed=7, n=1000 * 1000 * 1000, chunk=None),
+    # the coders `bench.py --codec X` reports on without a committed hash so far, at the chunk trc_round_chunk gives them
+    dict(name="rccdfi-drift100m-1536", codec=RCAI, kind="drift", seed=3, n=100 * 1000 * 1000, chunk=1536),
+    dict(name="anscdf1-drift100m-4096", codec=ANSO1, kind="drift", seed=3, n=100 * 1000 * 1000, chunk=4096),
+    dict(name="ansb-text100m-1536", codec=ANSB, kind="text", seed=7, n=100 * 1000 * 1000, chunk=1536),
+    dict(name="rccdfs-text100m-512", codec=RCS1, kind="text", seed=7, n=100 * 1000 * 1000, chunk=512),
+    dict(name="rccdfsm-text100m-512", codec=RCSM, kind="text", seed=7, n=100 * 1000 * 1000, chunk=512),
 ]
 
 
