@@ -327,6 +327,323 @@ __global__ __launch_bounds__(128 * W) void trc_o1_model2_kernel(
     }
 }
 
+// ------------------------------------------------------------------- encode, pass 1 by CHAINS ---
+// End of round 5.  The model passes above are chains of table round trips because they walk a chunk in POSITION order, every byte
+// touching the table of its own context.  But the encoder knows the whole input: the record of a byte depends only on the state of
+// ITS table, i.e. on the earlier bytes of the chunk that used the same table, in order.  The 4352 tables of a chunk are independent
+// adaptive chains -- hi table c over the bytes that follow byte value c, lo table (c, h) over those whose hi nibble is h as well --
+// and a chain that starts from the initial table needs no model memory: its one table lives in the registers of the lane walking it.
+//   A  trc_o1_sort_kernel (a wave per chunk): a stable counting sort of the chunk's positions by table -- histogram by LDS atomics,
+//      one scan over the 4352 bins, then row by row (64 positions) the rank of a position among the lanes with the same key (the
+//      key's bits as ballots: deterministic, no atomics).  Writes the chunk's STREAM -- u32 entries `pos | nibble << 12`, every
+//      chain contiguous and starting on a multiple of four entries (a WINDOW, 16 bytes), hi chains first; HEAD on a chain's first
+//      entry, LAST on its last (what follows in that window is never read as an entry), a window of END marks behind the last
+//      chain -- for every 64 entries the offset of the first chain start among them (`seghead`), and for every position where its
+//      two records will lie in that order (`perm`).
+//   B  trc_o1_walk_kernel (a workgroup per group of 64 chunks): the unit of work is "the chains that START in entries
+//      [64 j, 64 j + 64) of chunk i", taken off an LDS counter (the units of the chunks' hi chains, the long ones, first); a lane
+//      walks from the unit's first chain start to the first chain start at or behind the unit's end -- bounds, adapt, record -- so
+//      every chain is walked by exactly one lane, whole, and nothing but the stream says where chains begin.  All lanes busy
+//      whatever the statistics; a long chain (drift100m: 16 hi chains per chunk, the longest 1400 entries on average) is one lane's
+//      business while the others take the units behind it.  The lanes advance in lockstep by windows: every step each lane asks
+//      for the next window of its stream (`global_load_lds_dwordx4` into a four-row ring, one request per step whoever asks, so that
+//      the counted `s_waitcnt vmcnt(1)` two steps later is exact), and the records of four steps go back IN PLACE of their entries
+//      as four 16-byte stores at once: a step is as long as its instructions, not as a memory round trip (with compiler-placed
+//      waits every entry load also waited for the previous record store: 6.6 ms for this kernel; profiles/r05_notes.md).
+//   C  trc_o1_place_kernel (a workgroup per chunk): the chunk's records in stream order through LDS into the planar record space
+//      (`perm`), which the coding pass reads as before (written straight to their positions by B they were 2 x 10^8 partial-line
+//      writes: 5.5 ms).
+// Everything lives where the chunk's order-1 model block would (w.model, 139264 B per chunk; 101 744 used at most).  Positions are
+// 12 bits: chunks up to 4096 bytes (what trc_round_chunk gives this coder); longer chunks take the kernels above.
+#define O1S_STREAM   0u                                         // u32[21248 + 4]: 2 x 4096 entries + at most 3 unused slots behind each of 4352 chains, + END
+#define O1S_PERM     85008u                                     // u32[4096]: position -> (stream index of its hi record | lo << 16)
+#define O1S_NH       101392u                                    // u16[176]: the first chain start at or behind entry 128 j (none: the stream's length)
+#define O1S_LEN      101744u                                    // u32: entries of the stream (a multiple of 4)
+#define O1S_BIG      101760u                                    // u32[16]: the chunk's long chains, length << 8 | unit (0: none)
+#define O1S_BIGMIN   256u
+#define O1S_SEGS     168u                                       // units of 128 entries
+#define O1S_NHN      176u
+#define O1S_HEAD     0x10000u
+#define O1S_LAST     0x20000u
+#define O1S_BINS     4352u
+#define O1S_MARKS    (4u * O1S_SEGS * 4u)                       // one bit per stream slot
+#define O1S_SORT_LDS (4096u + 16u + O1S_BINS * 2u + 2u * O1S_MARKS)          // the chunk's bytes, packed u16 bins, chain-start and chain-end bits
+__device__ __forceinline__ u32 o1s_up4(u32 v) { return (v + 3u) & ~3u; }
+__global__ __launch_bounds__(64) void trc_o1_sort_kernel(
+    const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ model)
+{
+    __shared__ __attribute__((aligned(16))) u8 smem_[O1S_SORT_LDS];
+    __shared__ u32 big_[17];                                    // [16]: how many
+    const u32 lane = threadIdx.x;
+    if (lane < 17u) big_[lane] = 0u;
+    u8 *const bytes = smem_;
+    u8 *const bins = bytes + 4112u;
+    u32 *const hbits = (u32 *)(bins + O1S_BINS * 2u), *const lbits = hbits + 4u * O1S_SEGS;
+    const u32 c = blockIdx.x;
+    const u32 lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
+    const u32 len = c == nchunks - 1u ? lastlen : chunk, plen = len + (len & 1u);
+    u8 *const blk = model + (u64)c * O1_MODEL_BYTES;
+    const u8 *src = in + (u64)c * chunk;
+    for (u32 off = lane * 16u; off < chunk; off += 1024u)
+        if (off < len) *(uint4 *)(bytes + off) = *(const uint4 *)(src + off);
+    for (u32 i = lane; i < (O1S_BINS * 2u + 2u * O1S_MARKS) / 16u; i += 64u) ((uint4 *)bins)[i] = make_uint4(0, 0, 0, 0);
+    trc_wave_lds_fence();
+    const u32 R = (plen + 63u) >> 6;
+    for (u32 r = 0; r < R; r++) {
+        const u32 pos = r * 64u + lane;
+        if (pos < plen) {
+            const u32 x = pos < len ? bytes[pos] : 0u, pv = pos ? bytes[pos - 1u] : 0u;
+            const u32 kh = pv, kl = 256u + (pv << 4) + (x >> 4);
+            atomicAdd((u32 *)(bins + (kh >> 1) * 4u), 1u << ((kh & 1u) * 16u));
+            atomicAdd((u32 *)(bins + (kl >> 1) * 4u), 1u << ((kl & 1u) * 16u));
+        }
+    }
+    trc_wave_lds_fence();
+    u32 *const ent = (u32 *)(blk + O1S_STREAM);
+    {                                                           // counts -> window-aligned starts (68 bins per lane); a non-empty bin marks its ends
+        u32 cw[34];
+#pragma unroll
+        for (int i = 0; i < 34; i++) cw[i] = ((const u32 *)(bins + lane * 136u))[i];
+        u32 tot = 0;
+#pragma unroll
+        for (int i = 0; i < 34; i++) tot += o1s_up4(cw[i] & 0xffffu) + o1s_up4(cw[i] >> 16);
+        const u32 incl = trc_wave_incl_scan(tot);
+        u32 start = incl - tot;
+#pragma unroll
+        for (int i = 0; i < 34; i++) {
+            const u32 a = cw[i] & 0xffffu, b = cw[i] >> 16;
+            const u32 sa = start, sb = start + o1s_up4(a);
+            if (a) { atomicOr(&hbits[sa >> 5], 1u << (sa & 31u)); atomicOr(&lbits[(sa + a - 1u) >> 5], 1u << ((sa + a - 1u) & 31u)); }
+            if (b) { atomicOr(&hbits[sb >> 5], 1u << (sb & 31u)); atomicOr(&lbits[(sb + b - 1u) >> 5], 1u << ((sb + b - 1u) & 31u)); }
+            if (a >= O1S_BIGMIN) { const u32 k = atomicAdd(&big_[16], 1u); if (k < 16u) big_[k] = a << 8 | sa >> 7; }
+            if (b >= O1S_BIGMIN) { const u32 k = atomicAdd(&big_[16], 1u); if (k < 16u) big_[k] = b << 8 | sb >> 7; }
+            start = sb + o1s_up4(b);
+            ((u32 *)(bins + lane * 136u))[i] = sa | sb << 16;
+        }
+        const u32 L = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        if (lane == 0u) *(u32 *)(blk + O1S_LEN) = L;
+        trc_wave_lds_fence();
+        if (lane < 16u) ((u32 *)(blk + O1S_BIG))[lane] = big_[lane];
+        // nh[j] = the first chain start at or behind entry 128 j: three units per lane, then a suffix minimum over the lanes
+        u32 f[3];
+#pragma unroll
+        for (u32 q = 0; q < 3u; q++) {
+            const u32 j = lane * 3u + q;
+            f[q] = L;
+            if (j < O1S_SEGS) {
+#pragma unroll
+                for (int v = 3; v >= 0; v--) { const u32 hb = hbits[4u * j + (u32)v]; if (hb) f[q] = j * 128u + 32u * (u32)v + (u32)__builtin_ctz(hb); }
+            }
+        }
+        f[1] = trc_min(f[1], f[2]); f[0] = trc_min(f[0], f[1]);
+        u32 m = f[0];                                           // suffix minimum of the lanes' own minima
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl_down((int)m, d, 64); if (lane + (u32)d < 64u) m = trc_min(m, o); }
+        const u32 above = (u32)__shfl_down((int)m, 1, 64);      // ... of the lanes above this one
+        const u32 up = lane < 63u ? above : L;
+        u16 *const nh = (u16 *)(blk + O1S_NH);
+        const u32 n2 = trc_min(f[2], up), n1 = trc_min(f[1], up), n0 = trc_min(f[0], up);
+        if (lane * 3u + 0u < O1S_NHN) nh[lane * 3u + 0u] = (u16)n0;
+        if (lane * 3u + 1u < O1S_NHN) nh[lane * 3u + 1u] = (u16)n1;
+        if (lane * 3u + 2u < O1S_NHN) nh[lane * 3u + 2u] = (u16)n2;
+    }
+    u32 *const perm = (u32 *)(blk + O1S_PERM);
+    for (u32 r = 0; r < R; r++) {
+        const u32 pos = r * 64u + lane;
+        const bool valid = pos < plen;
+        const u32 x = valid && pos < len ? bytes[pos] : 0u, pv = valid && pos ? bytes[pos - 1u] : 0u;
+        // lanes of this row with the same hi key / the same lo key as mine (the key's bits as ballots; lane order = position order)
+        u64 mh = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const u64 B = __ballot((pv >> b) & 1u);
+            mh &= ((pv >> b) & 1u) ? B : ~B;
+        }
+        u64 ml = mh;
+#pragma unroll
+        for (int b = 4; b < 8; b++) {
+            const u64 B = __ballot((x >> b) & 1u);
+            ml &= ((x >> b) & 1u) ? B : ~B;
+        }
+        if (valid) {
+            const u32 kh = pv, kl = 256u + (pv << 4) + (x >> 4);
+            u16 *const bh = (u16 *)(bins + kh * 2u), *const bl = (u16 *)(bins + kl * 2u);
+            const u32 sh = *bh, sl = *bl;
+            const u32 rh = __builtin_amdgcn_mbcnt_hi((u32)(mh >> 32), __builtin_amdgcn_mbcnt_lo((u32)mh, 0u));
+            const u32 rl = __builtin_amdgcn_mbcnt_hi((u32)(ml >> 32), __builtin_amdgcn_mbcnt_lo((u32)ml, 0u));
+            const u32 nh = (u32)__popcll(mh), nl = (u32)__popcll(ml);
+            const u32 ih = sh + rh, il = sl + rl;
+            ent[ih] = pos | (x >> 4) << 12 | ((hbits[ih >> 5] >> (ih & 31u)) & 1u) << 16 | ((lbits[ih >> 5] >> (ih & 31u)) & 1u) << 17;
+            ent[il] = pos | (x & 15u) << 12 | ((hbits[il >> 5] >> (il & 31u)) & 1u) << 16 | ((lbits[il >> 5] >> (il & 31u)) & 1u) << 17;
+            perm[pos] = ih | il << 16;
+            if (rh == nh - 1u) *bh = (u16)(sh + nh);           // the key's last lane moves the bin on (after every lane of the row has read it)
+            if (rl == nl - 1u) *bl = (u16)(sl + nl);
+        }
+    }
+}
+
+#ifndef O1W_WAVES
+#define O1W_WAVES    2u
+#endif
+#ifndef O1W_GROUP
+#define O1W_GROUP    32u                                        // chunks per workgroup
+#endif
+#define O1W_NH       (TRC_NIBK_BYTES + 16u)
+#define O1W_BIG      (O1W_NH + O1W_GROUP * O1S_NHN * 2u)        // u32[GROUP x 16] as read, then the same sorted by length
+#define O1W_TAKEN    (O1W_BIG + 2u * O1W_GROUP * 64u)           // one bit per unit: somebody walks it
+#define O1W_STAGE    (O1W_TAKEN + O1W_GROUP * 32u)
+#define O1W_LDS      (O1W_STAGE + O1W_WAVES * 8u * 1024u)
+__global__ __launch_bounds__(64 * O1W_WAVES) void trc_o1_walk_kernel(u32 nchunks, u8 *__restrict__ model)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem_wg_[];
+    u8 *const kb = smem_wg_;
+    u32 *const ctr = (u32 *)(smem_wg_ + TRC_NIBK_BYTES);
+    const u16 *const nh = (const u16 *)(smem_wg_ + O1W_NH);
+    u32 *const big = (u32 *)(smem_wg_ + O1W_BIG), *const bigs = big + O1W_GROUP * 16u;
+    u32 *const taken = (u32 *)(smem_wg_ + O1W_TAKEN);           // [chunk][8]
+    const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = trc_lane();
+    const u32 stage_a = (u32)__builtin_amdgcn_readfirstlane((int)trc_lds_addr(smem_wg_ + O1W_STAGE + wv * 8192u));
+    const u32 c0 = blockIdx.x * O1W_GROUP;
+    const u32 rows = nchunks - c0 < O1W_GROUP ? nchunks - c0 : O1W_GROUP;
+    u8 *const gbase = model + (u64)c0 * O1_MODEL_BYTES;
+    if (threadIdx.x == 0u) ctr[0] = 0u;
+    for (u32 i = threadIdx.x; i < O1W_GROUP * O1S_NHN / 8u; i += 64u * O1W_WAVES) {       // the group's unit directory
+        const u32 ci = i / (O1S_NHN / 8u), q = i % (O1S_NHN / 8u);
+        ((uint4 *)(smem_wg_ + O1W_NH))[i] = ci < rows ? *(const uint4 *)(gbase + (size_t)ci * O1_MODEL_BYTES + O1S_NH + q * 16u)
+                                                      : make_uint4(0, 0, 0, 0);
+    }
+    for (u32 i = threadIdx.x; i < O1W_GROUP * 16u; i += 64u * O1W_WAVES) {                // its long chains: length << 16 | chunk << 8 | unit
+        const u32 ci = i >> 4;
+        const u32 v = ci < rows ? ((const u32 *)(gbase + (size_t)ci * O1_MODEL_BYTES + O1S_BIG))[i & 15u] : 0u;
+        big[i] = v ? (v >> 8) << 16 | ci << 8 | (v & 255u) : 0u;
+        bigs[i] = 0u;
+    }
+    for (u32 i = threadIdx.x; i < O1W_GROUP * 8u; i += 64u * O1W_WAVES) taken[i] = 0u;
+    o1_init_k(kb);                                              // (every wave writes the same K; ends with the barrier)
+    for (u32 i = threadIdx.x; i < O1W_GROUP * 16u; i += 64u * O1W_WAVES) {                // longest first: an item's rank is the number of items before it
+        const u32 v = big[i];
+        if (v) {
+            u32 rk = 0;
+            for (u32 k = 0; k < O1W_GROUP * 16u; k++) { const u32 o = big[k]; rk += (o > v || (o == v && k < i)) ? 1u : 0u; }
+            bigs[rk] = v;
+        }
+    }
+    __syncthreads();
+
+    const u32 nbig = O1W_GROUP * 16u, nunits = nbig + rows * O1S_SEGS;      // the long chains' units (zeros: none), then every unit
+    NibTable T = O1Cache::fresh();
+    bool active = false, done = false;
+    u32 widx = 0, uend = 0;                                     // the window to ask for next, the end of the unit
+    u8 *sbase = gbase;
+    uint4 rec[4];
+    u8 *recp[4], *reqp[4];                                      // where the records of the windows walked / asked for in this round go
+    bool recv[4], reqv[4];                                      // ... if anywhere (flags, not null pointers: the stores stay global_store)
+#pragma unroll
+    for (u32 w = 0; w < 4u; w++) { recp[w] = gbase; reqp[w] = gbase; recv[w] = false; reqv[w] = false; rec[w] = make_uint4(0, 0, 0, 0); }
+    u32 buf = 0;
+    bool more = true;
+    while (more) {
+        // A round = four windows per lane.  Everything asked for a round ago -- the windows of this round, the record stores of the
+        // last -- is a round old here: the one wait of the loop finds it done.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        {   // The four windows of a lane are usually 64 consecutive bytes.  Stored lane by lane they are 16-byte pieces of 64 different
+            // lines per instruction, and a piece costs the memory system what a whole sector does (this kernel: 1.43 ms, 0.99 without
+            // its stores).  Transposed across the quad -- records AND addresses -- instruction j has the quad's four lanes write the
+            // four windows of lane 4i + j: one 64-byte request where they are consecutive, still right where they are not.
+            u32 m[4][4], ad[4][4];
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                m[w][0] = rec[w].x; m[w][1] = rec[w].y; m[w][2] = rec[w].z; m[w][3] = rec[w].w;
+                ad[w][0] = (u32)(uintptr_t)recp[w]; ad[w][1] = (u32)((uintptr_t)recp[w] >> 32); ad[w][2] = recv[w] ? 1u : 0u; ad[w][3] = 0u;
+            }
+            trc_quad_transpose(m); trc_quad_transpose(ad);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (ad[j][2]) trc_gst128((void *)((uintptr_t)ad[j][1] << 32 | ad[j][0]), make_uint4(m[j][0], m[j][1], m[j][2], m[j][3]));
+        }
+#pragma unroll
+        for (u32 w = 0; w < 4u; w++) { recp[w] = reqp[w]; recv[w] = reqv[w]; }
+        const u32 rd = stage_a + buf * 4096u, wr = stage_a + (buf ^ 1u) * 4096u;
+        buf ^= 1u;
+#pragma unroll
+        for (u32 w = 0; w < 4u; w++) {                          // ask for the next round's windows
+            if (active && widx >= uend) active = false;
+            if (!active && !done) {                             // take the next unit
+                const u32 g = atomicAdd(&ctr[0], 1u);
+                if (g >= nunits) done = true;
+                else {
+                    const u32 it = g < nbig ? bigs[g] : 0u, h = g - nbig;
+                    const u32 ci = g < nbig ? (it >> 8) & 255u : h / O1S_SEGS, j = g < nbig ? it & 255u : h % O1S_SEGS;
+                    const u32 us = nh[ci * O1S_NHN + j], ue = nh[ci * O1S_NHN + j + 1u];
+                    const bool mine = (g >= nbig || it != 0u) && us < j * 128u + 128u &&
+                                      !(atomicOr(&taken[ci * 8u + (j >> 5)], 1u << (j & 31u)) & (1u << (j & 31u)));
+                    if (mine) {                                 // a chain starts in this unit and nobody has it: walk from there to the first start behind the unit
+                        sbase = gbase + (size_t)ci * O1_MODEL_BYTES + O1S_STREAM;
+                        widx = us; uend = ue; active = true;
+                    }
+                }
+            }
+            // window k of a stream only in slot k mod 4 of a round: a lane's four windows of a round are then ONE 64-byte sector
+            // (a unit that starts elsewhere idles up to three slots first)
+            const bool go = active && ((widx >> 2) & 3u) == w;
+            u8 *const src = go ? sbase + (size_t)widx * 4u : gbase;
+            reqp[w] = src; reqv[w] = go;
+            const u32 row = (u32)__builtin_amdgcn_readfirstlane((int)(wr + w * 1024u));
+            u32 keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(row) : "memory");
+            if (go) widx += 4u;
+        }
+#pragma unroll
+        for (u32 w = 0; w < 4u; w++) {                          // walk this round's windows (asked for a round ago)
+            const uint4 W = trc_ldsr128(rd + w * 1024u + lane * 16u);
+            const u32 e[4] = { W.x, W.y, W.z, W.w };
+            u32 r[4];
+            if (e[0] & O1S_HEAD) T = O1Cache::fresh();          // (chains start on windows; behind a LAST entry the table is garbage until then: nobody reads it)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const u32 sym = (e[i] >> 12) & 15u;
+                u32 a0, a1;
+                o1_bounds(T, sym, a0, a1);
+                o1_adapt(T, kb, sym);
+                r[i] = (a0 << TRC_PROB_BITS) | (a1 - a0);
+            }
+            rec[w] = make_uint4(r[0], r[1], r[2], r[3]);
+        }
+        bool pend = !done || active;
+#pragma unroll
+        for (u32 w = 0; w < 4u; w++) pend = pend || recv[w] || reqv[w];
+        more = __ballot(pend) != 0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (the last round's requests write LDS: not behind the wave's end)
+}
+
+#define O1P_SLOTS    9216u
+__global__ __launch_bounds__(256) void trc_o1_place_kernel(u64 n, u32 chunk, u32 nchunks, const u8 *__restrict__ model, u8 *__restrict__ recs)
+{
+    __shared__ __attribute__((aligned(16))) u32 sr[O1P_SLOTS];
+    const u32 c = blockIdx.x, t = threadIdx.x;
+    const u32 lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
+    const u32 len = c == nchunks - 1u ? lastlen : chunk, plen = len + (len & 1u);
+    const u8 *blk = model + (u64)c * O1_MODEL_BYTES;
+    const u32 L = *(const u32 *)(blk + O1S_LEN);
+    const u32 *st = (const u32 *)(blk + O1S_STREAM);
+    const bool staged = L <= O1P_SLOTS;                         // (many short chains -- incompressible input -- leave more unused slots: gather from memory then)
+    if (staged) for (u32 i = t * 4u; i < L; i += 1024u) *(uint4 *)(sr + i) = *(const uint4 *)(st + i);
+    __syncthreads();
+    u8 *const rb = recs + (u64)c * (8u * (u64)chunk);
+    const u32 *perm = (const u32 *)(blk + O1S_PERM);
+    for (u32 p = t; p < plen; p += 256u) {
+        const u32 pm = perm[p];
+        u8 *dst = rb + (p >> 4) * 128u + (p & 15u) * 4u;
+        u32 rh, rl;
+        if (staged) { rh = sr[pm & 0xffffu]; rl = sr[pm >> 16]; }
+        else { rh = trc_gld32(st + (pm & 0xffffu)); rl = trc_gld32(st + (pm >> 16)); }
+        *(u32 *)dst = rh;
+        *(u32 *)(dst + 64u) = rl;
+    }
+}
+
 // ------------------------------------------------------------------------------------- decode ---
 // Round 5: R chunks per wave (lanes 0 .. R - 1; 64 / R waves per group of 64 chunks).  These kernels are chains of table round trips:
 // a wave makes one per nibble as long as ANY of its lanes needs a table it does not hold, so with 64 chunks per wave (some lane always
@@ -441,6 +758,13 @@ __global__ __launch_bounds__(64) void trc_o1_dec_kernel(
 // returns true when the records were written to the PLANAR record space (the caller then runs the planar coding pass)
 bool trc_launch_anso1_model(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, hipStream_t s)
 {
+    static const int chains = getenv("TRC_O1_CHAINS") ? atoi(getenv("TRC_O1_CHAINS")) : 1;   // 0: the position-order passes below
+    if (chains && chunk <= 4096u) {
+        TRC_LAUNCH_TIMED(trc_o1_sort_kernel, dim3(w.nchunks), dim3(64), 0, s, d_in, (u64)n, chunk, w.nchunks, w.model);
+        TRC_LAUNCH_TIMED(trc_o1_walk_kernel, dim3((w.nchunks + O1W_GROUP - 1u) / O1W_GROUP), dim3(64 * O1W_WAVES), O1W_LDS, s, w.nchunks, w.model);
+        TRC_LAUNCH_TIMED(trc_o1_place_kernel, dim3(w.nchunks), dim3(256), 0, s, (u64)n, chunk, w.nchunks, (const u8 *)w.model, w.scratch2);
+        return true;
+    }
     static const int two = getenv("TRC_O1_MC") ? atoi(getenv("TRC_O1_MC")) : 1;      // 0: the one-wave pass of rounds 1-3 (interleaved records)
     // ... up to 1024 pairs: beyond that (100 MB at chunk 1024: 1526) the unit is saturated by one wave per 64 chunks already and the
     // second wave only adds its own input loads and record stores (3.30 -> 3.93 ms); chunk 4096: 5.35 -> 3.80 ms, 2048: 3.39 -> 3.19

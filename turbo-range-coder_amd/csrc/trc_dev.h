@@ -74,6 +74,13 @@ typedef __attribute__((address_space(3))) trc_v4u trc_lds_v4u;
 __device__ __forceinline__ uint4 trc_ldsr128(u32 a) { const trc_v4u v = *(const trc_lds_v4u *)(uintptr_t)a; return make_uint4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ void trc_ldsw128(u32 a, uint4 q) { const trc_v4u v = { q.x, q.y, q.z, q.w }; *(trc_lds_v4u *)(uintptr_t)a = v; }
 
+// a 16-byte store through an address the compiler cannot trace back to a kernel argument (pointers carried in arrays across loop
+// rounds): said to be global here, or it becomes flat_store, which counts on lgkmcnt too and makes every LDS wait a memory wait
+typedef __attribute__((address_space(1))) trc_v4u trc_glb_v4u;
+__device__ __forceinline__ void trc_gst128(void *p, uint4 q) { const trc_v4u v = { q.x, q.y, q.z, q.w }; *(trc_glb_v4u *)(uintptr_t)p = v; }
+typedef __attribute__((address_space(1))) u32 trc_glb_u32;
+__device__ __forceinline__ u32 trc_gld32(const void *p) { return *(const trc_glb_u32 *)(uintptr_t)p; }
+
 // LDS-only workgroup barrier (the two-wave encoders: a model wave feeding a coder wave through an LDS queue).
 // __syncthreads() also waits for vmcnt(0), i.e. for the coder wave's word stores and the model wave's input loads in
 // flight -- a memory round trip per period that nothing there needs.
