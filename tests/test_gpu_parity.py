@@ -418,6 +418,50 @@ def test_round5_workgroup_shapes(torch_cuda):
         assert r.returncode == 0 and "ok" in r.stdout, (env, r.stdout[-2000:] + r.stderr[-3000:])
 
 
+def test_order1_model_pass_by_chains_and_by_position(torch_cuda):
+    """End of round 5: `anscdf1` has two model passes -- by CHAINS (csrc/trc_ans_o1.hip: the chunk's positions sorted by table, every
+    table's chain walked by one lane, the records placed back) for chunks up to 4096 bytes, and the position-order passes of rounds
+    1-4 for longer chunks or TRC_O1_CHAINS=0.  Both are forced, each in a process of its own (the switch is read once), on what
+    the chain pass has special cases for: incompressible bytes (thousands of one-entry chains: the stream outgrows the placement
+    kernel's LDS stage and is gathered from memory), one byte value (two chains as long as the chunk), two alternating values, text,
+    runs; odd lengths (the coded dummy), a lone byte, chunk sizes below 4096, several groups of 64 chunks with a short last one.
+    Per-chunk payloads equal the oracle's; the round trip returns the input."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np, torch
+        sys.path[:0] = [%r, %r]
+        import trc, trc_testlib as T
+        from golden.make_golden import gen
+        rng = np.random.default_rng(11)
+        def data(kind, n):
+            if kind == "random": return rng.integers(0, 256, n, dtype=np.uint8)
+            if kind == "const": return np.full(n, 0x41, np.uint8)
+            if kind == "alt": return np.where(np.arange(n) & 1, 0x10, 0xfe).astype(np.uint8)
+            if kind == "hi16": return (rng.integers(0, 16, n, dtype=np.uint8) << 4).astype(np.uint8)
+            return gen(kind, n, 9)
+        cases = [("random", 64 * 4096 * 2 + 4097, 4096), ("const", 4096 * 70, 4096), ("const", 4095, 4096), ("alt", 4096 * 3 + 1, 4096),
+                 ("hi16", 4096 * 5, 4096), ("text", 64 * 4096 + 1234, 4096), ("runs", 4096 * 130 + 7, 4096), ("zipf", 100001, 2048),
+                 ("random", 30001, 1024), ("text", 1, 4096), ("text", 2, 4096), ("random", 3, 1024), ("text", 1 << 20, 65536)]
+        for kind, n, chunk in cases:
+            d = data(kind, n)
+            dc = trc.DeviceCoder(trc.ANSO1, n, chunk, "cuda:0")
+            d_in = torch.from_numpy(np.concatenate([d, np.zeros(512, np.uint8)])).to("cuda:0")
+            for rep in range(2):                                  # twice: the second call finds the workspace as the first left it
+                dc.encode(d_in, n)
+                clen, payload = dc.result(n)
+                ep, ec, _ = T.orc_chunked_enc(trc.ANSO1, d, chunk, None, 256)
+                assert np.array_equal(clen, ec) and np.array_equal(payload, ep), (kind, n, chunk, rep)
+                out = torch.full((n + 512,), 0xA5, dtype=torch.uint8, device="cuda:0")
+                dc.decode(out, n, dir_ready=True); torch.cuda.synchronize()
+                o = out.cpu().numpy()
+                assert np.array_equal(o[:n], d) and (o[n:] == 0xA5).all(), (kind, n, chunk, rep)
+        print("ok")
+    """) % (os.path.dirname(os.path.abspath(trc.__file__)), os.path.dirname(os.path.abspath(__file__)))
+    for env in (dict(TRC_O1_CHAINS="1"), dict(TRC_O1_CHAINS="0")):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+        assert r.returncode == 0 and "ok" in r.stdout, (env, r.stdout[-2000:] + r.stderr[-3000:])
+
+
 def test_bounded_host_decoder(torch_cuda):
     """trc_decode_host: the decoder that is told how long its input really is.  A valid container round-trips; a truncated
     buffer, a header that claims more payload than the buffer holds and a directory that does not add up are REJECTED

@@ -337,25 +337,28 @@ __global__ __launch_bounds__(128 * W) void trc_o1_model2_kernel(
 //      one scan over the 4352 bins, then row by row (64 positions) the rank of a position among the lanes with the same key (the
 //      key's bits as ballots: deterministic, no atomics).  Writes the chunk's STREAM -- u32 entries `pos | nibble << 12`, every
 //      chain contiguous and starting on a multiple of four entries (a WINDOW, 16 bytes), hi chains first; HEAD on a chain's first
-//      entry, LAST on its last (what follows in that window is never read as an entry), a window of END marks behind the last
-//      chain -- for every 64 entries the offset of the first chain start among them (`seghead`), and for every position where its
-//      two records will lie in that order (`perm`).
-//   B  trc_o1_walk_kernel (a workgroup per group of 64 chunks): the unit of work is "the chains that START in entries
-//      [64 j, 64 j + 64) of chunk i", taken off an LDS counter (the units of the chunks' hi chains, the long ones, first); a lane
-//      walks from the unit's first chain start to the first chain start at or behind the unit's end -- bounds, adapt, record -- so
-//      every chain is walked by exactly one lane, whole, and nothing but the stream says where chains begin.  All lanes busy
-//      whatever the statistics; a long chain (drift100m: 16 hi chains per chunk, the longest 1400 entries on average) is one lane's
-//      business while the others take the units behind it.  The lanes advance in lockstep by windows: every step each lane asks
-//      for the next window of its stream (`global_load_lds_dwordx4` into a four-row ring, one request per step whoever asks, so that
-//      the counted `s_waitcnt vmcnt(1)` two steps later is exact), and the records of four steps go back IN PLACE of their entries
-//      as four 16-byte stores at once: a step is as long as its instructions, not as a memory round trip (with compiler-placed
-//      waits every entry load also waited for the previous record store: 6.6 ms for this kernel; profiles/r05_notes.md).
+//      entry (the up to three slots behind its last one hold whatever memory held: walked like entries, their records never read)
+//      -- for every 128 entries the first chain start at or behind them (`nh`), the chunk's long chains, and for every position
+//      where its two records will lie in that order (`perm`).
+//   B  trc_o1_walk_kernel (a workgroup per O1W_GROUP chunks): the unit of work is "the chains that START in entries
+//      [128 j, 128 j + 128) of chunk i", taken off an LDS counter -- first the units of the group's long chains, longest first (the
+//      tail of this kernel is its longest chain: drift100m has 16 hi chains per chunk, the longest 1400 entries on average, up to
+//      3400), then every unit nobody has taken.  A lane walks from the unit's first chain start to the first chain start behind
+//      the unit (both in `nh`: no lane ever looks at a slot another lane writes) -- bounds, adapt, record -- so every chain is
+//      walked by exactly one lane, whole.  All lanes busy whatever the statistics.  The lanes advance in lockstep, a ROUND = four
+//      windows per lane: at its top the next round's windows are asked for (`global_load_lds_dwordx4` into the other half of an
+//      eight-row ring, one request per slot whoever asks) and the last round's records go back IN PLACE of their entries; the one
+//      `s_waitcnt vmcnt(0)` of the loop then finds everything a round old.  With compiler-placed waits every entry load also waited
+//      for the previous record store (6.6 ms for this kernel).  The stores: a lane's four windows of a round are one 64-byte sector
+//      (window k of a stream only in slot k mod 4), and records and addresses are transposed across the quad so that one
+//      instruction's four lanes write one lane's sector -- as 16-byte pieces of 64 different lines they cost the memory system a
+//      sector each (1.43 ms, 0.99 without the stores; 1.09 so).  profiles/r05_notes.md.
 //   C  trc_o1_place_kernel (a workgroup per chunk): the chunk's records in stream order through LDS into the planar record space
-//      (`perm`), which the coding pass reads as before (written straight to their positions by B they were 2 x 10^8 partial-line
-//      writes: 5.5 ms).
-// Everything lives where the chunk's order-1 model block would (w.model, 139264 B per chunk; 101 744 used at most).  Positions are
+//      (`perm`), which the coding pass reads as before (written straight to their positions by B they were 2 x 10^8 four-byte
+//      writes scattered over 800 MB: 5.5 ms).
+// Everything lives where the chunk's order-1 model block would (w.model, 139264 B per chunk; 101 824 used at most).  Positions are
 // 12 bits: chunks up to 4096 bytes (what trc_round_chunk gives this coder); longer chunks take the kernels above.
-#define O1S_STREAM   0u                                         // u32[21248 + 4]: 2 x 4096 entries + at most 3 unused slots behind each of 4352 chains, + END
+#define O1S_STREAM   0u                                         // u32[21248 + 4]: 2 x 4096 entries + at most 3 unused slots behind each of 4352 chains
 #define O1S_PERM     85008u                                     // u32[4096]: position -> (stream index of its hi record | lo << 16)
 #define O1S_NH       101392u                                    // u16[176]: the first chain start at or behind entry 128 j (none: the stream's length)
 #define O1S_LEN      101744u                                    // u32: entries of the stream (a multiple of 4)
@@ -364,10 +367,9 @@ __global__ __launch_bounds__(128 * W) void trc_o1_model2_kernel(
 #define O1S_SEGS     168u                                       // units of 128 entries
 #define O1S_NHN      176u
 #define O1S_HEAD     0x10000u
-#define O1S_LAST     0x20000u
 #define O1S_BINS     4352u
 #define O1S_MARKS    (4u * O1S_SEGS * 4u)                       // one bit per stream slot
-#define O1S_SORT_LDS (4096u + 16u + O1S_BINS * 2u + 2u * O1S_MARKS)          // the chunk's bytes, packed u16 bins, chain-start and chain-end bits
+#define O1S_SORT_LDS (4096u + 16u + O1S_BINS * 2u + O1S_MARKS)               // the chunk's bytes, packed u16 bins, one bit per stream slot: a chain starts here
 __device__ __forceinline__ u32 o1s_up4(u32 v) { return (v + 3u) & ~3u; }
 __global__ __launch_bounds__(64) void trc_o1_sort_kernel(
     const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ model)
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(64) void trc_o1_sort_kernel(
     if (lane < 17u) big_[lane] = 0u;
     u8 *const bytes = smem_;
     u8 *const bins = bytes + 4112u;
-    u32 *const hbits = (u32 *)(bins + O1S_BINS * 2u), *const lbits = hbits + 4u * O1S_SEGS;
+    u32 *const hbits = (u32 *)(bins + O1S_BINS * 2u);
     const u32 c = blockIdx.x;
     const u32 lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
     const u32 len = c == nchunks - 1u ? lastlen : chunk, plen = len + (len & 1u);
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(64) void trc_o1_sort_kernel(
     const u8 *src = in + (u64)c * chunk;
     for (u32 off = lane * 16u; off < chunk; off += 1024u)
         if (off < len) *(uint4 *)(bytes + off) = *(const uint4 *)(src + off);
-    for (u32 i = lane; i < (O1S_BINS * 2u + 2u * O1S_MARKS) / 16u; i += 64u) ((uint4 *)bins)[i] = make_uint4(0, 0, 0, 0);
+    for (u32 i = lane; i < (O1S_BINS * 2u + O1S_MARKS) / 16u; i += 64u) ((uint4 *)bins)[i] = make_uint4(0, 0, 0, 0);
     trc_wave_lds_fence();
     const u32 R = (plen + 63u) >> 6;
     for (u32 r = 0; r < R; r++) {
@@ -413,8 +415,8 @@ __global__ __launch_bounds__(64) void trc_o1_sort_kernel(
         for (int i = 0; i < 34; i++) {
             const u32 a = cw[i] & 0xffffu, b = cw[i] >> 16;
             const u32 sa = start, sb = start + o1s_up4(a);
-            if (a) { atomicOr(&hbits[sa >> 5], 1u << (sa & 31u)); atomicOr(&lbits[(sa + a - 1u) >> 5], 1u << ((sa + a - 1u) & 31u)); }
-            if (b) { atomicOr(&hbits[sb >> 5], 1u << (sb & 31u)); atomicOr(&lbits[(sb + b - 1u) >> 5], 1u << ((sb + b - 1u) & 31u)); }
+            if (a) atomicOr(&hbits[sa >> 5], 1u << (sa & 31u));
+            if (b) atomicOr(&hbits[sb >> 5], 1u << (sb & 31u));
             if (a >= O1S_BIGMIN) { const u32 k = atomicAdd(&big_[16], 1u); if (k < 16u) big_[k] = a << 8 | sa >> 7; }
             if (b >= O1S_BIGMIN) { const u32 k = atomicAdd(&big_[16], 1u); if (k < 16u) big_[k] = b << 8 | sb >> 7; }
             start = sb + o1s_up4(b);
@@ -473,8 +475,8 @@ __global__ __launch_bounds__(64) void trc_o1_sort_kernel(
             const u32 rl = __builtin_amdgcn_mbcnt_hi((u32)(ml >> 32), __builtin_amdgcn_mbcnt_lo((u32)ml, 0u));
             const u32 nh = (u32)__popcll(mh), nl = (u32)__popcll(ml);
             const u32 ih = sh + rh, il = sl + rl;
-            ent[ih] = pos | (x >> 4) << 12 | ((hbits[ih >> 5] >> (ih & 31u)) & 1u) << 16 | ((lbits[ih >> 5] >> (ih & 31u)) & 1u) << 17;
-            ent[il] = pos | (x & 15u) << 12 | ((hbits[il >> 5] >> (il & 31u)) & 1u) << 16 | ((lbits[il >> 5] >> (il & 31u)) & 1u) << 17;
+            ent[ih] = pos | (x >> 4) << 12 | ((hbits[ih >> 5] >> (ih & 31u)) & 1u) << 16;
+            ent[il] = pos | (x & 15u) << 12 | ((hbits[il >> 5] >> (il & 31u)) & 1u) << 16;
             perm[pos] = ih | il << 16;
             if (rh == nh - 1u) *bh = (u16)(sh + nh);           // the key's last lane moves the bin on (after every lane of the row has read it)
             if (rl == nl - 1u) *bl = (u16)(sl + nl);
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(64 * O1W_WAVES) void trc_o1_walk_kernel(u32 nchunks
             const uint4 W = trc_ldsr128(rd + w * 1024u + lane * 16u);
             const u32 e[4] = { W.x, W.y, W.z, W.w };
             u32 r[4];
-            if (e[0] & O1S_HEAD) T = O1Cache::fresh();          // (chains start on windows; behind a LAST entry the table is garbage until then: nobody reads it)
+            if (e[0] & O1S_HEAD) T = O1Cache::fresh();          // (chains start on windows; behind a chain's last entry the table is garbage until then: nobody reads it)
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const u32 sym = (e[i] >> 12) & 15u;
