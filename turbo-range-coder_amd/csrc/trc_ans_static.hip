@@ -18,10 +18,17 @@
 #include <stdio.h>
 #include <string.h>
 #include "trc_io.h"
+#include "trc_gather.h"
 #include "trc_launch.h"
 
 #define ENC_WAVE_LDS (TRC_SRING_BYTES)       // input arrives through an in-register quad transpose
-#define ENC_PACE_LDS 64u                     // TrcPace's progress counters, behind the symbol table
+#define ENC_PACE_LDS 192u                    // TrcPace's progress counters, behind the symbol table; then the fused gather's words:
+#define ENC_FUSE_WSUM   64u                  //   u32[16]  the waves' group sums
+#define ENC_FUSE_TICKET 128u                 //   u32      the workgroup's ticket
+#define ENC_FUSE_BASE   136u                 //   u64      the workgroup's place in the payload
+#ifndef TRC_ENC_FUSED
+#define TRC_ENC_FUSED 0                      // 1: the encoder's waves gather their own payload when the launch is one residency round (trc_gather.h) -- measured a wash, off
+#endif
 #ifndef TRC_ENC_BALANCE
 #define TRC_ENC_BALANCE 1                    // workgroups of twelve waves that keep each other's pace when the launch is one residency round
 #endif
@@ -133,11 +140,12 @@ __device__ __forceinline__ void ans_fetch4(EncQuad &q, u32 w, u32 tbase, int shi
 #ifdef TRC_ENC_PROF                                              // variant builds only: wall clock (100 MHz) per wave: start, first symbol, last symbol, end
 __device__ unsigned long long trc_enc_wall[4 * 4096];
 #endif
-template <int BLOCK, int REP>
+template <int BLOCK, int REP, bool FUSED>
 __global__ __launch_bounds__(BLOCK) void trc_ans4s_enc_kernel(
     const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks,
     const uint4 *__restrict__ etab_g, u8 *__restrict__ scratch, u32 stride,
-    u32 *__restrict__ clen, u32 *__restrict__ gsum)
+    u32 *__restrict__ clen, u32 *__restrict__ gsum,
+    u8 *__restrict__ payload, u64 *__restrict__ total, u64 *__restrict__ goff_out, u8 *__restrict__ sync)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     constexpr u32 TAB = 4096u * REP;
@@ -148,14 +156,20 @@ __global__ __launch_bounds__(BLOCK) void trc_ans4s_enc_kernel(
     const u64 ew0 = wall_clock64();
 #endif
     u8 *wbase = smem + TAB + ENC_PACE_LDS + wv * ENC_WAVE_LDS;
+    u32 *const fuse_wsum = (u32 *)(smem + TAB + ENC_FUSE_WSUM);
+    if (FUSED) {                                                // the workgroup's place in the container: a ticket, not blockIdx (trc_gather.h)
+        if (tid == 0) *(u32 *)(smem + TAB + ENC_FUSE_TICKET) = __hip_atomic_fetch_add((u32 *)(sync + TRC_SYNC_TICKET), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < 16u) fuse_wsum[tid] = 0u;
+    }
     for (u32 i = tid; i < 256u * REP; i += BLOCK) ((uint4 *)smem)[i] = etab_g[i / REP];
     TrcPace pace; pace.init(trc_lds_addr(smem) + TAB, tid, wv);
     __syncthreads();
+    const u32 wg = FUSED ? (u32)__builtin_amdgcn_readfirstlane((int)*(const u32 *)(smem + TAB + ENC_FUSE_TICKET)) : blockIdx.x;
 
     WaveChunks wc;
-    wc.c0 = (blockIdx.x * (BLOCK / 64) + wv) * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
+    wc.c0 = (wg * (BLOCK / 64) + wv) * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
     wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
-    if (wc.c0 >= nchunks) return;
+    if (wc.c0 >= nchunks) return;                               // (a barrier waits for the surviving waves only; wave 0 of a workgroup always has chunks)
     wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
 
     const bool alive = lane < wc.rows;
@@ -259,6 +273,40 @@ __global__ __launch_bounds__(BLOCK) void trc_ans4s_enc_kernel(
     if (alive) clen[c] = out_len;
     const u32 gs = trc_wave_sum(out_len);
     if (lane == 0) gsum[wc.c0 >> 6] = gs;
+    if (FUSED) {
+        // the gather, by the waves that wrote the bytes (trc_gather.h)
+        __builtin_amdgcn_s_setprio(0);
+        if (lane == 0) fuse_wsum[wv] = gs;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's drains (asm stores: not in the compiler's books) have left for the L2
+        trc_lds_barrier();
+        u64 *const pub = (u64 *)(sync + TRC_SYNC_PUB);
+        const u32 nwg = ((nchunks + 63u) / 64u + (u32)(BLOCK / 64) - 1u) / (u32)(BLOCK / 64);
+        if (wv == 0) {
+            u32 wsum_all = 0;
+#pragma unroll
+            for (u32 k = 0; k < (u32)(BLOCK / 64); k++) wsum_all += fuse_wsum[k];
+            if (lane == 0) trc_sync_store(pub + wg, TRC_SYNC_VALID | wsum_all);
+            const u64 wgbase = trc_sync_prefix(pub, wg);
+            if (lane == 0) {
+                *(u64 *)(smem + TAB + ENC_FUSE_BASE) = wgbase;
+                if (wg == nwg - 1u && total) *total = wgbase + wsum_all;
+                // the last workgroup to have finished polling leaves the area as it found it: zero
+                const u32 done = __hip_atomic_fetch_add((u32 *)(sync + TRC_SYNC_DONE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (done == nwg - 1u) {
+                    for (u32 j = 0; j < nwg; j++) trc_sync_store(pub + j, 0ull);
+                    __hip_atomic_store((u32 *)(sync + TRC_SYNC_TICKET), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store((u32 *)(sync + TRC_SYNC_DONE), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        trc_lds_barrier();
+        u64 base = *(const u64 *)(smem + TAB + ENC_FUSE_BASE);
+        for (u32 k = 0; k < wv; k++) base += fuse_wsum[k];
+        if (lane == 0 && goff_out) goff_out[wc.c0 >> 6] = base;  // (kept for a decode of this directory: TrcWork::goff_area)
+        const bool raw = out_len == len;
+        const u8 *src = raw ? in + (u64)c * chunk : scratch + (u64)(c + 1u) * stride - out_len;
+        trc_wave_gather64(payload + base, (u32 *)wbase, (u64 *)(wbase + 512), alive ? out_len : 0u, alive ? src : scratch);
+    }
 #ifdef TRC_ENC_PROF
     if (lane == 0) { const u32 wid = (wc.c0 >> 6) & 4095u; trc_enc_wall[4 * wid] = ew0; trc_enc_wall[4 * wid + 1] = ew1; trc_enc_wall[4 * wid + 2] = ew2; trc_enc_wall[4 * wid + 3] = wall_clock64(); }
 #endif
@@ -684,27 +732,33 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec2_kernel(
 //   replicated table is NOT faster (100 MB, chunk 512: 64 vs 63 us; REP 16 at 11 waves per CU, chunk 576: 67 vs 68 us;
 //   profiles/r02_notes.md): the bank conflicts round 1's PMC showed were not what the kernel waited for.
 template <int REP>
-static void ans4s_enc_launch(u32 wpb, const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
+static void ans4s_enc_launch(u32 wpb, bool fused, const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen,
+                             uint8_t *d_payload, uint64_t *d_total, hipStream_t s)
 {
     const uint4 *etab = (const uint4 *)(w.tables + TRC_TAB_ENC);
     const u32 nwaves = w.ngroups;
     const size_t sm = 4096u * REP + ENC_PACE_LDS + wpb * ENC_WAVE_LDS;
-#define TRC_ENC_CASE(W)                                                                                              \
-    case W: TRC_RAISE_LDS_ONCE((trc_ans4s_enc_kernel<64 * W, REP>), 4096u * REP + ENC_PACE_LDS + W * ENC_WAVE_LDS);  \
-            TRC_LAUNCH_TIMED((trc_ans4s_enc_kernel<64 * W, REP>), dim3((nwaves + W - 1) / W), dim3(64 * W), sm, s,   \
-                             d_in, (u64)n, chunk, w.nchunks, etab, w.scratch, w.stride, d_clen, w.gsum); break;
+    u8 *const sync = w.tables + TRC_TAB_SYNC;
+#define TRC_ENC_CASE(W, F)                                                                                              \
+    TRC_RAISE_LDS_ONCE((trc_ans4s_enc_kernel<64 * W, REP, F>), 4096u * REP + ENC_PACE_LDS + W * ENC_WAVE_LDS);          \
+    TRC_LAUNCH_TIMED((trc_ans4s_enc_kernel<64 * W, REP, F>), dim3((nwaves + W - 1) / W), dim3(64 * W), sm, s,           \
+                     d_in, (u64)n, chunk, w.nchunks, etab, w.scratch, w.stride, d_clen, w.gsum, d_payload, d_total, w.goff_area, sync);
     switch (wpb) {
-    TRC_ENC_CASE(1) TRC_ENC_CASE(4) TRC_ENC_CASE(12)
+    case 1: TRC_ENC_CASE(1, false) break;
+    case 4: TRC_ENC_CASE(4, false) break;
+    case 12: if (fused) { TRC_ENC_CASE(12, true) } else { TRC_ENC_CASE(12, false) } break;
     default: break;
     }
 #undef TRC_ENC_CASE
 }
-void trc_launch_ans4s_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w,
-                          uint32_t *d_clen, hipStream_t s)
+// returns true when the encoder's waves have gathered the payload themselves (trc_gather.h): no gather launch behind it
+bool trc_launch_ans4s_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w,
+                          uint32_t *d_clen, uint8_t *d_payload, uint64_t *d_total, hipStream_t s)
 {
     const u32 nwaves = w.ngroups;
     static const int env_rep = getenv("TRC_ENC_REP") ? atoi(getenv("TRC_ENC_REP")) : 0;     // tuning aids
     static const int env_wpb = getenv("TRC_ENC_WPB") ? atoi(getenv("TRC_ENC_WPB")) : 0;
+    static const int env_fused = getenv("TRC_ENC_FUSED") ? atoi(getenv("TRC_ENC_FUSED")) : TRC_ENC_FUSED;
     int rep = env_rep ? env_rep : TRC_ENC_REP_DEFAULT;
     u32 wpb = rep == 8 ? 12u : 4u;
     // one residency round (at most twelve waves per CU): one workgroup of twelve waves per CU, whose waves keep each other's pace
@@ -713,8 +767,10 @@ void trc_launch_ans4s_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const T
     if (TRC_ENC_BALANCE && nwaves <= 12u * 256u) wpb = 12u;
     if (nwaves < 2048) { rep = 1; wpb = 1; }                 // few waves: one per workgroup so they spread over all CUs (12.4 KiB -> 12 per CU)
     if (env_wpb == 1 || env_wpb == 4 || env_wpb == 12) wpb = (u32)env_wpb;      // (tuning aid / tests: forces the shape whatever the size)
-    if (rep == 8) ans4s_enc_launch<8>(wpb, d_in, n, chunk, w, d_clen, s);
-    else ans4s_enc_launch<1>(wpb, d_in, n, chunk, w, d_clen, s);
+    // the twelve-wave workgroups of a one-round launch gather their own payload (no scan kernel in the way: w.goff == NULL)
+    const bool fused = env_fused && wpb == 12u && !w.goff && (nwaves + 11u) / 12u <= TRC_SYNC_MAX_WG;
+    if (rep == 8) ans4s_enc_launch<8>(wpb, fused, d_in, n, chunk, w, d_clen, d_payload, d_total, s);
+    else ans4s_enc_launch<1>(wpb, fused, d_in, n, chunk, w, d_clen, d_payload, d_total, s);
 #ifdef TRC_ENC_PROF
     {
         static int calls = 0;
@@ -737,6 +793,7 @@ void trc_launch_ans4s_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const T
         }
     }
 #endif
+    return fused;
 }
 
 void trc_launch_ans4s_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,

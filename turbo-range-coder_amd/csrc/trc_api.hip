@@ -338,9 +338,10 @@ extern "C" int trc_encode_dev(int codec, const void *d_in, size_t n, uint32_t ch
     if ((rc = carve(codec, n, chunk, d_work, work_bytes, w))) return rc;
     if (is_static(codec) && !tables_ready) trc_launch_static_prep(d_cdf, cdfnum, w.tables, s);
     int from_end = 0;
+    bool gathered = false;                                       // the coder's own waves have put the payload in place (trc_gather.h)
     tm_begin(0);
     switch (codec) {
-    case TRC_ANS4S: trc_launch_ans4s_enc((const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 1; break;
+    case TRC_ANS4S: gathered = trc_launch_ans4s_enc((const uint8_t *)d_in, n, chunk, w, d_clen, (uint8_t *)d_payload, d_total, s); from_end = 1; break;
     case TRC_RCS1:  trc_launch_rcs_enc(1, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 0; break;
     case TRC_RCS2:  trc_launch_rcs_enc(2, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 2; break;
     case TRC_RCSM:  trc_launch_rcs_enc(-1, (const uint8_t *)d_in, n, chunk, w, d_clen, s); from_end = 0; break;
@@ -362,8 +363,10 @@ extern "C" int trc_encode_dev(int codec, const void *d_in, size_t n, uint32_t ch
                     from_end = 1; break;
     }
     tm_end(0);
-    if (w.goff) trc_launch_scan_groups(w.gsum, w.ngroups, w.goff, d_total, s);
-    trc_launch_gather((const uint8_t *)d_in, n, chunk, w, from_end, d_clen, (uint8_t *)d_payload, d_total, s);
+    if (!gathered) {
+        if (w.goff) trc_launch_scan_groups(w.gsum, w.ngroups, w.goff, d_total, s);
+        trc_launch_gather((const uint8_t *)d_in, n, chunk, w, from_end, d_clen, (uint8_t *)d_payload, d_total, s);
+    }
     HIPCHK(hipGetLastError());
     return TRC_OK;
 }

@@ -2,6 +2,7 @@
 // (per-group sums -> exclusive scan), the payload gather, and cdfini (histogram -> CDF) on device.
 #include <stdlib.h>
 #include "trc_dev.h"
+#include "trc_gather.h"
 #include "trc_launch.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -37,6 +38,8 @@ __global__ __launch_bounds__(256) void trc_static_prep_kernel(const u16 *__restr
         ((uint4 *)(tables + TRC_TAB_ENC))[tid] = e;
         ((u32 *)(tables + TRC_TAB_DEC))[tid] = d;
         for (u32 i = tid; i < 260; i += 256) ((u16 *)(tables + TRC_TAB_CDF))[i] = (u16)((i <= cdfnum) ? cdf[i] : TRC_PROB_ONE);
+        // the sync area of the encoders that gather their own payload (trc_gather.h) starts out zero; each such launch leaves it zero
+        for (u32 i = tid; i < TRC_SYNC_BYTES / 4u; i += 256) ((u32 *)(tables + TRC_TAB_SYNC))[i] = 0u;
     }
 }
 

@@ -63,6 +63,7 @@ struct TrcWork {
 #define TRC_TAB_DEC   4096       // u32[256]     decoder symbol table
 #define TRC_TAB_LUT   8192       // u8[32768]    slot -> symbol
 #define TRC_TAB_CDF   40960      // u16[260]     sanitised CDF copy
+#define TRC_TAB_SYNC  41984      // 2112 B       sync area of the encoders that gather their own payload (trc_gather.h): zero between calls
 #define TRC_TAB_BYTES 45056
 
 // static-table prep (ANS4S / RCS1 / RCS2)
@@ -78,8 +79,9 @@ void trc_launch_gather(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcW
                        const uint32_t *d_clen, uint8_t *d_payload, uint64_t *d_total, hipStream_t s);
 
 // ANS4S: static-CDF rANS (anscdf4senc / anscdf4sdec)
-void trc_launch_ans4s_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w,
-                          uint32_t *d_clen, hipStream_t s);
+// returns true when the payload is already in place (the encoder's waves gathered it: trc_gather.h) -- no trc_launch_gather then
+bool trc_launch_ans4s_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w,
+                          uint32_t *d_clen, uint8_t *d_payload, uint64_t *d_total, hipStream_t s);
 void trc_launch_ans4s_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                           const TrcWork &w, uint8_t *d_out, hipStream_t s);
 
