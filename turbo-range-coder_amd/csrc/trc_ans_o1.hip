@@ -28,7 +28,10 @@
 #include "trc_nibmodel.h"
 #include "trc_launch.h"
 
-#define O1_MODEL_BYTES TRC_O1_MODEL_BYTES                    // 139264 per chunk
+#define O1_MODEL_BYTES TRC_O1_MODEL_BYTES
+#ifndef TRC_O1_DEC_DEFAULT_ROWS                               // decoder form: 1 = eight lanes per chunk; 16 / 64 = one lane per chunk, that many chunks per wave
+#define TRC_O1_DEC_DEFAULT_ROWS(ngroups) ((ngroups) <= 512u ? 1 : 64)
+#endif                    // 139264 per chunk
 
 __device__ __forceinline__ NibTable o1_load(const u8 *tb)
 {
@@ -108,6 +111,9 @@ struct O1Cache {
     {
         typedef __attribute__((address_space(3))) u32 lds_u32;
         const u32 id = cx * 17u;
+#ifdef TRC_O1_ABL_NOMEM                                         // timing ablation (results wrong by construction): no table ever moves
+        if (on && id != hid) { hid = id; return; }
+#endif
         if (on && id != hid) {
             if (hid != ~0u) { NibTable W = H; W.d[0] |= hmask; o1_store(mine + (size_t)hid * 32u, W); }
             const u32 a = seen + ((cx >> 5) << 2), bits = *(const lds_u32 *)(uintptr_t)a, bit = 1u << (cx & 31u);
@@ -120,6 +126,9 @@ struct O1Cache {
     __device__ __forceinline__ void need_lo(bool on, u32 cx, u32 h)
     {
         const u32 id = cx * 17u + 1u + h;
+#ifdef TRC_O1_ABL_NOMEM
+        if (on && id != lid) { lid = id; return; }
+#endif
         if (on && id != lid) {
             if (lid != ~0u) o1_store(mine + (size_t)lid * 32u, L);
             if ((hmask >> h) & 1u) L = o1_load(mine + (size_t)id * 32u);
@@ -756,6 +765,157 @@ __global__ __launch_bounds__(64) void trc_o1_dec_kernel(
     trc_wave_copy_raw(__ballot(alive && cl == len && len != 0), off, len, out + (u64)wc.c0 * chunk, chunk, payload);
 }
 
+// ---------------------------------------------------------------------------- decode, by rows ---
+// Round 5 (late): EIGHT LANES PER CHUNK.  What the one-lane-per-chunk decoder above spends (timing ablation, 100 MB at chunk 4096,
+// profiles/r05_notes.md): 2.3-2.9 ms on its own instruction chain -- a nibble's search, select trees and 8-register update are ~100
+// instructions of a lone wave -- and 2.4-3.4 ms on table round trips, every one of them 64 scattered 16-byte lane accesses through the
+// texture-address unit.  Here a CDF16 table is spread over the eight lanes of a ROW (lane e holds entries 2e | 2e+1 as one packed
+// dword -- the memory format is unchanged, lane e moves dword e), a wave decodes eight chunks, and everything a chunk's decoder
+// keeps (states, stream position, context, table identities) is held redundantly by the row's lanes:
+//   * a table move is ONE coalesced 32-byte access per row (four bytes per lane);
+//   * the symbol: t = T - (slot + 1) in both halves (v_pk_sub_u16; entries and slots are below 2^15, so a half's sign bit says
+//     "entry <= slot"), two ballots, a popcount of the row's eight bits each: x = count - 1 (the entries are increasing);
+//   * the bounds: the dword holding (t[x], t[x+1]) is T of lane x / 2 when x is even, (T.hi of that lane, T.lo of the next) when
+//     odd -- every lane prepares both forms (a DPP row shift, entry 16 = 2^15 behind lane 7), picks by x's parity (x is
+//     row-uniform) and ONE ds_bpermute fetches it;
+//   * the update: K[x][i] = 10 i + (i > x ? 32736 : 0), and "i > x" is the complement of the search's sign bits; three packed
+//     16-bit operations, as cdf16upd does (cdf_.h, the wrapping arithmetic of trc_nibmodel.h).
+// ~45 instructions per nibble for eight chunks.  First touch without the hi table's entry 0: 256 "context seen" bits and 256 x 16
+// "lo table seen" bits per chunk in LDS (544 B per chunk, 4.25 KiB per wave).
+#define O1R_LANES 8u
+#define O1R_CHUNKS (64u / O1R_LANES)                          // chunks per wave
+#define O1R_SEEN_BYTES 544u                                   // u16 lo-seen[256], u32 hi-seen[8]
+__global__ __launch_bounds__(64) void trc_o1_dec_rows_kernel(
+    const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
+    u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ model, u8 *__restrict__ out)
+{
+    typedef __attribute__((address_space(3))) u32 lds_u32;
+    typedef __attribute__((address_space(3))) u16 lds_u16;
+    __shared__ __attribute__((aligned(16))) u8 seen_s[O1R_CHUNKS * O1R_SEEN_BYTES];
+    const u32 lane = threadIdx.x, e = lane & (O1R_LANES - 1u), row = lane / O1R_LANES;
+    for (u32 i = lane; i < O1R_CHUNKS * O1R_SEEN_BYTES / 4u; i += 64u) ((u32 *)seen_s)[i] = 0u;
+    __syncthreads();
+
+    constexpr u32 WPG = 64u / O1R_CHUNKS;                      // waves per group of 64 chunks
+    const u32 g0 = (blockIdx.x / WPG) * 64u, wq = blockIdx.x % WPG;
+    const u32 lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
+    // the directory of the whole group (payload offsets are per group of 64 chunks): lane L reads chunk g0 + L
+    const u32 cg = g0 + lane;
+    const u32 lenL = cg < nchunks ? ((cg == nchunks - 1u) ? lastlen : chunk) : 0u;
+    const u32 clL = cg < nchunks ? trc_min(clen[cg], lenL) : 0u;   // a directory entry above the chunk length (corrupt input) reads as raw
+    const u32 exL = trc_wave_incl_scan(clL) - clL;
+    const u64 gbase = trc_group_base(goff, gsum, g0 >> 6);
+    // lanes 0 .. 7 as "chunk wq * 8 + lane of the group" (the raw copy at the end), then every lane as its row's chunk
+    const u32 srcl = (wq * O1R_CHUNKS + lane) & 63u;
+    const u32 cl_w = (u32)__shfl((int)clL, (int)srcl, 64), ex_w = (u32)__shfl((int)exL, (int)srcl, 64), len_w = (u32)__shfl((int)lenL, (int)srcl, 64);
+    const u32 cl = (u32)__shfl((int)cl_w, (int)row, 64), ex = (u32)__shfl((int)ex_w, (int)row, 64), len = (u32)__shfl((int)len_w, (int)row, 64);
+    const u32 c0w = g0 + wq * O1R_CHUNKS, c = c0w + row;
+    const bool alive = c < nchunks;
+    const u64 off = gbase + ex;
+    const bool coded = alive && cl != len;
+
+    u8 *const mine = model + (u64)(alive ? c : 0u) * O1_MODEL_BYTES + e * 4u;          // this lane's dword of every table of the row's chunk
+    const u32 seen = trc_lds_addr(seen_s) + row * O1R_SEEN_BYTES;
+    const u32 fresh = trc_pk((2u * e) << 11, (2u * e + 1u) << 11);
+    const u32 kbase = trc_pk(20u * e, 20u * e + 10u);
+    const u32 rowsh = lane & 56u;
+    u32 H = fresh, L = fresh, hid = ~0u, lid = ~0u;
+
+    u32 st0 = TRC_ANS_LOW, st1 = TRC_ANS_LOW, st2 = TRC_ANS_LOW, st3 = TRC_ANS_LOW;
+    if (coded) {                                               // decoder st[i] = encoder st[3-i] (mnfill)
+        st0 = trc_ld32_a2(payload + off); st1 = trc_ld32_a2(payload + off + 4u);
+        st2 = trc_ld32_a2(payload + off + 8u); st3 = trc_ld32_a2(payload + off + 12u);
+    }
+    const u8 *const src = payload + off + 16u;                 // the words follow the four states
+    const u32 lim = trc_sub_sat(cl, 16u);
+    u32 rpos = 0, cx = 0;
+
+    // cdf16ansdec on the row's table T (anscdf_.h:164-174): the symbol, the state update, the table update
+    auto get_nibble = [&](u32 &s, u32 &T) -> u32 {
+        const u32 slot = s & (TRC_PROB_ONE - 1u);
+        const u32 t = trc_as_u32(trc_as_s2(T) - trc_as_s2((slot + 1u) * 0x10001u));
+        const u64 mh = __ballot((int)t < 0), ml = __ballot((t & 0x8000u) != 0u);
+        const u32 x = (u32)__popc((u32)(mh >> rowsh) & 0xffu) + (u32)__popc((u32)(ml >> rowsh) & 0xffu) - 1u;
+        u32 N = (u32)__builtin_amdgcn_update_dpp(0, (int)T, 0x101, 0xf, 0xf, true);      // row_shl:1 -- lane i takes lane i + 1
+        N = e == O1R_LANES - 1u ? TRC_PROB_ONE : N;
+        const u32 V = (x & 1u) ? __builtin_amdgcn_alignbit(N, T, 16) : T;
+        const u32 cc = (u32)__builtin_amdgcn_ds_bpermute((int)((rowsh + ((x >> 1) & 7u)) << 2), (int)V);
+        const u32 c0 = cc & 0xffffu;
+        s = __umul24((cc >> 16) - c0, s >> TRC_PROB_BITS) + slot - c0;
+        const u32 K = kbase + ((~t >> 15) & 0x10001u) * 32736u;
+        const trc_s2 d = (trc_as_s2(K) - trc_as_s2(T)) >> (trc_s2)7;
+        T = trc_as_u32(trc_as_s2(T) + d);
+        return x;
+    };
+    // the row's current table becomes table `id` (rows with sw only): the old one goes back to memory, the new one comes from
+    // there if this call has written it before
+    auto table_swap = [&](bool sw, u32 &T, u32 &cur, u32 id, bool was_seen) {
+        if (sw) {
+            if (cur != ~0u) *(u32 *)(mine + (size_t)cur * 32u) = T;
+            T = fresh;
+            if (was_seen) T = *(const u32 *)(mine + (size_t)id * 32u);
+            cur = id;
+        }
+    };
+    auto get_byte = [&](bool act, u32 &sh, u32 &sl) -> u32 {    // context cx -> byte, which becomes the context
+        {
+            const u32 id = cx * 17u;
+            const bool sw = act && id != hid;
+            const u32 a = seen + 512u + ((cx >> 5) << 2), bit = 1u << (cx & 31u);
+            const u32 bits = *(const lds_u32 *)(uintptr_t)a;
+            if (sw) *(lds_u32 *)(uintptr_t)a = bits | bit;     // (every lane of the row writes the same word)
+            table_swap(sw, H, hid, id, (bits & bit) != 0u);
+        }
+        const u32 h = get_nibble(sh, H) & 15u;
+        {
+            const u32 id = cx * 17u + 1u + h;
+            const bool sw = act && id != lid;
+            const u32 a = seen + cx * 2u, bit = 1u << h;
+            const u32 bits = *(const lds_u16 *)(uintptr_t)a;
+            if (sw) *(lds_u16 *)(uintptr_t)a = (u16)(bits | bit);
+            table_swap(sw, L, lid, id, (bits & bit) != 0u);
+        }
+        const u32 l = get_nibble(sl, L) & 15u;
+        const u32 b = h << 4 | l;
+        cx = act ? b : cx;
+        return b;
+    };
+
+    u8 *const dst = out + (u64)(alive ? c : 0u) * chunk;
+    for (u32 p0 = 0; p0 < chunk; p0 += 32u) {                  // 32 output bytes per trip: lane e keeps dword e of them
+        if (!__ballot(coded && p0 < len)) break;
+        u32 acc = 0;
+#pragma nounroll
+        for (u32 d = 0; d < 8u; d++) {
+            u32 w = 0;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {                      // mndec8x2x: two bytes, then four renorms in order st0..st3
+                const bool act = coded && p0 + 4u * d + 2u * (u32)j < len;     // the second byte of an odd tail is the dummy
+                const u8 *wp = src + trc_min(rpos, lim);       // the (up to) four words this pair's renorms take, requested now
+                const u32 w_lo = trc_ld32_a2(wp), w_hi = trc_ld32_a2(wp + 4);
+                const u32 x0 = get_byte(act, st0, st1);
+                const u32 x1 = get_byte(act, st2, st3);
+                w |= (x0 | x1 << 8) << (16 * j);
+                u64 ww = ((u64)w_hi << 32) | w_lo;
+                auto renorm = [&](u32 &s) {
+                    const bool rn = act && s < TRC_ANS_LOW;
+                    s = rn ? (s << 16) | ((u32)ww & 0xffffu) : s;
+                    ww = rn ? ww >> 16 : ww;
+                    rpos += rn ? 2u : 0u;
+                };
+                renorm(st0); renorm(st1); renorm(st2); renorm(st3);
+            }
+            acc = e == d ? w : acc;
+        }
+        const u32 pos = p0 + 4u * e;
+        if (coded && pos + 4u <= len) *(u32 *)(dst + pos) = acc;
+        else if (coded && pos < len)                            // ragged end of the last chunk
+            for (u32 k = 0; pos + k < len; k++) dst[pos + k] = (u8)(acc >> (8u * k));
+    }
+    trc_wave_copy_raw(__ballot(lane < O1R_CHUNKS && c0w + lane < nchunks && cl_w == len_w && len_w != 0u), gbase + ex_w, len_w,
+                      out + (u64)c0w * chunk, chunk, payload);
+}
+
 // ------------------------------------------------------------------------------------- launch ---
 // returns true when the records were written to the PLANAR record space (the caller then runs the planar coding pass)
 bool trc_launch_anso1_model(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, hipStream_t s)
@@ -787,8 +947,10 @@ void trc_launch_anso1_dec(const uint8_t *d_payload, const uint32_t *d_clen, size
     static const int env_rows = getenv("TRC_O1_ROWS") ? atoi(getenv("TRC_O1_ROWS")) : 0;       // tuning aid: 64 / 16 / 8 force the form
     // sparse waves where the chip is nearly empty (100 MB at chunk 4096: 382 groups -- 5.88 -> 5.36 ms; at 763 groups and up the
     // 64-chunk waves are as fast or faster: profiles/r05j_ab.txt)
-    const int rows = env_rows ? env_rows : (w.ngroups <= 512u ? 16 : 64);
-    if (rows == 16)
+    const int rows = env_rows ? env_rows : TRC_O1_DEC_DEFAULT_ROWS(w.ngroups);
+    if (rows == 1)                                              // eight lanes per chunk (trc_o1_dec_rows_kernel)
+        TRC_LAUNCH_TIMED(trc_o1_dec_rows_kernel, dim3(w.ngroups * (64u / O1R_CHUNKS)), dim3(64), 0, s, d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, w.model, d_out);
+    else if (rows == 16)
         TRC_LAUNCH_TIMED(trc_o1_dec_kernel<16>, dim3(w.ngroups * 4u), dim3(64), 0, s, d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, w.model, d_out);
     else if (rows == 8)
         TRC_LAUNCH_TIMED(trc_o1_dec_kernel<8>, dim3(w.ngroups * 8u), dim3(64), 0, s, d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, w.model, d_out);

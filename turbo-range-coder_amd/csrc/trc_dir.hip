@@ -104,8 +104,14 @@ void trc_launch_scan_groups(const uint32_t *gsum, uint32_t ngroups, uint64_t *go
 // (second load, merged by byte mask); if even the next piece ends inside it (tiny pieces) it is assembled byte by
 // byte.  (History, 100 MB / chunk 512: chunk-after-chunk copy 55 us, per-vector binary search 54 us, this walk 49 us;
 // the two-part layout went from a per-chunk wave copy, 152 us, to the same walk.)
+#ifndef TRC_GATHER_VPT
+#define TRC_GATHER_VPT 6
+#endif
+#ifndef TRC_GATHER_ATTR
+#define TRC_GATHER_ATTR
+#endif
 template <int PARTS>
-__global__ __launch_bounds__(256) void trc_gather_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks,
+__global__ __launch_bounds__(256) TRC_GATHER_ATTR void trc_gather_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks,
                                                          const u8 *__restrict__ scratch, u32 stride, int from_end,
                                                          const u8 *__restrict__ scratch2, u32 stride2, const u32 *__restrict__ aux,
                                                          const u32 *__restrict__ clen, const u64 *__restrict__ goff,
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(256) void trc_gather_kernel(const u8 *__restrict__ 
 {
     constexpr u32 NP = 64u * PARTS;                            // pieces per group
     constexpr u32 TPP = 256u / NP;                             // threads per piece (4 or 2)
-    constexpr u32 VPT = 6;                                     // vectors per thread per trip: 4 x 6 x 16 B covers a 384-byte piece in one trip
+    constexpr u32 VPT = TRC_GATHER_VPT;                        // vectors per thread per trip: 4 x 6 x 16 B covers a 384-byte piece in one trip
     __shared__ u32 ex_s[NP + 1];                               // exclusive prefix of the piece lengths
     __shared__ u64 src_s[NP];                                  // where piece p's bytes are
     __shared__ u64 base_s;
