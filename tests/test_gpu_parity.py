@@ -377,7 +377,7 @@ def test_round5_workgroup_shapes(torch_cuda):
     """round 5: the launch code picks between two workgroup shapes by the size of the launch -- small workgroups (rounds 1-4), or
     one large workgroup per CU whose waves keep each other's pace (TrcPace, csrc/trc_dev.h) when the launch is one residency round:
     static rANS / range-coder encoders (1 / 4 vs 12 waves), the two-stream pair encoder (2 vs 12), the four-lanes-per-chunk rANS
-    coding passes (4 vs 16), the order-1 decoder (64 / 16 / 8 chunks per wave).  The pace-keeping itself only moves wave priorities.
+    coding passes (4 vs 16), the order-1 decoder (eight lanes per chunk by default; one lane per chunk with 64 / 16 / 8 chunks per wave).  The pace-keeping itself only moves wave priorities.
     Every shape is FORCED in a process of its own (the switches are read once) on inputs of a few groups -- which the automatic
     rule would never give the large shape: ragged tails, a short last workgroup, raw chunks -- per-chunk parity with the oracle
     and round trip."""

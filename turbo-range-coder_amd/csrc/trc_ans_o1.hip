@@ -30,7 +30,7 @@
 
 #define O1_MODEL_BYTES TRC_O1_MODEL_BYTES
 #ifndef TRC_O1_DEC_DEFAULT_ROWS                               // decoder form: 1 = eight lanes per chunk; 16 / 64 = one lane per chunk, that many chunks per wave
-#define TRC_O1_DEC_DEFAULT_ROWS(ngroups) ((ngroups) <= 512u ? 1 : 64)
+#define TRC_O1_DEC_DEFAULT_ROWS(ngroups) 1
 #endif                    // 139264 per chunk
 
 __device__ __forceinline__ NibTable o1_load(const u8 *tb)
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(64) void trc_o1_dec_kernel(
 //     row-uniform) and ONE ds_bpermute fetches it;
 //   * the update: K[x][i] = 10 i + (i > x ? 32736 : 0), and "i > x" is the complement of the search's sign bits; three packed
 //     16-bit operations, as cdf16upd does (cdf_.h, the wrapping arithmetic of trc_nibmodel.h).
-// ~45 instructions per nibble for eight chunks.  First touch without the hi table's entry 0: 256 "context seen" bits and 256 x 16
+// ~50 instructions per nibble for eight chunks (107 per byte with the renormalisations and the output).  First touch without the hi table's entry 0: 256 "context seen" bits and 256 x 16
 // "lo table seen" bits per chunk in LDS (544 B per chunk, 4.25 KiB per wave).
 #define O1R_LANES 8u
 #define O1R_CHUNKS (64u / O1R_LANES)                          // chunks per wave
@@ -814,66 +814,79 @@ __global__ __launch_bounds__(64) void trc_o1_dec_rows_kernel(
     const u64 off = gbase + ex;
     const bool coded = alive && cl != len;
 
-    u8 *const mine = model + (u64)(alive ? c : 0u) * O1_MODEL_BYTES + e * 4u;          // this lane's dword of every table of the row's chunk
+    // this lane's dword of table `id` of the row's chunk: mbase[moff + 32 id] (a wave-uniform base and a 32-bit offset: one
+    // address instruction per access).  Rows past the last chunk compute offsets beyond the model space and never use them.
+    u8 *const mbase = model + (u64)(c0w < nchunks ? c0w : 0u) * O1_MODEL_BYTES;
+    const u32 moff = row * O1_MODEL_BYTES + e * 4u;
     const u32 seen = trc_lds_addr(seen_s) + row * O1R_SEEN_BYTES;
     const u32 fresh = trc_pk((2u * e) << 11, (2u * e + 1u) << 11);
-    const u32 kbase = trc_pk(20u * e, 20u * e + 10u);
-    const u32 rowsh = lane & 56u;
-    u32 H = fresh, L = fresh, hid = ~0u, lid = ~0u;
+    const u32 kbase1 = trc_pk(20u * e, 20u * e + 10u) + 0x7fe07fe0u;   // K of a lane none of whose entries is <= slot; every such entry takes 32736 off
+    const u32 rowb4 = (lane & 56u) << 2;
+    const bool last_lane = e == O1R_LANES - 1u;
+    // The row starts out HOLDING the hi table of context 0 and the lo table (0, 0), both fresh, both marked "seen": the first byte's
+    // context is 0, so H is right as it stands, and L is either right (first hi nibble 0) or goes to memory untouched -- a swap never
+    // has to ask whether there is a table to put back.
+    u32 H = fresh, L = fresh, hid = 0u, lid = 1u;
+    if (e == 0u) { *(lds_u32 *)(uintptr_t)(seen + 512u) = 1u; *(lds_u16 *)(uintptr_t)seen = (u16)1u; }
+    trc_wave_lds_fence();
 
     u32 st0 = TRC_ANS_LOW, st1 = TRC_ANS_LOW, st2 = TRC_ANS_LOW, st3 = TRC_ANS_LOW;
     if (coded) {                                               // decoder st[i] = encoder st[3-i] (mnfill)
         st0 = trc_ld32_a2(payload + off); st1 = trc_ld32_a2(payload + off + 4u);
         st2 = trc_ld32_a2(payload + off + 8u); st3 = trc_ld32_a2(payload + off + 12u);
     }
-    const u8 *const src = payload + off + 16u;                 // the words follow the four states
+    const u8 *const sbase = payload + gbase;                   // the words follow the four states: sbase[soff + position]
+    const u32 soff = ex + 16u;
     const u32 lim = trc_sub_sat(cl, 16u);
+    const u32 lenc = coded ? len : 0u;
     u32 rpos = 0, cx = 0;
 
     // cdf16ansdec on the row's table T (anscdf_.h:164-174): the symbol, the state update, the table update
     auto get_nibble = [&](u32 &s, u32 &T) -> u32 {
         const u32 slot = s & (TRC_PROB_ONE - 1u);
-        const u32 t = trc_as_u32(trc_as_s2(T) - trc_as_s2((slot + 1u) * 0x10001u));
-        const u64 mh = __ballot((int)t < 0), ml = __ballot((t & 0x8000u) != 0u);
-        const u32 x = (u32)__popc((u32)(mh >> rowsh) & 0xffu) + (u32)__popc((u32)(ml >> rowsh) & 0xffu) - 1u;
+        const u32 t = trc_as_u32(trc_as_s2(T) - trc_as_s2(__umul24(slot, 0x10001u) + 0x10001u));
+        const u32 f = (t >> 15) & 0x10001u;                    // per half: entry <= slot
+        u32 cnt = (f + (f >> 16)) & 3u;                        // the row's sum, in every lane: xor 1, xor 2, mirror of the eight
+        cnt += (u32)__builtin_amdgcn_update_dpp(0, (int)cnt, 0xB1, 0xf, 0xf, true);      // quad_perm:[1,0,3,2]
+        cnt += (u32)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x4E, 0xf, 0xf, true);      // quad_perm:[2,3,0,1]
+        cnt += (u32)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x141, 0xf, 0xf, true);     // row_half_mirror
+        const u32 x = cnt - 1u;
         u32 N = (u32)__builtin_amdgcn_update_dpp(0, (int)T, 0x101, 0xf, 0xf, true);      // row_shl:1 -- lane i takes lane i + 1
-        N = e == O1R_LANES - 1u ? TRC_PROB_ONE : N;
+        N = last_lane ? TRC_PROB_ONE : N;
         const u32 V = (x & 1u) ? __builtin_amdgcn_alignbit(N, T, 16) : T;
-        const u32 cc = (u32)__builtin_amdgcn_ds_bpermute((int)((rowsh + ((x >> 1) & 7u)) << 2), (int)V);
+        const u32 cc = (u32)__builtin_amdgcn_ds_bpermute((int)(((x << 1) & 0x1cu) | rowb4), (int)V);
         const u32 c0 = cc & 0xffffu;
         s = __umul24((cc >> 16) - c0, s >> TRC_PROB_BITS) + slot - c0;
-        const u32 K = kbase + ((~t >> 15) & 0x10001u) * 32736u;
+        const u32 K = (u32)(__mul24((int)f, -32736) + (int)kbase1);
         const trc_s2 d = (trc_as_s2(K) - trc_as_s2(T)) >> (trc_s2)7;
         T = trc_as_u32(trc_as_s2(T) + d);
         return x;
     };
-    // the row's current table becomes table `id` (rows with sw only): the old one goes back to memory, the new one comes from
-    // there if this call has written it before
-    auto table_swap = [&](bool sw, u32 &T, u32 &cur, u32 id, bool was_seen) {
-        if (sw) {
-            if (cur != ~0u) *(u32 *)(mine + (size_t)cur * 32u) = T;
-            T = fresh;
-            if (was_seen) T = *(const u32 *)(mine + (size_t)id * 32u);
-            cur = id;
-        }
-    };
     auto get_byte = [&](bool act, u32 &sh, u32 &sl) -> u32 {    // context cx -> byte, which becomes the context
         {
             const u32 id = cx * 17u;
-            const bool sw = act && id != hid;
-            const u32 a = seen + 512u + ((cx >> 5) << 2), bit = 1u << (cx & 31u);
-            const u32 bits = *(const lds_u32 *)(uintptr_t)a;
-            if (sw) *(lds_u32 *)(uintptr_t)a = bits | bit;     // (every lane of the row writes the same word)
-            table_swap(sw, H, hid, id, (bits & bit) != 0u);
+            if (act && id != hid) {                            // the row's hi table goes back to memory, the context's comes in
+                *(u32 *)(mbase + (moff + hid * 32u)) = H;
+                const u32 ld = *(const u32 *)(mbase + (moff + id * 32u));      // (a table never written: whatever is there, dropped below)
+                const u32 a = seen + 512u + ((cx >> 5) << 2), bit = 1u << (cx & 31u);
+                const u32 bits = *(const lds_u32 *)(uintptr_t)a;
+                *(lds_u32 *)(uintptr_t)a = bits | bit;         // (every lane of the row writes the same word)
+                H = (bits & bit) ? ld : fresh;
+                hid = id;
+            }
         }
         const u32 h = get_nibble(sh, H) & 15u;
         {
             const u32 id = cx * 17u + 1u + h;
-            const bool sw = act && id != lid;
-            const u32 a = seen + cx * 2u, bit = 1u << h;
-            const u32 bits = *(const lds_u16 *)(uintptr_t)a;
-            if (sw) *(lds_u16 *)(uintptr_t)a = (u16)(bits | bit);
-            table_swap(sw, L, lid, id, (bits & bit) != 0u);
+            if (act && id != lid) {
+                *(u32 *)(mbase + (moff + lid * 32u)) = L;
+                const u32 ld = *(const u32 *)(mbase + (moff + id * 32u));
+                const u32 a = seen + cx * 2u, bit = 1u << h;
+                const u32 bits = *(const lds_u16 *)(uintptr_t)a;
+                *(lds_u16 *)(uintptr_t)a = (u16)(bits | bit);
+                L = (bits & bit) ? ld : fresh;
+                lid = id;
+            }
         }
         const u32 l = get_nibble(sl, L) & 15u;
         const u32 b = h << 4 | l;
@@ -881,36 +894,37 @@ __global__ __launch_bounds__(64) void trc_o1_dec_rows_kernel(
         return b;
     };
 
+    struct __attribute__((packed, aligned(2))) W2 { u32 lo, hi; };
     u8 *const dst = out + (u64)(alive ? c : 0u) * chunk;
     for (u32 p0 = 0; p0 < chunk; p0 += 32u) {                  // 32 output bytes per trip: lane e keeps dword e of them
-        if (!__ballot(coded && p0 < len)) break;
+        if (!__ballot(p0 < lenc)) break;
         u32 acc = 0;
 #pragma nounroll
         for (u32 d = 0; d < 8u; d++) {
             u32 w = 0;
 #pragma unroll
             for (int j = 0; j < 2; j++) {                      // mndec8x2x: two bytes, then four renorms in order st0..st3
-                const bool act = coded && p0 + 4u * d + 2u * (u32)j < len;     // the second byte of an odd tail is the dummy
-                const u8 *wp = src + trc_min(rpos, lim);       // the (up to) four words this pair's renorms take, requested now
-                const u32 w_lo = trc_ld32_a2(wp), w_hi = trc_ld32_a2(wp + 4);
+                const bool act = p0 + 4u * d + 2u * (u32)j < lenc;             // the second byte of an odd tail is the dummy
+                const W2 w2 = *(const W2 *)(sbase + (soff + trc_min(rpos, lim)));   // the (up to) four words this pair's renorms take, requested now
                 const u32 x0 = get_byte(act, st0, st1);
                 const u32 x1 = get_byte(act, st2, st3);
                 w |= (x0 | x1 << 8) << (16 * j);
-                u64 ww = ((u64)w_hi << 32) | w_lo;
-                auto renorm = [&](u32 &s) {
-                    const bool rn = act && s < TRC_ANS_LOW;
-                    s = rn ? (s << 16) | ((u32)ww & 0xffffu) : s;
-                    ww = rn ? ww >> 16 : ww;
-                    rpos += rn ? 2u : 0u;
+                const u64 ww = ((u64)w2.hi << 32) | w2.lo;
+                u32 taken = 0;                                 // bits of ww used up
+                auto renorm = [&](u32 &s) {                    // (rows that are done or raw run on garbage: nothing of theirs is used)
+                    const bool rn = s < TRC_ANS_LOW;
+                    s = rn ? __builtin_amdgcn_perm(s, (u32)(ww >> taken), 0x05040100u) : s;      // (s << 16) | next word
+                    taken += rn ? 16u : 0u;
                 };
                 renorm(st0); renorm(st1); renorm(st2); renorm(st3);
+                rpos += act ? taken >> 3 : 0u;
             }
             acc = e == d ? w : acc;
         }
         const u32 pos = p0 + 4u * e;
-        if (coded && pos + 4u <= len) *(u32 *)(dst + pos) = acc;
-        else if (coded && pos < len)                            // ragged end of the last chunk
-            for (u32 k = 0; pos + k < len; k++) dst[pos + k] = (u8)(acc >> (8u * k));
+        if (pos + 4u <= lenc) *(u32 *)(dst + pos) = acc;
+        else if (pos < lenc)                                    // ragged end of the last chunk
+            for (u32 k = 0; pos + k < lenc; k++) dst[pos + k] = (u8)(acc >> (8u * k));
     }
     trc_wave_copy_raw(__ballot(lane < O1R_CHUNKS && c0w + lane < nchunks && cl_w == len_w && len_w != 0u), gbase + ex_w, len_w,
                       out + (u64)c0w * chunk, chunk, payload);
@@ -945,8 +959,8 @@ void trc_launch_anso1_dec(const uint8_t *d_payload, const uint32_t *d_clen, size
                           const TrcWork &w, uint8_t *d_out, hipStream_t s)
 {
     static const int env_rows = getenv("TRC_O1_ROWS") ? atoi(getenv("TRC_O1_ROWS")) : 0;       // tuning aid: 64 / 16 / 8 force the form
-    // sparse waves where the chip is nearly empty (100 MB at chunk 4096: 382 groups -- 5.88 -> 5.36 ms; at 763 groups and up the
-    // 64-chunk waves are as fast or faster: profiles/r05j_ab.txt)
+    // eight lanes per chunk at every size (100 MB: chunk 4096 5.28 -> 3.79 ms, 2048 3.67 -> 3.71, 1024 3.83 -> 3.71: profiles/r05_notes.md);
+    // the one-lane-per-chunk forms (64 / 16 / 8 chunks per wave) stay behind TRC_O1_ROWS
     const int rows = env_rows ? env_rows : TRC_O1_DEC_DEFAULT_ROWS(w.ngroups);
     if (rows == 1)                                              // eight lanes per chunk (trc_o1_dec_rows_kernel)
         TRC_LAUNCH_TIMED(trc_o1_dec_rows_kernel, dim3(w.ngroups * (64u / O1R_CHUNKS)), dim3(64), 0, s, d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, w.model, d_out);
