@@ -818,6 +818,13 @@ __global__ __launch_bounds__(64) void trc_o1_dec_rows_kernel(
     // address instruction per access).  Rows past the last chunk compute offsets beyond the model space and never use them.
     u8 *const mbase = model + (u64)(c0w < nchunks ? c0w : 0u) * O1_MODEL_BYTES;
     const u32 moff = row * O1_MODEL_BYTES + e * 4u;
+#ifndef TRC_O1_SWIZZLE
+#define TRC_O1_SWIZZLE 1
+#endif
+    // Table `id` lies in slot id ^ (chunk & 127) of the chunk's block (4352 = 34 x 128 slots: the low seven bits permute inside their
+    // 128).  The blocks are 34 x 4096 bytes apart, so without it table `id` of EVERY chunk sits at the same address modulo 4096 -- the
+    // same L2 channel -- and the tables of the few contexts most bytes follow are hit by all the rows of the chip at once.
+    const u32 swz = TRC_O1_SWIZZLE ? (c & 127u) : 0u;
     const u32 seen = trc_lds_addr(seen_s) + row * O1R_SEEN_BYTES;
     const u32 fresh = trc_pk((2u * e) << 11, (2u * e + 1u) << 11);
     const u32 kbase1 = trc_pk(20u * e, 20u * e + 10u) + 0x7fe07fe0u;   // K of a lane none of whose entries is <= slot; every such entry takes 32736 off
@@ -866,8 +873,8 @@ __global__ __launch_bounds__(64) void trc_o1_dec_rows_kernel(
         {
             const u32 id = cx * 17u;
             if (act && id != hid) {                            // the row's hi table goes back to memory, the context's comes in
-                *(u32 *)(mbase + (moff + hid * 32u)) = H;
-                const u32 ld = *(const u32 *)(mbase + (moff + id * 32u));      // (a table never written: whatever is there, dropped below)
+                *(u32 *)(mbase + (moff + (hid ^ swz) * 32u)) = H;
+                const u32 ld = *(const u32 *)(mbase + (moff + (id ^ swz) * 32u));      // (a table never written: whatever is there, dropped below)
                 const u32 a = seen + 512u + ((cx >> 5) << 2), bit = 1u << (cx & 31u);
                 const u32 bits = *(const lds_u32 *)(uintptr_t)a;
                 *(lds_u32 *)(uintptr_t)a = bits | bit;         // (every lane of the row writes the same word)
@@ -879,8 +886,8 @@ __global__ __launch_bounds__(64) void trc_o1_dec_rows_kernel(
         {
             const u32 id = cx * 17u + 1u + h;
             if (act && id != lid) {
-                *(u32 *)(mbase + (moff + lid * 32u)) = L;
-                const u32 ld = *(const u32 *)(mbase + (moff + id * 32u));
+                *(u32 *)(mbase + (moff + (lid ^ swz) * 32u)) = L;
+                const u32 ld = *(const u32 *)(mbase + (moff + (id ^ swz) * 32u));
                 const u32 a = seen + cx * 2u, bit = 1u << h;
                 const u32 bits = *(const lds_u16 *)(uintptr_t)a;
                 *(lds_u16 *)(uintptr_t)a = (u16)(bits | bit);
