@@ -824,7 +824,7 @@ __global__ __launch_bounds__(64) void trc_o1_dec_rows_kernel(
     // Table `id` lies in slot id ^ (chunk & 127) of the chunk's block (4352 = 34 x 128 slots: the low seven bits permute inside their
     // 128).  The blocks are 34 x 4096 bytes apart, so without it table `id` of EVERY chunk sits at the same address modulo 4096 -- the
     // same L2 channel -- and the tables of the few contexts most bytes follow are hit by all the rows of the chip at once.
-    const u32 swz = TRC_O1_SWIZZLE ? (c & 127u) : 0u;
+    const u32 swz = TRC_O1_SWIZZLE ? (c & 127u) << 5 : 0u;     // (as a byte offset)
     const u32 seen = trc_lds_addr(seen_s) + row * O1R_SEEN_BYTES;
     const u32 fresh = trc_pk((2u * e) << 11, (2u * e + 1u) << 11);
     const u32 kbase1 = trc_pk(20u * e, 20u * e + 10u) + 0x7fe07fe0u;   // K of a lane none of whose entries is <= slot; every such entry takes 32736 off
@@ -833,7 +833,8 @@ __global__ __launch_bounds__(64) void trc_o1_dec_rows_kernel(
     // The row starts out HOLDING the hi table of context 0 and the lo table (0, 0), both fresh, both marked "seen": the first byte's
     // context is 0, so H is right as it stands, and L is either right (first hi nibble 0) or goes to memory untouched -- a swap never
     // has to ask whether there is a table to put back.
-    u32 H = fresh, L = fresh, hid = 0u, lid = 1u;
+    u32 H = fresh, L = fresh;
+    u32 hoff = (0u ^ swz) + moff, loff = (32u ^ swz) + moff;   // where the row's current tables live: table id at ((32 id) ^ swz) + moff
     if (e == 0u) { *(lds_u32 *)(uintptr_t)(seen + 512u) = 1u; *(lds_u16 *)(uintptr_t)seen = (u16)1u; }
     trc_wave_lds_fence();
 
@@ -853,14 +854,14 @@ __global__ __launch_bounds__(64) void trc_o1_dec_rows_kernel(
         const u32 slot = s & (TRC_PROB_ONE - 1u);
         const u32 t = trc_as_u32(trc_as_s2(T) - trc_as_s2(__umul24(slot, 0x10001u) + 0x10001u));
         const u32 f = (t >> 15) & 0x10001u;                    // per half: entry <= slot
-        u32 cnt = (f + (f >> 16)) & 3u;                        // the row's sum, in every lane: xor 1, xor 2, mirror of the eight
+        u32 cnt = (u32)__popc(f);                              // the row's sum, in every lane: xor 1, xor 2, mirror of the eight
         cnt += (u32)__builtin_amdgcn_update_dpp(0, (int)cnt, 0xB1, 0xf, 0xf, true);      // quad_perm:[1,0,3,2]
         cnt += (u32)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x4E, 0xf, 0xf, true);      // quad_perm:[2,3,0,1]
         cnt += (u32)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x141, 0xf, 0xf, true);     // row_half_mirror
         const u32 x = cnt - 1u;
         u32 N = (u32)__builtin_amdgcn_update_dpp(0, (int)T, 0x101, 0xf, 0xf, true);      // row_shl:1 -- lane i takes lane i + 1
         N = last_lane ? TRC_PROB_ONE : N;
-        const u32 V = (x & 1u) ? __builtin_amdgcn_alignbit(N, T, 16) : T;
+        const u32 V = __builtin_amdgcn_alignbit(N, T, (x << 4) & 16u);       // x even: T; odd: T.hi | N.lo << 16
         const u32 cc = (u32)__builtin_amdgcn_ds_bpermute((int)(((x << 1) & 0x1cu) | rowb4), (int)V);
         const u32 c0 = cc & 0xffffu;
         s = __umul24((cc >> 16) - c0, s >> TRC_PROB_BITS) + slot - c0;
@@ -870,29 +871,30 @@ __global__ __launch_bounds__(64) void trc_o1_dec_rows_kernel(
         return x;
     };
     auto get_byte = [&](bool act, u32 &sh, u32 &sl) -> u32 {    // context cx -> byte, which becomes the context
+        const u32 cb = (cx << 9) + (cx << 5);                 // 32 x the context's first table (17 tables per context: 544 bytes)
         {
-            const u32 id = cx * 17u;
-            if (act && id != hid) {                            // the row's hi table goes back to memory, the context's comes in
-                *(u32 *)(mbase + (moff + (hid ^ swz) * 32u)) = H;
-                const u32 ld = *(const u32 *)(mbase + (moff + (id ^ swz) * 32u));      // (a table never written: whatever is there, dropped below)
+            const u32 noff = (cb ^ swz) + moff;
+            if (act && noff != hoff) {                         // the row's hi table goes back to memory, the context's comes in
+                *(u32 *)(mbase + hoff) = H;
+                const u32 ld = *(const u32 *)(mbase + noff);   // (a table never written: whatever is there, dropped below)
                 const u32 a = seen + 512u + ((cx >> 5) << 2), bit = 1u << (cx & 31u);
                 const u32 bits = *(const lds_u32 *)(uintptr_t)a;
                 *(lds_u32 *)(uintptr_t)a = bits | bit;         // (every lane of the row writes the same word)
                 H = (bits & bit) ? ld : fresh;
-                hid = id;
+                hoff = noff;
             }
         }
         const u32 h = get_nibble(sh, H) & 15u;
         {
-            const u32 id = cx * 17u + 1u + h;
-            if (act && id != lid) {
-                *(u32 *)(mbase + (moff + (lid ^ swz) * 32u)) = L;
-                const u32 ld = *(const u32 *)(mbase + (moff + (id ^ swz) * 32u));
+            const u32 noff = ((cb + 32u + (h << 5)) ^ swz) + moff;
+            if (act && noff != loff) {
+                *(u32 *)(mbase + loff) = L;
+                const u32 ld = *(const u32 *)(mbase + noff);
                 const u32 a = seen + cx * 2u, bit = 1u << h;
                 const u32 bits = *(const lds_u16 *)(uintptr_t)a;
                 *(lds_u16 *)(uintptr_t)a = (u16)(bits | bit);
                 L = (bits & bit) ? ld : fresh;
-                lid = id;
+                loff = noff;
             }
         }
         const u32 l = get_nibble(sl, L) & 15u;
