@@ -225,7 +225,8 @@ def beyond_cache_leg(torch, trc, T, codec, chunk, dev, steps=5, warmup=2, n=1000
 # (VERDICT r4 #7): config 3 = adaptive-CDF byte coders (rccdf = -e46 literal, anscdf = -e56), config 4 = rcs (-e1), and rccdfs2 =
 # what configs 1 / 2 literally name (-e45).  Each is THIS script run once more in its own process on the coder's own workload and the
 # library's chunk, short (10 timed steps after a 100 ms clock preamble), no CPU leg; the sub-object keeps the fields a reader needs.
-OTHER_CONFIGS = ("rccdfs2", "rccdf", "anscdf", "rcs")
+# (anscdf1 -- SURVEY 8f rank 2, not a BASELINE configuration -- rides along since the end of round 5: the coder VERDICT r4 listed first under "weak".)
+OTHER_CONFIGS = ("rccdfs2", "rccdf", "anscdf", "rcs", "anscdf1")
 
 
 def other_configs():
