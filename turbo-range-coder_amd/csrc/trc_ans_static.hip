@@ -384,7 +384,14 @@ __device__ __forceinline__ void ans_get_pair(u32 &s0, u32 &s1, u32 &sl0, u32 &sl
 #endif
     u32 t0 = __umul24(e0.x, s0 >> TRC_PROB_BITS) + e0.y + sl0;
     u32 t1 = __umul24(e1.x, s1 >> TRC_PROB_BITS) + e1.y + sl1;
+#ifndef TRC_DEC_ALIGNBYTE
+#define TRC_DEC_ALIGNBYTE 0                                     // measured: 60.7-61.0 us either way (profiles/r05zi_alignbyte.txt)
+#endif
+#if TRC_DEC_ALIGNBYTE                                            // v_alignbyte shifts by 8 x (operand & 3): 2 hc is a plain v_add (2.3 cycles per SIMD), hc << 4 a v_lshlrev (4.2-5)
+    const u32 w32 = __builtin_amdgcn_alignbyte(dw1, dw0, hc + hc);                       // units hc, hc + 1
+#else
     const u32 w32 = __builtin_amdgcn_alignbit(dw1, dw0, hc << 4);                        // units hc, hc + 1 (the shift uses 5 bits: 16 x parity)
+#endif
     u32 c0, c1, sl;
     u64 m1, cy;
     asm("v_cmp_gt_u32_e32 vcc, 0x8000, %[t0]\n\t"
