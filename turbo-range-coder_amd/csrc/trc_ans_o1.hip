@@ -875,8 +875,12 @@ __global__ __launch_bounds__(64) void trc_o1_dec_rows_kernel(
         {
             const u32 noff = (cb ^ swz) + moff;
             if (act && noff != hoff) {                         // the row's hi table goes back to memory, the context's comes in
+#ifdef TRC_O1_ABL_NOMEM                                         // timing ablation (results wrong by construction): no table ever moves
+                const u32 ld = H;
+#else
                 *(u32 *)(mbase + hoff) = H;
                 const u32 ld = *(const u32 *)(mbase + noff);   // (a table never written: whatever is there, dropped below)
+#endif
                 const u32 a = seen + 512u + ((cx >> 5) << 2), bit = 1u << (cx & 31u);
                 const u32 bits = *(const lds_u32 *)(uintptr_t)a;
                 *(lds_u32 *)(uintptr_t)a = bits | bit;         // (every lane of the row writes the same word)
@@ -888,8 +892,12 @@ __global__ __launch_bounds__(64) void trc_o1_dec_rows_kernel(
         {
             const u32 noff = ((cb + 32u + (h << 5)) ^ swz) + moff;
             if (act && noff != loff) {
+#ifdef TRC_O1_ABL_NOMEM
+                const u32 ld = L;
+#else
                 *(u32 *)(mbase + loff) = L;
                 const u32 ld = *(const u32 *)(mbase + noff);
+#endif
                 const u32 a = seen + cx * 2u, bit = 1u << h;
                 const u32 bits = *(const lds_u16 *)(uintptr_t)a;
                 *(lds_u16 *)(uintptr_t)a = (u16)(bits | bit);
