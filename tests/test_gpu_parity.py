@@ -742,12 +742,13 @@ def test_bench_config_total_parity(torch_cuda, cfg):
     assert torch.equal(d_out[:n], d_in[:n]), "round trip failed"
 
 
-@pytest.mark.parametrize("name", ["rcs-text100m-1536", "anscdf-drift100m-1536"])
+@pytest.mark.parametrize("name", ["rcs-text100m-1536", "anscdf-drift100m-1536", "anscdf1-drift100m-4096"])
 def test_model_coders_next_to_another_coder_on_a_second_stream(torch_cuda, name):
     """the hand-written carry chains of `rcs` / `anscdf` were only ever exercised with their kernel alone on the
     device (one wave per SIMD).  Here the coder encodes and decodes its 100 MB bench configuration on one stream while a second stream
     keeps the static rANS coder (three waves per SIMD wherever it lands) and the bitwise rANS busy on the same device: every payload
-    must hash to the committed SHA-256 of the reference's per-chunk outputs, every decode must return the input."""
+    must hash to the committed SHA-256 of the reference's per-chunk outputs, every decode must return the input.  (The order-1 coder rides
+    along since the end of round 5: its chain passes and its eight-lanes-per-chunk decoder keep per-chunk state in LDS and in HBM.)"""
     import hashlib
     torch = torch_cuda
     cfg = [c for c in T.BENCH_CONFIGS if c["name"] == name][0]
