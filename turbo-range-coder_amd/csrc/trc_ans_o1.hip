@@ -640,12 +640,20 @@ __global__ __launch_bounds__(256) void trc_o1_place_kernel(u64 n, u32 chunk, u32
     const u32 L = *(const u32 *)(blk + O1S_LEN);
     const u32 *st = (const u32 *)(blk + O1S_STREAM);
     const bool staged = L <= O1P_SLOTS;                         // (many short chains -- incompressible input -- leave more unused slots: gather from memory then)
-    if (staged) for (u32 i = t * 4u; i < L; i += 1024u) *(uint4 *)(sr + i) = *(const uint4 *)(st + i);
-    __syncthreads();
     u8 *const rb = recs + (u64)c * (8u * (u64)chunk);
     const u32 *perm = (const u32 *)(blk + O1S_PERM);
-    for (u32 p = t; p < plen; p += 256u) {
-        const u32 pm = perm[p];
+    // (late round 5) a thread's sixteen `perm` words are asked for at once, together with the staging loads: as a loop of load -> two
+    // LDS reads -> two stores the workgroup walked sixteen dependent round trips, four workgroups per CU, 24 rounds of them
+    u32 pmv[16];
+#pragma unroll
+    for (u32 k = 0; k < 16u; k++) { const u32 p = t + 256u * k; pmv[k] = p < plen ? perm[p] : 0u; }
+    if (staged) for (u32 i = t * 4u; i < L; i += 1024u) *(uint4 *)(sr + i) = *(const uint4 *)(st + i);
+    __syncthreads();
+#pragma unroll
+    for (u32 k = 0; k < 16u; k++) {
+        const u32 p = t + 256u * k;
+        if (p >= plen) break;
+        const u32 pm = pmv[k];
         u8 *dst = rb + (p >> 4) * 128u + (p & 15u) * 4u;
         u32 rh, rl;
         if (staged) { rh = sr[pm & 0xffffu]; rl = sr[pm >> 16]; }
