@@ -58,17 +58,25 @@ def test_config_calls_work_without_gpu(lib):
     assert lib.trc_set_chunk(100) != 0          # rejected: not a multiple of 64 in range
     lib.trc_last_error.restype = ctypes.c_char_p
     assert b"chunk" in lib.trc_last_error()
-    # the chunk size of a host-pointer call follows its input length unless the caller fixes it
+    # the chunk size of a host-pointer call (round 6): the largest chunk whose one-wave time hides behind the call's PCIe time
+    # (budget max(1.7 ms, 0.35 n / 50 GB/s)) -- the caller sees the ratio, and the link, not the kernels, sets the pace
     lib.trc_auto_chunk.restype = ctypes.c_uint32
     lib.trc_auto_chunk.argtypes = [ctypes.c_size_t]
-    assert [lib.trc_auto_chunk(n) for n in (1, 100 * 10**6, 201326591, 201326592, 402653184, 805306368, 8 * 10**9)] == [512, 512, 512, 1024, 2048, 4096, 4096]
-    # ... and its coder: the model-per-lane coders fill the chip with 65 536 chunks, and go up only with 16 slices of that left
+    assert [lib.trc_auto_chunk(n) for n in (1, 100 * 10**6, 8 * 10**9)] == [4096, 4096, 4096]          # static coders: 4096 (nothing to gain above)
     lib.trc_auto_chunk_codec.restype = ctypes.c_uint32
     lib.trc_auto_chunk_codec.argtypes = [ctypes.c_int, ctypes.c_size_t]
-    GB = 1 << 30
-    assert [lib.trc_auto_chunk_codec(1, n) for n in (1, 100 * 10**6, 201326592, 8 * 10**9)] == [512, 512, 1024, 4096]        # static rANS
-    assert [lib.trc_auto_chunk_codec(4, n) for n in (1, 100 * 10**6, GB - 1, GB, 2 * GB, 4 * GB)] == [512, 512, 512, 1024, 2048, 4096]
-    assert [lib.trc_auto_chunk_codec(12, n) for n in (1, 100 * 10**6, 8 * GB)] == [4096, 4096, 4096]                          # order-1 rANS
+    GB = 10**9
+    for codec in (1, 2, 3, 11):
+        assert [lib.trc_auto_chunk_codec(codec, n) for n in (1, 100 * 10**6, 8 * GB)] == [4096, 4096, 4096]
+    assert [lib.trc_auto_chunk_codec(4, n) for n in (1, 100 * 10**6, 200 * 10**6, 400 * 10**6, GB)] == [4096, 4096, 4096, 6144, 16384]    # rccdf
+    assert [lib.trc_auto_chunk_codec(5, n) for n in (1, 100 * 10**6, GB)] == [4096, 4096, 16384]                                         # anscdf
+    assert [lib.trc_auto_chunk_codec(6, n) for n in (1, 100 * 10**6, GB)] == [2048, 2048, 8192]                                         # rcs: 592 ns per chunk byte
+    assert [lib.trc_auto_chunk_codec(12, n) for n in (1, 100 * 10**6, GB, 8 * GB)] == [4096, 4096, 6144, 16384]                                    # order-1 rANS: never below 4096
+    assert [lib.trc_auto_chunk_codec(13, n) for n in (1, 100 * 10**6, 8 * GB)] == [2048, 2048, 8192]                                     # bitwise rANS: within one reference block
+    for codec in range(1, 28):
+        for n in (1, 10**6, 100 * 10**6, GB, 8 * GB):
+            c = lib.trc_auto_chunk_codec(codec, n)
+            assert c % 64 == 0 and 512 <= c <= 16384 and c >= lib.trc_auto_chunk_codec(codec, max(1, n // 2)), (codec, n, c)             # grows with the input
     # the chunk of a device-resident call: the input becomes a whole number of residency rounds of the coder's lanes, barely
     lib.trc_round_chunk.restype = ctypes.c_uint32
     lib.trc_round_chunk.argtypes = [ctypes.c_int, ctypes.c_size_t]

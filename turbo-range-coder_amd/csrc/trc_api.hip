@@ -48,30 +48,56 @@ extern "C" int trc_device_count(void)
 }
 
 // ------------------------------------------------------------------------------------ config ---
-// The chunk is the parallel unit: a call fills the chip when it has ~196 000 chunks (256 CUs x 12 waves x 64 lanes), and
-// every chunk costs 8 bytes of coder state and 4 bytes of directory.  Unless the caller fixes the size (trc_set_chunk,
-// TRC_CHUNK), a host-pointer call picks it from its input length: the largest of 4096 / 2048 / 1024 / 512 that still
-// gives one full residency round (>= 805 / 403 / 201 MB), 512 below that.
-// The coders that keep a MODEL per lane in LDS (adaptive, bitwise, order-1) hold 4 waves per CU, not 12: one residency
-// round is 65 536 chunks, and that is also the slice of their host-pointer calls (slice_plan).  They take the larger
-// chunk only when the call still has 16 such slices to pipeline (>= 1 / 2.1 / 4.3 GB).
+// The chunk is the parallel unit AND the price of the format: every chunk costs 8 bytes of coder state and 4 bytes of
+// directory, and an adaptive model learns its statistics anew in every chunk (20 MB of `drift` through rccdfenc: 38.7 % stored
+// at chunk 512, 30.6 % at 1536, 28.0 % at 4096, 26.9 % at 16 384; one whole-buffer call of the reference 26.7 %).
+// Rounds 3-5 picked the chunk of a host-pointer call for the KERNELS (512 below 1 GB: the chip full of short waves) -- on a path
+// whose pace is set by PCIe, not by the kernels (the policy optimised the one quantity the caller cannot see and
+// gave away the one it can).  Round 6: unless the caller fixes the size (trc_set_chunk, TRC_CHUNK), a host-pointer call takes the
+// LARGEST chunk whose one-wave time still hides behind the call's transfer time:
+//     wave time(chunk) = trc_wave_ns(codec) x chunk        (a launch lasts one wave's time however few chunks it has, and the
+//                                                           slices of a call are coded concurrently: trc_host.inc)
+//     budget           = max(1.7 ms, 0.35 x n / 50 GB/s)    (a third of what the link needs for the call: the last slice to arrive
+//                                                           still has a wave's time to go, so a call lasts link time + wave time;
+//                                                           the floor is what 100 MB are given: rccdf at 4096, 28.0 % stored)
+// from the ladder 512 .. 16 384; static coders stop at 4096 (text100m: 63.50 % of payload against 63.35 % whole-buffer -- nothing
+// left to gain), the bitwise rANS at one reference block (8192), the order-1 coder never goes below 4096.
+// 100 MB: rccdf / rccdfi / anscdf 4096, rcs 2048, static 4096; 1 GB: rccdf / anscdf 16 384, rcs 8192.
 #define TRC_MODEL_ROUND_CHUNKS 65536u                         // 256 CUs x 4 waves x 64 lanes
 static uint32_t g_chunk = 0;                                  // 0: not read yet;  ~0u: automatic
 static bool chunk_ok(uint32_t c) { return c >= TRC_CHUNK_MIN && c <= TRC_CHUNK_MAX && (c % 64u) == 0; }
-extern "C" uint32_t trc_auto_chunk(size_t n)
+static inline bool is_static(int codec);
+// one wave's time per byte of its chunk, ns, the slower of encode and decode (profiles/r05_all_codecs.txt: kernel time at chunk
+// 4096 with the chip a third full / 4096)
+static double trc_wave_ns(int codec)
 {
-    for (uint32_t c = 4096u; c > TRC_CHUNK_AUTO_MIN; c >>= 1)
-        if (n / c >= 196608u) return c;
-    return TRC_CHUNK_AUTO_MIN;
+    switch (codec) {
+    case TRC_ANS4S: return 67;  case TRC_RCS1: return 184; case TRC_RCS2: return 112; case TRC_RCSM: return 230;
+    case TRC_RCB: return 592;   case TRC_ANSB: return 635; case TRC_RCA: return 406;  case TRC_RCAI: return 397;
+    case TRC_ANSA: return 336;  case TRC_ANSO1: return 884;
+    case TRC_RCA4: return 245;  case TRC_RCAI4: return 260; case TRC_ANSA4: return 255;
+    case TRC_RCV8: return 746;  case TRC_RCVI8: return 797;
+    case TRC_VLCU16: case TRC_VLCV16: case TRC_VLCVZ16: return 391;
+    case TRC_VLCU32: case TRC_VLCV32: case TRC_VLCVZ32: return 214;
+    case TRC_VLAU16: case TRC_VLAV16: case TRC_VLAVZ16: return 370;
+    case TRC_VLAUZ16: return 260;
+    case TRC_VLAV32: case TRC_VLAVZ32: return 201;
+    }
+    return 400;
 }
+#define TRC_AUTO_CHUNK_MAX 16384u
 extern "C" uint32_t trc_auto_chunk_codec(int codec, size_t n)
 {
-    if (codec == TRC_ANS4S || codec == TRC_RCS1 || codec == TRC_RCS2 || codec == TRC_RCSM) return trc_auto_chunk(n);
-    if (codec == TRC_ANSO1) return 4096u;                     // 256 x 17 tables per chunk: nothing to learn from in fewer bytes (and 136 KiB of workspace each)
-    for (uint32_t c = 4096u; c > TRC_CHUNK_AUTO_MIN; c >>= 1)
-        if (n / c / TRC_MODEL_ROUND_CHUNKS >= 16u) return codec == TRC_ANSB && c > TRC_ANSB_CHUNK_MAX ? TRC_ANSB_CHUNK_MAX : c;
-    return TRC_CHUNK_AUTO_MIN;
+    static const uint32_t ladder[] = { 16384u, 12288u, 8192u, 6144u, 4096u, 3072u, 2048u, 1536u, 1024u, 768u, 512u };
+    const double link_ns = 0.35 * (double)n / 50.0;               // 50 GB/s = 50 bytes per ns
+    const double budget_ns = link_ns > 1.7e6 ? link_ns : 1.7e6;
+    const uint32_t cap = is_static(codec) ? 4096u : codec == TRC_ANSB ? TRC_ANSB_CHUNK_MAX : TRC_AUTO_CHUNK_MAX;
+    const uint32_t lo = codec == TRC_ANSO1 ? 4096u : TRC_CHUNK_AUTO_MIN;
+    for (uint32_t c : ladder)
+        if (c <= cap && (c <= lo || trc_wave_ns(codec) * c <= budget_ns)) return c;
+    return lo;
 }
+extern "C" uint32_t trc_auto_chunk(size_t n) { return trc_auto_chunk_codec(TRC_ANS4S, n); }      // the static coders' rule
 // The chunk for a DEVICE-RESIDENT call of n bytes (one launch over the whole input: trc_encode_dev, bench.py).  A launch lasts
 // (residency rounds) x (one wave's time, proportional to its chunk), so the input should be a whole number of rounds of the
 // coder's resident lanes, barely: the LARGEST chunk (multiple of 64) with ceil(n / chunk) <= k rounds for the smallest k that
@@ -85,7 +111,6 @@ extern "C" uint32_t trc_auto_chunk_codec(int codec, size_t n)
 // 26.7 %); it now takes one round of chunk 15 296.  The kernels take chunks up to 65 536; above 16 KiB the
 // ratio has nothing left to gain.  (The bitwise rANS stays within one reference block, the order-1 coder at 4096.)
 #define TRC_ROUND_CHUNK_MAX 16384u
-static inline bool is_static(int codec);
 static size_t round_chunks(int codec)
 {
     if (codec == TRC_RCS2) return 98304u;
@@ -439,486 +464,7 @@ extern "C" const char *trc_kernel_name(int codec, int decode)
 }
 
 // --------------------------------------------------- layer 1: reference prototypes (host pointers) ---
-// A TurboRC-style caller hands over pageable host buffers and times the whole call, so this layer is a PCIe pipeline:
-//   * the buffer is cut into slices (whole groups of 64 chunks, ~16 MB); slice i+1 is on its way to the GPU while slice i
-//     is coded and slice i-1 travels back: three streams (H2D, kernels, D2H) tied by events, both DMA directions busy at
-//     once (PCIe Gen5 x16 measured on the MI355X box: 57 GB/s one way, 48 GB/s each way when both run);
-//   * a hipMemcpyAsync on pageable memory returns only when the copy is done (measured: two directions from one thread
-//     = 28 GB/s each), so transfers go through pinned staging buffers, filled and emptied by a small pool of copy threads
-//     (one thread moves 28 GB/s, four 110 GB/s); registering the caller's buffers instead costs 5.5 ms per 100 MB and a
-//     registration must not outlive memory the caller may free;
-//   * one context per DEVICE (the caller's current device at the time of the call), each with its own lock: calls on one
-//     device serialise, calls on different devices do not.
-#include <condition_variable>
-#include <thread>
-#include <vector>
-namespace {
-// ---- copy threads: memcpy(dst, src, len) split over the pool, caller blocks until done --------------------------
-class CopyPool {
-public:
-    // A pool belongs to ONE HostCtx (one device): two per context -- one fills the staging buffers on the way in, one empties
-    // them on the way out, both directions at once -- created with the context and used only under the context's lock, so
-    // calls on different devices never meet in a pool (round 2 had two process-wide pools behind per-device locks: two
-    // threads could both pass wait() and the second overwrite the first's job).  Never destroyed: the threads are detached
-    // and wait on the condition variable for the life of the process (destroying a condition variable with waiters blocks
-    // in glibc: a process would hang at exit).
-    // start a copy on the pool's threads and return; wait() blocks until it is done (one copy in flight per pool).
-    // Waiting for the previous job and installing the new one happen under ONE lock, so start() is safe on its own too.
-    void start(void *dst, const void *src, size_t len)
-    {
-        std::unique_lock<std::mutex> lk(mu_);
-        done_.wait(lk, [&] { return pending_ == 0; });
-        if (len == 0) return;
-        if (nthr_ == 0) { lk.unlock(); memcpy(dst, src, len); return; }
-        dst_ = (uint8_t *)dst; src_ = (const uint8_t *)src; len_ = len; next_ = 0; pending_ = nthr_; gen_++;
-        lk.unlock();
-        cv_.notify_all();
-    }
-    void wait()
-    {
-        std::unique_lock<std::mutex> lk(mu_);
-        done_.wait(lk, [&] { return pending_ == 0; });
-    }
-    // copy with the caller's help, blocking
-    void copy(void *dst, const void *src, size_t len)
-    {
-        if (len < (1u << 20)) { wait(); memcpy(dst, src, len); return; }
-        start(dst, src, len);
-        work();
-        wait();
-    }
-    CopyPool()
-    {
-        const char *e = getenv("TRC_COPY_THREADS");
-        nthr_ = e ? atoi(e) : 6;                                            // per pool (+ the calling thread in copy())
-        if (nthr_ < 0) nthr_ = 0;
-        if (nthr_ > 15) nthr_ = 15;
-        for (int i = 0; i < nthr_; i++) std::thread([this] { loop(); }).detach();
-    }
-    CopyPool(const CopyPool &) = delete;
-private:
-    static constexpr size_t PIECE = 1u << 19;
-    void work()
-    {
-        for (;;) {
-            size_t o;
-            { std::lock_guard<std::mutex> lk(mu_); if (next_ >= len_) return; o = next_; next_ += PIECE; }
-            memcpy(dst_ + o, src_ + o, len_ - o < PIECE ? len_ - o : PIECE);
-        }
-    }
-    void loop()
-    {
-        uint64_t seen = 0;
-        for (;;) {
-            { std::unique_lock<std::mutex> lk(mu_); cv_.wait(lk, [&] { return gen_ != seen; }); seen = gen_; }
-            work();
-            { std::lock_guard<std::mutex> lk(mu_); if (--pending_ == 0) done_.notify_all(); }
-        }
-    }
-    std::mutex mu_;
-    std::condition_variable cv_, done_;
-    uint8_t *dst_ = nullptr; const uint8_t *src_ = nullptr;
-    size_t len_ = 0, next_ = 0;
-    int nthr_ = 0, pending_ = 0;
-    uint64_t gen_ = 0;
-};
-
-#define TRC_NSLOT 3                                  // staging slots per direction
-struct HostCtx {
-    std::mutex mu;
-    bool init = false;
-    int dev = -1;
-    hipStream_t s_in = nullptr, s_k = nullptr, s_out = nullptr;
-    uint8_t *d_in = nullptr;   size_t cap_in = 0;      // plain bytes (encode input / decode output)
-    uint8_t *d_cont = nullptr; size_t cap_cont = 0;    // container: hdr | clen[] | payload
-    uint8_t *d_work = nullptr; size_t cap_work = 0;
-    uint8_t *d_small = nullptr;                        // cdf (1 KiB) | totals (8 B x 4096 slices at 2048) | status
-    uint8_t *pin_in[TRC_NSLOT] = {}, *pin_out[TRC_NSLOT] = {}; size_t cap_pin[TRC_NSLOT] = {};
-    uint64_t *pin_tot = nullptr;                       // pinned: per-slice totals
-    hipEvent_t ev_in[TRC_NSLOT] = {}, ev_k[TRC_NSLOT] = {}, ev_out[TRC_NSLOT] = {};
-    CopyPool *pool_in = nullptr, *pool_out = nullptr;  // this context's copy threads (staging in / unstaging out)
-};
-// Every failure of a host-pointer call leaves through this guard: copy threads may still be writing into the caller's
-// `out`, DMAs may still target the staging buffers -- nothing of the call may be in flight when it returns (the caller may
-// free `out`, the next call may reallocate the pinned buffers).
-struct HostDrain {
-    HostCtx &c; bool ok = false;
-    explicit HostDrain(HostCtx &ctx) : c(ctx) {}
-    ~HostDrain()
-    {
-        if (ok) return;
-        if (c.pool_in) c.pool_in->wait();
-        if (c.pool_out) c.pool_out->wait();
-        if (c.s_in) (void)hipStreamSynchronize(c.s_in);
-        if (c.s_k) (void)hipStreamSynchronize(c.s_k);
-        if (c.s_out) (void)hipStreamSynchronize(c.s_out);
-    }
-};
-#define TRC_MAX_DEV 64
-HostCtx g_ctxs[TRC_MAX_DEV];
-
-int ctx_get(HostCtx *&out)
-{
-    int ndev = 0, dev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
-        return fail(TRC_E_NODEV, "no HIP device: libturborc_hip has no CPU coding path");
-    HIPCHK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= TRC_MAX_DEV) return fail(TRC_E_ARG, "device %d out of range", dev);
-    out = &g_ctxs[dev];
-    return TRC_OK;
-}
-int ctx_init(HostCtx &c, int dev)
-{
-    if (c.init) return TRC_OK;
-    c.dev = dev;
-    HIPCHK(hipStreamCreateWithFlags(&c.s_in, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&c.s_k, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&c.s_out, hipStreamNonBlocking));
-    HIPCHK(hipMalloc((void **)&c.d_small, 65536));
-    HIPCHK(hipHostMalloc((void **)&c.pin_tot, 4096 * sizeof(uint64_t)));
-    for (int i = 0; i < TRC_NSLOT; i++) {
-        HIPCHK(hipEventCreateWithFlags(&c.ev_in[i], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&c.ev_k[i], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&c.ev_out[i], hipEventDisableTiming));
-    }
-    c.pool_in = new CopyPool; c.pool_out = new CopyPool;
-    c.init = true;
-    return TRC_OK;
-}
-int grow(uint8_t **p, size_t *cap, size_t need)
-{
-    need = up256(need + TRC_PAD);
-    if (*cap >= need) return TRC_OK;
-    if (*p) HIPCHK(hipFree(*p));
-    *p = nullptr; *cap = 0;
-    size_t want = need + need / 8;
-    HIPCHK(hipMalloc((void **)p, want));
-    *cap = want;
-    return TRC_OK;
-}
-// staging slots of `need` bytes each for a call of `nslices` slices (slice i uses slot i % TRC_NSLOT: a one-slice call --
-// the order-1 coder's whole input, up to 256 MB -- pins one pair of buffers, not three)
-int grow_pins(HostCtx &c, size_t need, size_t nslices)
-{
-    need = up256(need + TRC_PAD);
-    const int want = nslices < TRC_NSLOT ? (int)nslices : TRC_NSLOT;
-    for (int i = 0; i < want; i++) {
-        if (c.cap_pin[i] >= need) continue;
-        const size_t twice = 2 * c.cap_pin[i] < ((size_t)40 << 20) ? 2 * c.cap_pin[i] : (size_t)40 << 20;    // calls of growing length re-pin a few times, not every time
-        const size_t sz = need < twice ? twice : need;
-        if (c.pin_in[i]) HIPCHK(hipHostFree(c.pin_in[i]));
-        if (c.pin_out[i]) HIPCHK(hipHostFree(c.pin_out[i]));
-        c.pin_in[i] = c.pin_out[i] = nullptr; c.cap_pin[i] = 0;
-        HIPCHK(hipHostMalloc((void **)&c.pin_in[i], sz));
-        HIPCHK(hipHostMalloc((void **)&c.pin_out[i], sz));
-        c.cap_pin[i] = sz;
-    }
-    return TRC_OK;
-}
-// Is [p, p + len) page-locked host memory the GPU can address (hipHostMalloc, or registered with hipHostRegister /
-// trc_host_pin)?  Then a host-pointer call moves its bytes by DMA straight from / to the caller's buffer; pageable
-// buffers go through the pinned staging slots and the copy threads.
-bool host_is_pinned(const void *p, size_t len)
-{
-    static const bool off = getenv("TRC_HOST_NO_DIRECT") != nullptr;      // tuning aid: always stage
-    if (off || !p || !len) return false;
-    const char *ends[2] = { (const char *)p, (const char *)p + len - 1 };
-    for (const char *q : ends) {
-        hipPointerAttribute_t a;
-        if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }
-        if (a.type != hipMemoryTypeHost) return false;
-    }
-    return true;
-}
-// cdfnum = index of the terminating 1<<15 (cdf is strictly increasing from 0)
-int host_cdfnum(const cdf_t *cdf)
-{
-    if (!cdf || cdf[0] != 0) return -1;
-    for (int i = 1; i <= 256; i++) {
-        if (cdf[i] == TRC_PROB_ONE_HOST) return i;
-        if (cdf[i] <= cdf[i - 1] || cdf[i] > TRC_PROB_ONE_HOST) return -1;
-    }
-    return -1;
-}
-// Slice plan of a host-pointer call: whole groups of 64 chunks.  Static coders: ~16 MB of input per slice in the middle of
-// the call (8-32 MB measure alike on the MI355X box, 4 MB throughout is 30 % slower: per-slice synchronisation) -- their
-// kernels are far faster than the link, so the slice is sized for the copies.  Model-per-lane coders: one residency round of
-// 65 536 chunks (32 MB at chunk 512), because a launch with fewer waves than the chip holds still takes one wave's full time:
-// with 16 MB slices the kernels, not the link, set the pace (page-locked 100 MB, GB/s: rccdf 33 -> 41, rcs 18 -> 38,
-// ansb 16 -> 29, rccdf8 22 -> 38, order-1 1.7 -> 9 with its whole input in one slice; profiles/r03_notes.md section 7).
-// TRC_HOST_SLICE overrides the byte target for every coder.  The plan ramps up from 1/8 of the slice at the start and down
-// to 1/8 at the end: the first H2D copy and the last D2H copy + unstaging are the part of the pipeline nothing overlaps
-// with, so they are kept short.
-// first[i] = first chunk of slice i, first[nsl] = nchunks; returns the largest slice in chunks.
-size_t slice_plan(int codec, uint32_t chunk, size_t nchunks, std::vector<size_t> &first)
-{
-    static const size_t forced = getenv("TRC_HOST_SLICE") ? (size_t)strtoull(getenv("TRC_HOST_SLICE"), 0, 10) : 0;
-    static const bool ramp = !getenv("TRC_HOST_NO_RAMP");
-    const size_t target = forced ? forced : (size_t)16 << 20;
-    size_t groups = forced || is_static(codec) ? target / ((size_t)chunk * 64) : TRC_MODEL_ROUND_CHUNKS / 64;
-    if (!forced && groups * 64 * (size_t)chunk > ((size_t)256 << 20)) groups = ((size_t)256 << 20) / ((size_t)chunk * 64);   // caller-fixed chunks above 4096: the staging slots stay <= 256 MB
-    // the order-1 coder keeps 136 KiB of model per chunk of a slice in the workspace: a 65 536-chunk slice would ask for 9 GB of it
-    // (ADVICE r3); 4 GiB of models = 30 000 chunks = 123 MB slices at chunk 4096, still one launch for the inputs it is used on
-    if (codec == TRC_ANSO1 && !forced && groups > ((size_t)4 << 30) / (64u * (size_t)TRC_O1_MODEL_BYTES)) groups = ((size_t)4 << 30) / (64u * (size_t)TRC_O1_MODEL_BYTES);
-    if (groups < 1) groups = 1;
-    size_t per = groups * 64;
-    while ((nchunks + per - 1) / per > 2000) per *= 2;                    // the totals area holds 2048 slices
-    auto part = [&](int sh) { size_t g = (per / 64) >> sh; return (g < 1 ? 1 : g) * 64; };
-    first.clear();
-    size_t c = 0;
-    std::vector<size_t> tail;
-    size_t left = nchunks;
-    size_t ramp_chunks = 0;
-    for (int sh = 3; sh >= 1; sh--) ramp_chunks += part(sh);                // part() never goes below one group: with small slice targets the
-    if (ramp && nchunks > 4 * per && nchunks > 2 * ramp_chunks + per) {     // ramps are longer than 7/8 of a slice each -- count what they really take
-        for (int sh = 3; sh >= 1; sh--) { first.push_back(c); c += part(sh); }   // up: per/8, per/4, per/2; the same coming down
-        for (int sh = 3; sh >= 1; sh--) tail.push_back(part(sh));
-        left = nchunks - 2 * ramp_chunks;
-    }
-    for (size_t done = 0; done < left; done += per) first.push_back(c + done);
-    c += left;
-    for (size_t k = tail.size(); k-- > 0;) { first.push_back(c); c += tail[k]; }      // largest first: per/2, per/4, per/8
-    first.push_back(nchunks);
-    const size_t all = (nchunks + 63) / 64 * 64;                            // a short call sizes its staging slots and workspace by what it has
-    return per < all ? per : all;
-}
-}  // namespace
-
-#define HCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fail(TRC_E_HIP, "%s -> %s", #x, hipGetErrorString(e_)); return 0; } } while (0)
-
-// ---- host-pointer encode/decode shared by every reference-signature export --------------------
-// chunk_override / outcap != 0: the trc_encode_host form -- explicit chunk size, and the container is returned whatever its
-// size (no folding into "== inlen means raw"); out holds outcap bytes
-static size_t host_encode(int codec, const unsigned char *in, size_t inlen, unsigned char *out,
-                          const cdf_t *cdf, int cdfnum, uint32_t chunk_override = 0, size_t outcap = 0)
-{
-    if (inlen == 0) return 0;
-    HostCtx *cp = nullptr;
-    if (ctx_get(cp)) return 0;
-    HostCtx &c = *cp;
-    std::lock_guard<std::mutex> lk(c.mu);
-    int dev = 0; HCHK(hipGetDevice(&dev));
-    if (ctx_init(c, dev)) return 0;
-    HostDrain guard(c);
-    uint32_t chunk = chunk_override ? chunk_override : trc_get_chunk();
-    if (!chunk) chunk = trc_auto_chunk_codec(codec, inlen);
-    if (!chunk_ok(chunk)) { fail(TRC_E_ARG, "chunk %u: must be a multiple of 64 in [%u,%u]", chunk, TRC_CHUNK_MIN, TRC_CHUNK_MAX); return 0; }
-    if (codec == TRC_ANSB && chunk > TRC_ANSB_CHUNK_MAX) chunk = TRC_ANSB_CHUNK_MAX;
-    if (codec == TRC_ANSO1 && chunk < 4096u && !chunk_override) chunk = 4096u;    // also under TRC_CHUNK / trc_set_chunk: see trc_auto_chunk_codec
-    const size_t nchunks = (inlen + chunk - 1) / chunk, dir = 4 * nchunks, hdrsz = sizeof(trc_container_hdr);
-    if (outcap && outcap < hdrsz + dir + inlen) { fail(TRC_E_ARG, "encode_host: out holds %zu bytes, the container may need %zu", outcap, hdrsz + dir + inlen); return 0; }
-    if (is_static(codec)) {
-        if (cdfnum <= 0) cdfnum = host_cdfnum(cdf);
-        if (cdfnum <= 0 || cdfnum > 256) { fail(TRC_E_CDF, "bad CDF (need cdf[0]=0 < ... < cdf[cdfnum]=32768)"); return 0; }
-    } else cdfnum = 0;
-    std::vector<size_t> sc;
-    const size_t per = slice_plan(codec, chunk, nchunks, sc), nsl = sc.size() - 1;
-    const size_t slice_bytes = per * (size_t)chunk;
-    const size_t wb = trc_work_bytes(codec, slice_bytes < inlen ? slice_bytes : inlen, chunk);
-    // page-locked caller buffers are read / written by DMA directly (no staging copy on that side)
-    const bool in_direct = host_is_pinned(in, inlen), out_direct = host_is_pinned(out, outcap ? outcap : inlen);
-    if (grow(&c.d_in, &c.cap_in, inlen) || grow(&c.d_cont, &c.cap_cont, hdrsz + dir + inlen + 64) || grow(&c.d_work, &c.cap_work, wb) ||
-        ((!in_direct || !out_direct) && grow_pins(c, slice_bytes + 4 * per + 64, nsl))) return 0;
-    uint16_t *d_cdf = (uint16_t *)c.d_small;
-    uint64_t *d_tot = (uint64_t *)(c.d_small + 2048);
-    uint32_t *d_clen = (uint32_t *)(c.d_cont + hdrsz);
-    uint8_t *d_payload = c.d_cont + hdrsz + dir;
-    int flags = 0;
-    if (cdfnum) {
-        HCHK(hipMemcpyAsync(d_cdf, cdf, (cdfnum + 1) * sizeof(cdf_t), hipMemcpyHostToDevice, c.s_k));
-        if (trc_tables_dev(d_cdf, (unsigned)cdfnum, c.d_work, c.cap_work, c.s_k)) return 0;
-        flags = TRC_TABLES_READY;
-    }
-    // Slice i: stage (copy threads) -> H2D (s_in) -> encode (s_k) -> size known (host) -> D2H (s_out) -> unstage.  The loop
-    // runs three stages at once: it stages slice i+1 and fetches slice i-1 while slice i is being coded.
-    size_t ppos = 0;                 // payload bytes already placed in `out`
-    size_t dpos = 0;                 // device payload offset of the next slice (each slice's payload starts 2-byte aligned: sums of even lengths... kept explicit)
-    bool raw = false;
-    const size_t lim = outcap ? (size_t)-1 : inlen > hdrsz + dir ? inlen - hdrsz - dir : 0;      // payload bytes above which the call returns raw
-    auto slice_off = [&](size_t i) { return sc[i] * (size_t)chunk; };
-    auto slice_len = [&](size_t i) { const size_t o = slice_off(i), e = i + 1 == nsl ? inlen : slice_off(i + 1); return e - o; };
-    auto put_in = [&](size_t i) -> bool {                                   // stage + H2D of slice i
-        const int k = (int)(i % TRC_NSLOT);
-        const size_t o = slice_off(i), l = slice_len(i);
-        if (in_direct) {
-            if (hipMemcpyAsync(c.d_in + o, in + o, l, hipMemcpyHostToDevice, c.s_in) != hipSuccess) return false;
-            return hipEventRecord(c.ev_in[k], c.s_in) == hipSuccess;
-        }
-        if (i >= TRC_NSLOT && hipEventSynchronize(c.ev_in[k]) != hipSuccess) return false;   // slot free: its last H2D is done
-        c.pool_in->copy(c.pin_in[k], in + o, l);
-        if (hipMemcpyAsync(c.d_in + o, c.pin_in[k], l, hipMemcpyHostToDevice, c.s_in) != hipSuccess) return false;
-        return hipEventRecord(c.ev_in[k], c.s_in) == hipSuccess;
-    };
-    struct Pending { size_t i, pos, tot; bool live; } pend = { 0, 0, 0, false };
-    auto fetch = [&](Pending &p) -> bool {                                  // unstage slice p.i (its D2H was enqueued earlier): starts the copy, returns
-        if (!p.live) return true;
-        p.live = false;
-        if (out_direct) return true;                                        // its D2H writes `out` itself; the stream is drained at the end
-        const int k = (int)(p.i % TRC_NSLOT);
-        if (hipEventSynchronize(c.ev_out[k]) != hipSuccess) return false;
-        const size_t nc = sc[p.i + 1] - sc[p.i];
-        memcpy(out + hdrsz + 4 * sc[p.i], c.pin_out[k], 4 * nc);
-        c.pool_out->start(out + hdrsz + dir + p.pos, c.pin_out[k] + 4 * per, p.tot);
-        p.live = false;
-        return true;
-    };
-    // staging runs TWO slices ahead of the coder (three staging slots): with one slice of look-ahead the H2D engine had
-    // nothing queued while the host staged the next slice -- the period was staging + coding instead of the copy time
-    if (!put_in(0) || (nsl > 1 && !put_in(1))) { fail(TRC_E_HIP, "host encode: staging failed"); return 0; }
-    for (size_t i = 0; i < nsl; i++) {
-        const int k = (int)(i % TRC_NSLOT);
-        const size_t o = slice_off(i), l = slice_len(i), c0 = sc[i];
-        HCHK(hipStreamWaitEvent(c.s_k, c.ev_in[k], 0));
-        if (trc_encode_dev(codec | flags, c.d_in + o, l, chunk, cdfnum ? d_cdf : nullptr, (unsigned)cdfnum, d_clen + c0, d_payload + dpos,
-                           d_tot + i, c.d_work, c.cap_work, c.s_k)) return 0;
-        HCHK(hipMemcpyAsync(c.pin_tot + i, d_tot + i, 8, hipMemcpyDeviceToHost, c.s_k));
-        HCHK(hipEventRecord(c.ev_k[k], c.s_k));
-        if (i + 2 < nsl && !put_in(i + 2)) { fail(TRC_E_HIP, "host encode: staging failed"); return 0; }   // overlaps slice i's kernels, slice i+1's H2D and slice i-1's way back
-        if (!fetch(pend)) { fail(TRC_E_HIP, "host encode: fetch failed"); return 0; }                         // slice i-1 has arrived: the out-pool copies it to `out` ...
-        HCHK(hipEventSynchronize(c.ev_k[k]));                                                                 // ... while this thread waits for slice i's size
-        const size_t tot = (size_t)c.pin_tot[i];
-        if (raw || ppos + tot >= lim) { raw = true; dpos += (tot + 1) & ~(size_t)1; continue; }               // (keep going: cheap, and the state stays simple)
-        const size_t nc = sc[i + 1] - c0;
-        // (slot k's previous content, slice i-3, left it two fetches ago: start() waits for the copy before it)
-        HCHK(hipStreamWaitEvent(c.s_out, c.ev_k[k], 0));
-        if (out_direct) {
-            HCHK(hipMemcpyAsync(out + hdrsz + 4 * c0, d_clen + c0, 4 * nc, hipMemcpyDeviceToHost, c.s_out));
-            HCHK(hipMemcpyAsync(out + hdrsz + dir + ppos, d_payload + dpos, tot, hipMemcpyDeviceToHost, c.s_out));
-        } else {
-            HCHK(hipMemcpyAsync(c.pin_out[k], d_clen + c0, 4 * nc, hipMemcpyDeviceToHost, c.s_out));
-            HCHK(hipMemcpyAsync(c.pin_out[k] + 4 * per, d_payload + dpos, tot, hipMemcpyDeviceToHost, c.s_out));
-        }
-        HCHK(hipEventRecord(c.ev_out[k], c.s_out));
-        pend = { i, ppos, tot, true };
-        ppos += tot;
-        dpos += (tot + 1) & ~(size_t)1;
-    }
-    if (!fetch(pend)) { fail(TRC_E_HIP, "host encode: fetch failed"); return 0; }
-    c.pool_out->wait();
-    HCHK(hipStreamSynchronize(c.s_in));
-    if (out_direct) HCHK(hipStreamSynchronize(c.s_out));
-    guard.ok = true;                                                        // everything of this call has landed
-    if (raw) { memcpy(out, in, inlen); return inlen; }                      // reference convention: == inlen => raw
-    trc_container_hdr h;
-    memset(&h, 0, sizeof h);
-    h.magic = TRC_MAGIC; h.codec = (uint8_t)codec; h.version = 1; h.cdfnum = (uint16_t)cdfnum;
-    h.chunk = chunk; h.nchunks = (uint32_t)nchunks; h.n = inlen; h.payload = ppos;
-    memcpy(out, &h, hdrsz);
-    return hdrsz + dir + ppos;
-}
-
-static size_t host_decode(int codec, const unsigned char *in, size_t outlen, unsigned char *out,
-                          const cdf_t *cdf, int cdfnum)
-{
-    if (outlen == 0) return 0;
-    HostCtx *cp = nullptr;
-    if (ctx_get(cp)) return 0;
-    HostCtx &c = *cp;
-    std::lock_guard<std::mutex> lk(c.mu);
-    int dev = 0; HCHK(hipGetDevice(&dev));
-    if (ctx_init(c, dev)) return 0;
-    HostDrain guard(c);
-    trc_container_hdr h;
-    memcpy(&h, in, sizeof h);
-    if (h.magic != TRC_MAGIC || h.version != 1 || h.codec != codec || h.n != outlen ||
-        !chunk_ok(h.chunk) || h.nchunks != (outlen + h.chunk - 1) / h.chunk || h.payload > outlen) {
-        fail(TRC_E_ARG, "not a TRC1 container for codec %d / length %zu (raw streams must be memcpy'd by the caller)", codec, outlen);
-        return 0;
-    }
-    const size_t hdrsz = sizeof h, nchunks = h.nchunks, dir = 4 * nchunks;
-    const uint32_t chunk = h.chunk;
-    // The prototype carries no input length, so this is a SELF-CONSISTENCY test of the container, not a bound on the caller's
-    // buffer: the length passed below is the one the header itself states.  It rejects truncated or inconsistent
-    // directories; a forged header can still make this function read up to outlen + 4 * nchunks + 32 bytes from `in`.
-    // Callers holding untrusted input must call trc_container_check(buf, REAL_LENGTH, ...) themselves first, as
-    // harness/trcfile.c does.
-    if (trc_container_check(in, hdrsz + dir + (size_t)h.payload, codec, outlen)) return 0;
-    if (is_static(codec)) {
-        if (cdfnum <= 0) cdfnum = host_cdfnum(cdf);
-        if (cdfnum <= 0 || cdfnum > 256) { fail(TRC_E_CDF, "bad CDF"); return 0; }
-    } else cdfnum = 0;
-    std::vector<size_t> sc;
-    const size_t per = slice_plan(codec, chunk, nchunks, sc), nsl = sc.size() - 1;
-    const size_t slice_bytes = per * (size_t)chunk;
-    const size_t wb = trc_work_bytes(codec, slice_bytes < outlen ? slice_bytes : outlen, chunk);
-    // page-locked caller buffers are read / written by DMA directly (no staging copy on that side)
-    const bool in_direct = host_is_pinned(in, hdrsz + dir + (size_t)h.payload), out_direct = host_is_pinned(out, outlen);
-    if (grow(&c.d_in, &c.cap_in, outlen) || grow(&c.d_cont, &c.cap_cont, hdrsz + dir + outlen + 64 + 2 * nsl) || grow(&c.d_work, &c.cap_work, wb) ||
-        ((!in_direct || !out_direct) && grow_pins(c, slice_bytes + 4 * per + 64, nsl))) return 0;
-    uint16_t *d_cdf = (uint16_t *)c.d_small;
-    uint32_t *d_clen = (uint32_t *)(c.d_cont + hdrsz);
-    uint8_t *d_payload = c.d_cont + hdrsz + dir;
-    int flags = 0;
-    if (cdfnum) {
-        HCHK(hipMemcpyAsync(d_cdf, cdf, (cdfnum + 1) * sizeof(cdf_t), hipMemcpyHostToDevice, c.s_k));
-        if (trc_tables_dev(d_cdf, (unsigned)cdfnum, c.d_work, c.cap_work, c.s_k)) return 0;
-        flags = TRC_TABLES_READY;
-    }
-    // payload bytes of every slice from the directory (the decoders clamp an entry above the chunk length to "raw")
-    std::vector<size_t> pstart(nsl + 1, 0);
-    for (size_t i = 0; i < nsl; i++) {
-        const size_t c0 = sc[i], c1 = sc[i + 1];
-        size_t sum = 0;
-        for (size_t k = c0; k < c1; k++) {
-            uint32_t l; memcpy(&l, in + hdrsz + 4 * k, 4);
-            const size_t len = (k + 1 == nchunks) ? outlen - k * (size_t)chunk : chunk;
-            sum += l < len ? l : len;
-        }
-        pstart[i + 1] = pstart[i] + sum;
-    }
-    auto slice_off = [&](size_t i) { return sc[i] * (size_t)chunk; };
-    auto slice_len = [&](size_t i) { const size_t o = slice_off(i), e = i + 1 == nsl ? outlen : slice_off(i + 1); return e - o; };
-    auto put_in = [&](size_t i) -> bool {                                   // stage + H2D of slice i's directory and payload
-        const int k = (int)(i % TRC_NSLOT);
-        const size_t c0 = sc[i], nc = sc[i + 1] - c0, pl = pstart[i + 1] - pstart[i];
-        if (in_direct) {
-            if (hipMemcpyAsync(d_clen + c0, in + hdrsz + 4 * c0, 4 * nc, hipMemcpyHostToDevice, c.s_in) != hipSuccess) return false;
-            if (hipMemcpyAsync(d_payload + ((pstart[i] + 1) & ~(size_t)1) + 2 * i, in + hdrsz + dir + pstart[i], pl, hipMemcpyHostToDevice, c.s_in) != hipSuccess) return false;
-            return hipEventRecord(c.ev_in[k], c.s_in) == hipSuccess;
-        }
-        if (i >= TRC_NSLOT && hipEventSynchronize(c.ev_in[k]) != hipSuccess) return false;
-        memcpy(c.pin_in[k], in + hdrsz + 4 * c0, 4 * nc);
-        c.pool_in->copy(c.pin_in[k] + 4 * per, in + hdrsz + dir + pstart[i], pl);
-        // (payload offsets may be odd only for corrupt directories; the device layer wants 2-byte alignment: keep the slice's own offset even)
-        if (hipMemcpyAsync(d_clen + c0, c.pin_in[k], 4 * nc, hipMemcpyHostToDevice, c.s_in) != hipSuccess) return false;
-        if (hipMemcpyAsync(d_payload + ((pstart[i] + 1) & ~(size_t)1) + 2 * i, c.pin_in[k] + 4 * per, pl, hipMemcpyHostToDevice, c.s_in) != hipSuccess) return false;
-        return hipEventRecord(c.ev_in[k], c.s_in) == hipSuccess;
-    };
-    struct Pending { size_t i; bool live; } pend = { 0, false };
-    auto fetch = [&](Pending &p) -> bool {
-        if (!p.live) return true;
-        p.live = false;
-        if (out_direct) return true;                                        // its D2H wrote `out` itself; the stream is drained at the end
-        const int k = (int)(p.i % TRC_NSLOT);
-        if (hipEventSynchronize(c.ev_out[k]) != hipSuccess) return false;
-        c.pool_out->start(out + slice_off(p.i), c.pin_out[k], slice_len(p.i));
-        return true;
-    };
-    if (!put_in(0) || (nsl > 1 && !put_in(1))) { fail(TRC_E_HIP, "host decode: staging failed"); return 0; }   // two slices ahead, as in host_encode
-    for (size_t i = 0; i < nsl; i++) {
-        const int k = (int)(i % TRC_NSLOT);
-        const size_t o = slice_off(i), l = slice_len(i), c0 = sc[i];
-        HCHK(hipStreamWaitEvent(c.s_k, c.ev_in[k], 0));
-        if (i >= TRC_NSLOT) HCHK(hipStreamWaitEvent(c.s_k, c.ev_out[k], 0));   // (d_in + o is private to the slice: nothing to wait for; kept for symmetry of the slots)
-        if (trc_decode_dev(codec | flags, d_clen + c0, d_payload + ((pstart[i] + 1) & ~(size_t)1) + 2 * i, l, chunk, cdfnum ? d_cdf : nullptr, (unsigned)cdfnum,
-                           c.d_in + o, c.d_work, c.cap_work, c.s_k)) return 0;
-        HCHK(hipEventRecord(c.ev_k[k], c.s_k));
-        // slice i's way back is queued BEFORE slice i-1 is copied out of its staging slot (different slots): the D2H
-        // engine never waits for the host
-        HCHK(hipStreamWaitEvent(c.s_out, c.ev_k[k], 0));
-        HCHK(hipMemcpyAsync(out_direct ? out + o : c.pin_out[k], c.d_in + o, l, hipMemcpyDeviceToHost, c.s_out));
-        HCHK(hipEventRecord(c.ev_out[k], c.s_out));
-        if (!fetch(pend)) { fail(TRC_E_HIP, "host decode: fetch failed"); return 0; }                         // slice i-1: out-pool copies it to `out` ...
-        if (i + 2 < nsl && !put_in(i + 2)) { fail(TRC_E_HIP, "host decode: staging failed"); return 0; }   // ... while slice i+2 is staged by the in-pool
-        pend = { i, true };
-    }
-    if (!fetch(pend)) { fail(TRC_E_HIP, "host decode: fetch failed"); return 0; }
-    c.pool_out->wait();
-    HCHK(hipStreamSynchronize(c.s_in));
-    if (out_direct) HCHK(hipStreamSynchronize(c.s_out));
-    guard.ok = true;
-    return outlen;
-}
+#include "trc_host.inc"
 
 // Page-lock a caller's buffer for the host-pointer calls (hipHostRegister / hipHostUnregister behind plain C: a harness needs
 // no HIP header).  Registration costs ~55 us per MB: once per buffer, not per call.
@@ -1018,16 +564,16 @@ int cdfini(unsigned char *in, size_t inlen, cdf_t *cdf, unsigned cdfnum)
     std::lock_guard<std::mutex> lk(c.mu);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || ctx_init(c, dev)) return -1;
-    if (grow(&c.d_in, &c.cap_in, inlen) || grow(&c.d_work, &c.cap_work, 4096)) return -1;
+    if (grow(&c.d_in, &c.cap_in, inlen) || grow(&c.d_work[0], &c.cap_work[0], 4096)) return -1;
     uint16_t *d_cdf = (uint16_t *)c.d_small;
     int32_t *d_status = (int32_t *)(c.d_small + 32768);
 #define ICHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fail(TRC_E_HIP, "%s -> %s", #x, hipGetErrorString(e_)); return -1; } } while (0)
-    ICHK(hipMemcpyAsync(c.d_in, in, inlen, hipMemcpyHostToDevice, c.s_k));
-    if (trc_cdfini_dev(c.d_in, inlen, d_cdf, cdfnum, d_status, c.d_work, c.s_k)) return -1;
+    ICHK(hipMemcpyAsync(c.d_in, in, inlen, hipMemcpyHostToDevice, c.s_k[0]));
+    if (trc_cdfini_dev(c.d_in, inlen, d_cdf, cdfnum, d_status, c.d_work[0], c.s_k[0])) return -1;
     int32_t st = -1;
-    ICHK(hipMemcpyAsync(&st, d_status, 4, hipMemcpyDeviceToHost, c.s_k));
-    ICHK(hipMemcpyAsync(cdf, d_cdf, (cdfnum + 1) * sizeof(cdf_t), hipMemcpyDeviceToHost, c.s_k));
-    ICHK(hipStreamSynchronize(c.s_k));
+    ICHK(hipMemcpyAsync(&st, d_status, 4, hipMemcpyDeviceToHost, c.s_k[0]));
+    ICHK(hipMemcpyAsync(cdf, d_cdf, (cdfnum + 1) * sizeof(cdf_t), hipMemcpyDeviceToHost, c.s_k[0]));
+    ICHK(hipStreamSynchronize(c.s_k[0]));
     if (st < 0) { fail(TRC_E_CDF, "cdfini: distribution cannot be normalised to a strictly increasing 15-bit CDF"); return -1; }
     return (int)inlen;
 }
