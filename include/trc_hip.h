@@ -94,16 +94,26 @@ const char *trc_last_error(void);
 int trc_device_count(void);
 
 /* chunk size of the host-pointer (reference-signature) calls, process-wide.  0 = automatic (the default): every call
- * takes trc_auto_chunk_codec(its coder, its input length).  Static coders (trc_auto_chunk): the largest of 4096 / 2048 /
- * 1024 / 512 that still fills the chip (one residency round of 196 608 chunks: >= 805 / 403 / 201 MB), 512 below.
- * Coders with a model per lane in LDS hold 4 waves per CU (a round is 65 536 chunks, which is also the slice their
- * host-pointer calls pipeline by): the larger chunk only when 16 such slices remain (>= 4.3 / 2.1 / 1 GB); order-1 rANS
- * always 4096.  trc_set_chunk(c) or TRC_CHUNK=c in the environment fix it; trc_set_chunk(0) returns to automatic.
- * Decoders take the size from the container. */
+ * takes trc_auto_chunk_codec(its coder, its input length) -- round 6: the LARGEST chunk of the ladder 512 .. 16 384 whose
+ * one-wave time still hides behind the call's PCIe time (budget max(1.7 ms, 0.35 n / 50 GB/s)); what the caller of these
+ * functions sees is the stored size and a PCIe-bound rate, and every chunk costs coder state, a directory entry and, for
+ * the adaptive coders, a model that starts from scratch.  100 MB: 4096 for the static and the adaptive byte coders, 2048
+ * for the bitwise ones; 1 GB: 16 384 (rccdfenc on drift: 26.9 % stored against 26.7 % for one whole-buffer call of the
+ * reference; at chunk 512 it was 38.7 %).  Static coders stop at 4096, the bitwise rANS at one reference block (8192), the
+ * order-1 rANS never goes below 4096.  trc_set_chunk(c) or TRC_CHUNK=c in the environment fix it; trc_set_chunk(0)
+ * returns to automatic.  Decoders take the size from the container. */
 int      trc_set_chunk(uint32_t chunk);
 uint32_t trc_get_chunk(void);
-uint32_t trc_auto_chunk(size_t n);
+uint32_t trc_auto_chunk(size_t n);                   /* = trc_auto_chunk_codec(TRC_ANS4S, n): the static coders' rule */
 uint32_t trc_auto_chunk_codec(int codec, size_t n);
+/* The devices of the host-pointer calls.  Default (ndev = 0, TRC_DEVICES unset): the caller's current device.  With a list --
+ * trc_set_devices, or TRC_DEVICES="all" / "0,1,2,3" in the environment -- every call is cut into contiguous shards of whole
+ * chunk groups, one per list entry, coded at the same time (one pipeline and one host thread per entry) and written straight
+ * to their places in the caller's buffer: the result is byte-identical to the one-device container, and it is how a
+ * single-threaded caller such as the reference harness (turborc.c:420-579) uses all GPUs of a node.  An entry may repeat (two
+ * pipelines on one device: what the tests do on a one-GPU box).  trc_get_devices returns the list length. */
+int trc_set_devices(const int *devs, int ndev);
+int trc_get_devices(int *devs, int cap);
 /* the chunk for a DEVICE-RESIDENT call of n bytes (one launch over the whole input): the largest multiple of 64 <= 4096 that
  * makes the input a whole number of residency rounds of the coder's lanes, barely (a launch lasts rounds x one wave's time:
  * 100 MB of the model-per-lane coders at 1280 instead of 1536 is half the throughput).  What bench.py runs every coder at. */

@@ -90,6 +90,8 @@ def lib():
         l.trc_timing_read.restype = C.c_int
         l.trc_timing_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         l.trc_kernel_name.restype = C.c_char_p; l.trc_kernel_name.argtypes = [C.c_int, C.c_int]
+        l.trc_set_devices.restype = C.c_int; l.trc_set_devices.argtypes = [C.POINTER(C.c_int), C.c_int]
+        l.trc_get_devices.restype = C.c_int; l.trc_get_devices.argtypes = [C.POINTER(C.c_int), C.c_int]
         _lib = l
     return _lib
 
@@ -268,6 +270,12 @@ def host_decode(codec, comp, n, cdf=None, cdfnum=256, name=None):
     if l != n:
         raise TrcError(lib().trc_last_error().decode())
     return out[:n].copy()
+
+
+def set_devices(devs):
+    """devices of the host-pointer calls ([] = the caller's current device; an entry may repeat: include/trc_hip.h)"""
+    arr = (C.c_int * max(len(devs), 1))(*devs)
+    _chk(lib().trc_set_devices(arr, len(devs)))
 
 
 def host_cdfini(data, cdfnum=None):
