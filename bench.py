@@ -221,19 +221,98 @@ def beyond_cache_leg(torch, trc, T, codec, chunk, dev, steps=5, warmup=2, n=1000
             "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4)}
 
 
+def host_pointer_leg(trc, T, rank, runs=7):
+    """What a drop-in caller sees (SURVEY 8d / BASELINE.md 3: "end-to-end time including H2D/D2H through the host-pointer API"): the
+    reference-named functions called with HOST pointers on 100 MB -- anscdf4senc/anscdf4sdec on text100m, rccdfenc/rccdfdec on
+    drift100m -- chunk chosen by the library (trc_auto_chunk_codec), timed around the whole call like the reference's harness does
+    (include_/time_.h:174-213, min over runs), with pageable buffers (what a malloc-ing caller has) and with page-locked ones
+    (trc_host_pin: DMA straight from / to the caller's memory).  The caller is harness/trcbench -- plain C against include/*.h, the
+    shape of the reference's bench() -- started on the workload written to a temporary file; without the binary, the same calls
+    through ctypes from this process.  ratio_container = bytes the call returned / input bytes; ratio_reference_whole_buffer = ONE
+    call of the reference function over the whole input (tests/golden/bench_configs.json)."""
+    import ctypes as C
+    import re
+    import tempfile
+    lib = trc.lib()
+    n = 100 * 1000 * 1000
+    whole = {}
+    gold = os.path.join(ROOT, "tests", "golden", "bench_configs.json")
+    if os.path.exists(gold):
+        for e in json.load(open(gold)):
+            if "whole_buffer_bytes" in e and e["n"] == n:
+                whole[(e["codec"], e["kind"])] = e["whole_buffer_bytes"]
+    exe = os.path.join(ROOT, "harness", "trcbench")
+    use_c = os.path.exists(exe)
+    out = {"bytes": n, "runs": runs, "caller": "harness/trcbench (plain C, include/turborc.h + include/anscdf.h)" if use_c else "ctypes from bench.py",
+           "timed": "wall clock around the whole call, min over runs (PCIe both ways included); MB = 10^6"}
+    u8p = C.POINTER(C.c_uint8)
+    for name, codec, kind, hid in (("anscdf4senc", trc.ANS4S, "text", 65), ("rccdfenc", trc.RCA, "drift", 46)):
+        d, wname = make_input(n, rank, kind)
+        res = {"workload": wname, "chunk": int(lib.trc_auto_chunk_codec(codec, n))}
+        if use_c:
+            with tempfile.NamedTemporaryFile(suffix=".bin") as f:
+                d.tofile(f); f.flush()
+                for mode, flag in (("pageable", []), ("pinned", ["--pin"])):
+                    r = subprocess.run([exe, "-I", str(runs), "-e", str(hid)] + flag + [f.name], capture_output=True, text=True, timeout=300)
+                    m = re.search(r"^\s*(\d+)\s+[\d.]+%%\s+([\d.]+)\s+([\d.]+)\s+%d:" % hid, r.stdout, re.M)
+                    if r.returncode != 0 or not m or "MISMATCH" in r.stdout:
+                        raise RuntimeError("trcbench -e %d failed: %s" % (hid, (r.stdout + r.stderr)[-300:]))
+                    l, e_, d_ = int(m.group(1)), float(m.group(2)), float(m.group(3))
+                    res[mode] = {"enc_MBps": round(e_, 1), "dec_MBps": round(d_, 1), "encdec_MBps": round(1.0 / (1.0 / e_ + 1.0 / d_), 1)}
+        else:
+            lib.trc_host_pin.restype = C.c_int; lib.trc_host_pin.argtypes = [C.c_void_p, C.c_size_t]
+            lib.trc_host_unpin.restype = C.c_int; lib.trc_host_unpin.argtypes = [C.c_void_p]
+            cdf = None
+            if codec in trc.STATIC:
+                r, cdf, _ = trc.host_cdfini(d, 256)               # untimed, as in the reference harness (turborc.c:429-433)
+                assert r == n
+            enc = trc._host_fn(trc._HOST_ENC[codec], codec)
+            dec = trc._host_fn(trc._HOST_DEC[codec], codec)
+            comp = np.zeros(n + n // 3 + 1024, dtype=np.uint8)     # the harness's OSIZE (turborc.c:418)
+            back = np.zeros(n + 1024, dtype=np.uint8)
+            args_e = [d.ctypes.data_as(u8p), n, comp.ctypes.data_as(u8p)]
+            args_d = [comp.ctypes.data_as(u8p), n, back.ctypes.data_as(u8p)]
+            if codec == trc.ANS4S:
+                args_e.append(cdf.ctypes.data_as(C.POINTER(C.c_uint16))); args_d.append(args_e[-1])
+            for mode in ("pageable", "pinned"):
+                if mode == "pinned":
+                    for a in (d, comp, back):
+                        assert lib.trc_host_pin(a.ctypes.data, a.nbytes) == 0, lib.trc_last_error()
+                te = td = 1e9
+                for _ in range(runs):
+                    t0 = time.perf_counter(); l = enc(*args_e); t1 = time.perf_counter()
+                    assert 0 < l < n, (name, l)
+                    k = dec(*args_d); t2 = time.perf_counter()
+                    assert k == n
+                    te, td = min(te, t1 - t0), min(td, t2 - t1)
+                assert np.array_equal(back[:n], d), name + ": round trip through the host-pointer calls failed"
+                res[mode] = {"enc_MBps": round(n / te / 1e6, 1), "dec_MBps": round(n / td / 1e6, 1), "encdec_MBps": round(n / (te + td) / 1e6, 1)}
+                if mode == "pinned":
+                    for a in (d, comp, back):
+                        lib.trc_host_unpin(a.ctypes.data)
+        res["container_bytes"] = int(l)
+        res["ratio_container"] = round(l / n, 5)
+        w = whole.get((trc.CODEC_NAMES[codec], kind))
+        res["ratio_reference_whole_buffer"] = round(w / n, 5) if w and "ENWIK8" not in os.environ and "ENWIK8BWT" not in os.environ else None
+        out[name] = res
+    return out
+
+
 # BASELINE.json's other single-GPU configurations, so that the driver's BENCH record carries a driver-timed number for each of them
 # (VERDICT r4 #7): config 3 = adaptive-CDF byte coders (rccdf = -e46 literal, anscdf = -e56), config 4 = rcs (-e1), and rccdfs2 =
 # what configs 1 / 2 literally name (-e45).  Each is THIS script run once more in its own process on the coder's own workload and the
 # library's chunk, short (10 timed steps after a 100 ms clock preamble), no CPU leg; the sub-object keeps the fields a reader needs.
 # (anscdf1 -- SURVEY 8f rank 2, not a BASELINE configuration -- rides along since the end of round 5: the coder VERDICT r4 listed first under "weak".)
-OTHER_CONFIGS = ("rccdfs2", "rccdf", "anscdf", "rcs", "anscdf1")
+# Round 6: `anscdf4s_chunk4096` -- the headline coder at SURVEY 8d config 2's stated default chunk (24 414 chunks = 382 waves on 1 024
+# SIMDs): the other end of the chunk trade-off, driver-timed next to the headline's chunk 512.
+OTHER_CONFIGS = ("anscdf4s_chunk4096", "rccdfs2", "rccdf", "anscdf", "rcs", "anscdf1")
 
 
 def other_configs():
     out = {}
     for name in OTHER_CONFIGS:
-        cmd = [sys.executable, os.path.abspath(__file__), "--codec", name, "--steps", "10", "--warmup", "2", "--clock-warmup-ms", "100",
-               "--no-cpu", "--no-beyond", "--no-cold", "--no-configs"]
+        cmd = [sys.executable, os.path.abspath(__file__), "--codec", name.split("_chunk")[0], "--steps", "10", "--warmup", "2", "--clock-warmup-ms", "100",
+               "--no-cpu", "--no-beyond", "--no-cold", "--no-configs", "--no-host"] + (["--chunk", name.split("_chunk")[1]] if "_chunk" in name else [])
         t0 = time.perf_counter()
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=180)
@@ -244,7 +323,7 @@ def other_configs():
                          "workload": j["config"]["workload"], "chunk": j["config"]["chunk"],
                          "enc_kernel_ms": rf["enc_kernel_ms"], "dec_kernel_ms": rf["dec_kernel_ms"],
                          "roofline": {"kernel": rf["kernel"], "achieved": rf["achieved"], "peak": rf["peak"], "unit": rf["unit"], "frac": rf["frac"],
-                                      "traffic": rf["traffic"], "traffic_source": rf["traffic_source"]},
+                                      "traffic": rf["traffic"], "traffic_source": rf["traffic_source"], "step_frac": rf.get("step_frac"), "enc_path": rf.get("enc_path")},
                          "ratio_container": j["config"]["ratio_container"], "ratio_reference_whole_buffer": j["config"]["ratio_reference_whole_buffer"],
                          "payload_matches_reference_sha256": j.get("payload_matches_reference_sha256"),
                          "wall_s": round(time.perf_counter() - t0, 1)}
@@ -335,6 +414,7 @@ def main():
                          "+9 %% at chunk 512, +31 %% at chunk 1024, profiles/r02_notes.md -- with longer per-kernel times)")
     ap.add_argument("--no-beyond", action="store_true", help="default workload, N = 1: skip the beyond-cache leg (the same step on 1 GB generated on the device)")
     ap.add_argument("--dry-launch", action="store_true", help="with --gpus N > 1 and no WORLD_SIZE: print the launch (command, environment) as JSON and exit")
+    ap.add_argument("--no-host", action="store_true", help="default line, N = 1: skip the host_pointer leg (the reference-named calls on host buffers, PCIe included)")
     ap.add_argument("--no-configs", action="store_true", help="default line, N = 1: skip the `configs` sub-objects (BASELINE configs 3 / 4 and the -e45 literal, "
                     "each a short run of this script in its own process after the headline leg)")
     args = ap.parse_args()
@@ -518,6 +598,7 @@ def main():
     trc.timing_pause(False)
     enc_ms, enc_cnt = trc.timing_read(False)
     dec_ms, dec_cnt = trc.timing_read(True)
+    gat_ms, gat_cnt = trc.timing_read(2)                       # the encode path's scan + gather kernels
 
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -576,18 +657,21 @@ def main():
         # dominant kernel = the slower of the two directions' coder kernels; algorithmic bytes = N + C per launch
         dom = "enc" if enc_avg >= dec_avg else "dec"
         dom_ms = max(enc_avg, dec_avg)
+        gat_avg = gat_ms / max(gat_cnt, 1)
         alg_bytes = n + total_c
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes of this same command
         # (scripts/gpu_profile_round.sh -> scripts/pmc_traffic.py -> profiles/pmc_traffic.json): counters cannot be read
         # from inside the timed process, so the line names where the figure was taken (`traffic_source`)
-        traffic = traffic_source = None
+        traffic = traffic_source = gather_traffic = enc_traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
                 if n == 100 * 1000 * 1000 and args.workload == "default":   # the PMC passes were taken on the default workload
                     tj = json.load(open(tpath))
                     traffic = tj.get("%s_%s_chunk%d" % (args.codec, dom, chunk))
+                    gather_traffic = tj.get("gather_chunk%d" % chunk) if args.codec == "anscdf4s" else None
+                    enc_traffic = tj.get("%s_enc_chunk%d" % (args.codec, chunk))
                     if traffic is not None:
                         traffic_source = "profiles/pmc_traffic.json (%s)" % tj.get("source" if args.codec == "anscdf4s" else "source_cfg34",
                                                                                     "rocprofv3 --pmc passes of `python bench.py`, TCC_EA0_RDREQ/WRREQ by request size")
@@ -609,7 +693,8 @@ def main():
                        "ratio_container": round((32 + 4 * ((n + chunk - 1) // chunk) + total_c) / n, 5), "ratio_reference_whole_buffer": None,
                        "steps_in_flight": inflight, "exchange_group_steps": G if use_dist else None, "exchange_lag_steps": (pipe.lag if pipe is not None else None),
                        "exchange": ("none" if world == 1 else "rccl gather of every step's payloads, root rotating over the ranks, %d steps per grouped exchange" % G if rotate else "rccl gather of payloads to rank 0")},
-            "flags": ["TABLES_READY", "DIR_READY"] if (codec in trc.STATIC and DIRR) else (["DIR_READY"] if DIRR else (["TABLES_READY"] if codec in trc.STATIC else [])),
+            "flags": (["TABLES_READY"] if codec in trc.STATIC else []) + (["DIR_READY"] if DIRR else []) +
+                     (["CLOCK_WARMUP: `value` is measured after an untimed preamble of %d steps (%.0f ms) of the same step; value_cold_clocks is the W + K protocol without it" % (pre_steps, args.clock_warmup_ms)] if pre_steps else []),
             "value_cold": round(cold[0], 1) if cold else None,
             "ms_per_step_cold": round(cold[1], 4) if cold else None,
             "clock_warmup": {"ms": args.clock_warmup_ms, "steps": pre_steps,
@@ -623,6 +708,16 @@ def main():
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "alg_bytes_per_launch": alg_bytes,
+                         # round 6 (VERDICT r5 "next" 2b): the whole step and the encode DIRECTION, not only the slower coder kernel.  step_frac
+                         # = 2 (N + C) / ms_per_step / peak (everything a step launches, launch gaps included); enc_path = (N + C) / (encoder
+                         # kernels + scan + gather): the payload gather is part of producing the compressed bytes and is timed with its own
+                         # event pairs (trc_timing_read class 2)
+                         "step_frac": round(2 * alg_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "enc_path": {"achieved": round(alg_bytes / ((enc_avg + gat_avg) * 1e-3) / 1e9, 1) if enc_avg + gat_avg > 0 else None,
+                                      "frac": round(alg_bytes / ((enc_avg + gat_avg) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if enc_avg + gat_avg > 0 else None,
+                                      "gather_kernel_ms": round(gat_avg, 4), "gather_launches_timed": gat_cnt,
+                                      "traffic": (enc_traffic + gather_traffic) if (enc_traffic and gather_traffic) else None,
+                                      "gather_traffic": gather_traffic},
                          "enc_kernel_ms": round(enc_avg, 4), "dec_kernel_ms": round(dec_avg, 4), "launches_timed": enc_cnt,
                          "timed": "HIP event pairs on the coder-kernel launches of every %s timed step (two-pass encoders: both passes summed); directory and gather kernels are in ms_per_step only" % ("" if te == 1 else {2: "2nd", 3: "3rd"}.get(te, "%dth" % te))},
         }
@@ -646,6 +741,11 @@ def main():
             res["beyond_cache"] = beyond_cache_leg(torch, trc, T, codec, chunk, dev)
             res["roofline"]["frac_beyond_l3"] = res["beyond_cache"]["frac"]
             res["roofline"]["note_l3"] = "frac is measured on the 100 MB workload, which (with its 64.5 MB payload) fits the 256 MiB Infinity Cache; frac_beyond_l3 is the same kernel on 1 GB"
+        if world == 1 and default_metric and not args.no_host and not args.no_cpu and not args.no_beyond and inflight == 1:
+            try:                                               # (a failed leg must not take the headline line with it)
+                res["host_pointer"] = host_pointer_leg(trc, T, rank)
+            except Exception as e:
+                res["host_pointer"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         if world == 1 and default_metric and not args.no_configs and not args.no_cpu and not args.no_beyond and inflight == 1:
             res["configs"] = other_configs()                   # (the full default line only: the measuring scripts pass --no-cpu / --no-beyond)
         if world == 1 and not args.no_cpu:

@@ -226,7 +226,9 @@ int trc_container_check(const void *buf, size_t buflen, int codec, size_t outlen
  * rANS encoders and the order-1 model fill included (the directory/gather kernels are not coder kernels).
  * enable(1) resets the counters; read() waits for the recorded events and returns the summed duration and the
  * number of encode (decode) CALLS measured: total_ms / launches = coder-kernel time of one call (at most 4096
- * kernel launches per direction between two enable() calls).  Thread-safe. */
+ * kernel launches per direction between two enable() calls).  `decode` = 2 reads the third class: the encode path's own
+ * directory work (group scan on large inputs, payload gather), so that (N + C) / (coder + gather) is a measured quantity.
+ * Thread-safe. */
 int trc_timing_enable(int on);
 int trc_timing_pause(int paused);   /* suspend (1) / resume (0) the event pairs without resetting what was collected: time a SAMPLE of the calls */
 int trc_timing_read(int decode, double *total_ms, int *launches);

@@ -120,6 +120,9 @@ def test_host_layer_multi_device(torch_cuda, codec):
         for devs in ([0, 0], [0, 0, 0], [0, 0, 0, 0, 0]):
             trc.set_devices(devs)
             for (d, cdf, cdfnum, comp) in single:
+                if codec in trc.STATIC:                    # cdfini over the list: per-pipeline histograms summed on the host -> the same CDF
+                    r, cdf2, _ = trc.host_cdfini(d, cdfnum)
+                    assert r == d.size and np.array_equal(cdf2[:cdfnum + 1], cdf[:cdfnum + 1]), (devs, d.size, "cdfini over the device list")
                 multi = trc.host_encode(codec, d, cdf, cdfnum)
                 assert multi.size == comp.size and np.array_equal(multi, comp), (devs, d.size, "container differs from the one-device call")
                 if comp.size != d.size:

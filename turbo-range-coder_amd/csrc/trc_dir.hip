@@ -92,7 +92,7 @@ __global__ __launch_bounds__(1024) void trc_scan_groups_kernel(const u32 *__rest
 }
 void trc_launch_scan_groups(const uint32_t *gsum, uint32_t ngroups, uint64_t *goff, uint64_t *d_total, hipStream_t s)
 {
-    hipLaunchKernelGGL(trc_scan_groups_kernel, dim3(1), dim3(1024), 0, s, gsum, ngroups, goff, d_total);
+    TRC_LAUNCH_TIMED(trc_scan_groups_kernel, dim3(1), dim3(1024), 0, s, gsum, ngroups, goff, d_total);
 }
 
 // Payload gather: one workgroup per group of 64 chunks moves the group's bytes to payload + base as dst-aligned
@@ -231,11 +231,11 @@ void trc_launch_gather(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcW
                        const uint32_t *d_clen, uint8_t *d_payload, uint64_t *d_total, hipStream_t s)
 {
     if (from_end >= 2)                                         // two pieces per chunk: mode 2 (two regions) or 3 (both ends of one region)
-        hipLaunchKernelGGL(trc_gather_kernel<2>, dim3(w.ngroups), dim3(256), 0, s, d_in, (u64)n, chunk, w.nchunks,
+        TRC_LAUNCH_TIMED((trc_gather_kernel<2>), dim3(w.ngroups), dim3(256), 0, s, d_in, (u64)n, chunk, w.nchunks,
                            w.scratch, w.stride, from_end >= 3 ? from_end : 0, w.scratch2, w.stride2, w.aux, d_clen, w.goff, w.gsum, w.ngroups,
                            d_payload, w.goff ? (u64 *)nullptr : d_total, w.goff ? (u64 *)nullptr : w.goff_area);
     else
-        hipLaunchKernelGGL(trc_gather_kernel<1>, dim3(w.ngroups), dim3(256), 0, s, d_in, (u64)n, chunk, w.nchunks,
+        TRC_LAUNCH_TIMED((trc_gather_kernel<1>), dim3(w.ngroups), dim3(256), 0, s, d_in, (u64)n, chunk, w.nchunks,
                            w.scratch, w.stride, from_end, w.scratch2, w.stride2, w.aux, d_clen, w.goff, w.gsum, w.ngroups,
                            d_payload, w.goff ? (u64 *)nullptr : d_total, w.goff ? (u64 *)nullptr : w.goff_area);
 }

@@ -115,9 +115,9 @@ def timing_pause(paused=True):
 
 
 def timing_read(decode):
-    """-> (total_ms, launches) of the coder kernel since timing_enable()"""
+    """-> (total_ms, launches) of the coder kernels since timing_enable(); decode = 2: the encode path's scan + gather kernels"""
     ms, cnt = C.c_double(0), C.c_int(0)
-    _chk(lib().trc_timing_read(1 if decode else 0, C.byref(ms), C.byref(cnt)))
+    _chk(lib().trc_timing_read(2 if decode == 2 else 1 if decode else 0, C.byref(ms), C.byref(cnt)))
     return ms.value, cnt.value
 
 
