@@ -414,6 +414,12 @@ def main():
                          "+9 %% at chunk 512, +31 %% at chunk 1024, profiles/r02_notes.md -- with longer per-kernel times)")
     ap.add_argument("--no-beyond", action="store_true", help="default workload, N = 1: skip the beyond-cache leg (the same step on 1 GB generated on the device)")
     ap.add_argument("--dry-launch", action="store_true", help="with --gpus N > 1 and no WORLD_SIZE: print the launch (command, environment) as JSON and exit")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the exchange: nccl (= RCCL, the product path) or gloo with the device tensors staged through "
+                         "host memory (shard.StagedDist): the device-side schedule against real peer processes where RCCL has no peer")
+    ap.add_argument("--same-device", action="store_true", help="every rank on cuda:0 (with --backend gloo: N ranks rehearse the N-GPU schedule on one GPU)")
+    ap.add_argument("--verify-gather", action="store_true",
+                    help="N > 1: after the timed region, 2 more groups of steps with every root hashing what it received against the SHA-256 each owner computed of its own result")
     ap.add_argument("--no-host", action="store_true", help="default line, N = 1: skip the host_pointer leg (the reference-named calls on host buffers, PCIe included)")
     ap.add_argument("--no-configs", action="store_true", help="default line, N = 1: skip the `configs` sub-objects (BASELINE configs 3 / 4 and the -e45 literal, "
                     "each a short run of this script in its own process after the headline leg)")
@@ -436,15 +442,24 @@ def main():
     if world != args.gpus and not (world == 1 and args.gpus <= 1):
         sys.exit("bench.py --gpus %d inside a job of WORLD_SIZE=%d: the two must agree" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU: libturborc_hip has no CPU path"
+    if args.same_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     use_dist = world > 1 or args.force_dist
     if use_dist:
-        import torch.distributed as dist
+        import torch.distributed as tdist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "gloo":
+            tdist.init_process_group("gloo", rank=rank, world_size=world)
+            dist = shard.StagedDist(tdist, torch)              # device tensors staged through host memory: a rehearsal transport
+        else:
+            if args.same_device and world > 1:
+                sys.exit("--same-device with RCCL: one communicator cannot hold two ranks of one GPU; use --backend gloo")
+            tdist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist = tdist
 
     codec = {v: k for k, v in trc.CODEC_NAMES.items()}[args.codec]
     n = args.size or (1000 * 1000 * 1000 if args.workload == "zipf1g" else 100 * 1000 * 1000)
@@ -506,15 +521,21 @@ def main():
     own = (dc.clen, dc.payload, dc.total)
     pipe = None
     if use_dist:
-        def new_result():
-            return (torch.zeros_like(dc.clen), torch.zeros_like(dc.payload), torch.zeros_like(dc.total))
-        banks = [[new_result() for _ in range(G)] for _ in range(2)]
-        banks[0][0] = own
+        # (total, chunks) of every step of a bank sit in ONE tensor: the encoder writes a step's total into its row, the chunk count is
+        # written once, and a group's exchange all-gathers the rows as they are (shard.exchange_group `meta`: no kernel of its own)
+        metas = [torch.zeros(G, 2, dtype=torch.int64, device=dev) for _ in range(2)]
+        for mt in metas:
+            mt[:, 1] = nch
+
+        def new_result(b, j):
+            return (torch.zeros_like(dc.clen), torch.zeros_like(dc.payload), metas[b][j, 0:1])
+        banks = [[new_result(b, j) for j in range(G)] for b in range(2)]
+        own = banks[0][0]
         recv = [None, None]
         if world > 1 and (rotate or rank == 0):                # this rank is the root of one step per group
             recv = [([torch.empty(nch, dtype=torch.int32, device=dev) for _ in range(world - 1)],
                      [torch.empty(n + 1024, dtype=torch.uint8, device=dev) for _ in range(world - 1)]) for _ in range(2)]
-        pipe = shard.StepPipeline(dist, rank, world, G, banks, recv, nch, shard.CudaRuntime(torch, dev), rotate=rotate, lag=args.lag)
+        pipe = shard.StepPipeline(dist, rank, world, G, banks, recv, nch, shard.CudaRuntime(torch, dev), rotate=rotate, lag=args.lag, metas=metas)
 
     def step(k, last):
         if pipe is None:
@@ -626,6 +647,36 @@ def main():
         cold = (n * ksteps / cdt / 1e6, cdt / ksteps * 1e3, ksteps)
     trc.timing_enable(False)
 
+    # ---- after the clock (N > 1): every root hashes what it receives against the hash each owner computed of its own result ----
+    gather_check = None
+    if pipe is not None and world > 1 and args.verify_gather:
+        torch.cuda.synchronize(dev)
+        own_res = pipe.banks[0][0]
+        tot0 = int(own_res[2][0].item())
+        mine_sha = hashlib.sha256(own_res[0][:nch].cpu().numpy().tobytes() + own_res[1][:tot0].cpu().numpy().tobytes()).hexdigest()
+        owners = [None] * world
+        dist.all_gather_object(owners, mine_sha)
+        seen = {"steps": 0, "pieces": 0, "bad": []}
+
+        def on_gathered(first, sizes, got):
+            torch.cuda.current_stream(dev).synchronize()       # (the hook runs on the side stream, behind the group's transfers)
+            for j, (cl, pl) in got.items():
+                seen["steps"] += 1
+                for r in range(world):
+                    h = hashlib.sha256(cl[r].cpu().numpy().tobytes() + pl[r].cpu().numpy().tobytes()).hexdigest()
+                    seen["pieces"] += 1
+                    if h != owners[r]:
+                        seen["bad"].append((first + j, r))
+        pipe.on_gathered = on_gathered
+        vsteps = 2 * G + (1 if G > 1 else 0)                   # two full groups (both banks) and a ragged last one
+        run_untimed(vsteps)
+        pipe.on_gathered = None
+        allseen = [None] * world
+        dist.all_gather_object(allseen, seen)
+        gather_check = {"steps_run": vsteps, "steps_checked_on_their_roots": sum(s["steps"] for s in allseen), "pieces_hashed": sum(s["pieces"] for s in allseen),
+                        "mismatches": sum(len(s["bad"]) for s in allseen), "ok": all(not s["bad"] for s in allseen) and sum(s["steps"] for s in allseen) == vsteps}
+        assert gather_check["ok"], "gathered pieces differ from their owners' results: %s" % allseen
+
     last_result = own if pipe is None else pipe.banks[shard.group_plan(args.steps - 1, G, True)[1]][shard.group_plan(args.steps - 1, G, True)[0]]
     total_c = int(last_result[2][0].item())
     sha = clen_sha = None
@@ -692,6 +743,8 @@ def main():
                        # next to ONE call of the reference function over the whole input (filled in below from the committed fixture)
                        "ratio_container": round((32 + 4 * ((n + chunk - 1) // chunk) + total_c) / n, 5), "ratio_reference_whole_buffer": None,
                        "steps_in_flight": inflight, "exchange_group_steps": G if use_dist else None, "exchange_lag_steps": (pipe.lag if pipe is not None else None),
+                       "exchange_schedule": (None if not use_dist else "rotate" if rotate else "root0"), "exchange_backend": (None if not use_dist else "rccl" if args.backend == "nccl" else "gloo, device tensors staged through host memory (rehearsal of the schedule, not a transport)"),
+                       "ranks_share_device": bool(args.same_device and world > 1),
                        "exchange": ("none" if world == 1 else "rccl gather of every step's payloads, root rotating over the ranks, %d steps per grouped exchange" % G if rotate else "rccl gather of payloads to rank 0")},
             "flags": (["TABLES_READY"] if codec in trc.STATIC else []) + (["DIR_READY"] if DIRR else []) +
                      (["CLOCK_WARMUP: `value` is measured after an untimed preamble of %d steps (%.0f ms) of the same step; value_cold_clocks is the W + K protocol without it" % (pre_steps, args.clock_warmup_ms)] if pre_steps else []),
@@ -723,6 +776,8 @@ def main():
         }
         if checked is not None:
             res["oracle_checked_chunks"] = checked
+        if gather_check is not None:
+            res["gather_check"] = gather_check
         gold = os.path.join(ROOT, "tests", "golden", "bench_configs.json")
         if args.workload == "default" and os.path.exists(gold) and "ENWIK8" not in os.environ:
             for e in json.load(open(gold)):

@@ -118,10 +118,13 @@ def test_group_exchange_with_rotating_roots(world, nbatch):
     assert res == [(j, True) for j in range(nbatch)]
 
 
-def _pipeline_worker(rank, world, port, group, steps, prealloc, q, lag=1):
-    """bench.py's N>1 schedule (shard.StepPipeline) with CPU tensors: the oracle stands in for the HIP coder"""
+def _pipeline_worker(rank, world, port, group, steps, prealloc, q, lag=1, staged=False):
+    """bench.py's N>1 schedule (shard.StepPipeline) with CPU tensors: the oracle stands in for the HIP coder.
+    staged: through shard.StagedDist (the adapter `bench.py --backend gloo` puts between the pipeline and gloo) and with the
+    (total, chunks) rows of a bank in one tensor (`metas`), as bench.py keeps them since round 6"""
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    xdist = shard.StagedDist(dist, torch) if staged else dist
     try:
         codec, n, chunk = T.ANS4S, 40001, 1024
         start, ln = shard.shard_bounds(n, world, chunk)[rank]
@@ -135,6 +138,12 @@ def _pipeline_worker(rank, world, port, group, steps, prealloc, q, lag=1):
             return (torch.zeros(nch + 8, dtype=torch.int32), torch.zeros(cap, dtype=torch.uint8), torch.zeros(2, dtype=torch.int64))
         rotate = group > 1
         banks = [[new_result() for _ in range(group)] for _ in range(2)]
+        metas = None
+        if staged:
+            metas = [torch.zeros(group, 2, dtype=torch.int64) for _ in range(2)]
+            for b in range(2):
+                metas[b][:, 1] = nch
+                banks[b] = [(r[0], r[1], metas[b][j, 0:1]) for j, r in enumerate(banks[b])]
         recv = [None, None]
         if prealloc and (rotate or rank == 0):
             recv = [([torch.empty(64, dtype=torch.int32) for _ in range(world - 1)], [torch.empty(n + 64, dtype=torch.uint8) for _ in range(world - 1)])
@@ -150,7 +159,7 @@ def _pipeline_worker(rank, world, port, group, steps, prealloc, q, lag=1):
                 ref = shard.assemble_container(codec, n, chunk, cdfnum, [fc], [fp])
                 seen.append((first + j, bool(np.array_equal(cont, ref))))
 
-        pipe = shard.StepPipeline(dist, rank, world, group, banks, recv, nch, shard.HostRuntime(), rotate=rotate, on_gathered=on_gathered, lag=lag)
+        pipe = shard.StepPipeline(xdist, rank, world, group, banks, recv, nch, shard.HostRuntime(), rotate=rotate, on_gathered=on_gathered, lag=lag, metas=metas)
         cur = {}
 
         def encode(result):
@@ -174,9 +183,10 @@ def _pipeline_worker(rank, world, port, group, steps, prealloc, q, lag=1):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,group,steps,prealloc,lag", [(2, 2, 5, True, 1), (4, 4, 9, True, 1), (4, 4, 4, False, 4), (2, 1, 3, True, 1), (3, 3, 7, False, 2),
-                                                            (8, 8, 17, True, 1), (8, 8, 9, False, 4), (8, 8, 24, True, 8)])
-def test_step_pipeline_schedule(world, group, steps, prealloc, lag):
+@pytest.mark.parametrize("world,group,steps,prealloc,lag,staged", [(2, 2, 5, True, 1, False), (4, 4, 9, True, 1, False), (4, 4, 4, False, 4, False), (2, 1, 3, True, 1, False), (3, 3, 7, False, 2, False),
+                                                                   (8, 8, 17, True, 1, False), (8, 8, 9, False, 4, False), (8, 8, 24, True, 8, False),
+                                                                   (2, 2, 5, True, 1, True), (4, 4, 9, False, 2, True), (2, 1, 3, True, 1, True), (8, 8, 17, True, 1, True)])
+def test_step_pipeline_schedule(world, group, steps, prealloc, lag, staged):
     """shard.StepPipeline -- the class bench.py --gpus N runs its steps through -- with CPU tensors over gloo: every step
     of two consecutive runs must arrive whole on its root (step j of a group on rank j; group 1: rank 0) and equal the
     single-process container of that step's data, incl. the partial last group and bank reuse.  World 8 (round 4) is the
@@ -185,7 +195,7 @@ def test_step_pipeline_schedule(world, group, steps, prealloc, lag):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, group, steps, prealloc, q, lag)) for r in range(world)]
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, group, steps, prealloc, q, lag, staged)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

@@ -91,7 +91,7 @@ def group_plan(k, group, last):
     return j, bank, (j + 1 if (j == group - 1 or last) else 0)
 
 
-def exchange_group(dist, rank, world, totals, clens, payloads, recv_clen=None, recv_payload=None):
+def exchange_group(dist, rank, world, totals, clens, payloads, recv_clen=None, recv_payload=None, meta=None):
     """Gather the results of len(totals) consecutive batches, batch j onto rank j % world, in one grouped P2P call.
 
     totals[j]   : int64[1] tensor   this rank's payload bytes of batch j
@@ -101,6 +101,10 @@ def exchange_group(dist, rank, world, totals, clens, payloads, recv_clen=None, r
                   this rank is the root of, or None to allocate
     Returns (sizes, got): sizes[j][r] = (payload bytes, chunks) of rank r in batch j; got[j] = (clen list, payload
     list) in rank order for the batches rooted here (this rank's own pieces included, not copied).
+    meta        : optional int64 tensor of 2 * len(totals) elements, (payload bytes, chunks) of batch j at [2j], [2j + 1], that the
+                  caller keeps up to date by itself -- the totals are VIEWS into it that the encoder writes, the counts are written
+                  once -- so that a group's exchange starts with no kernel of its own (round 6: building it from eight one-element
+                  tensors was nine small launches per group on the side stream)
     Pairs of ranks see their transfers in the same order on both sides (batch order, directory before payload), which
     is all a grouped send/receive needs; a group of one batch rooted at rank 0 is `gather_to_root`.
     """
@@ -110,15 +114,20 @@ def exchange_group(dist, rank, world, totals, clens, payloads, recv_clen=None, r
     # the chunk counts are host numbers: one cached device tensor per shape of group (round 4 -- eight torch.tensor(n, device=...)
     # per group were eight blocking host-to-device copies on the side stream, each waiting for the group's last encode with the
     # HOST: 36 us per step of idle GPU at groups of 8 on one rank, profiles/r04_notes.md)
-    key = (str(dev), tuple(int(c.numel()) for c in clens))
-    counts = _COUNTS.get(key)
-    if counts is None:
-        counts = _COUNTS[key] = torch.tensor(key[1], dtype=torch.int64).to(dev)
-    meta = torch.cat([torch.cat([t.reshape(1).to(torch.int64) for t in totals]), counts])
     allmeta = torch.empty(2 * ns * world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(allmeta, meta)
-    m = allmeta.tolist()
-    sizes = [[(m[2 * ns * r + j], m[2 * ns * r + ns + j]) for r in range(world)] for j in range(ns)]
+    if meta is not None:
+        dist.all_gather_into_tensor(allmeta, meta.reshape(-1)[:2 * ns])
+        m = allmeta.tolist()
+        sizes = [[(m[2 * ns * r + 2 * j], m[2 * ns * r + 2 * j + 1]) for r in range(world)] for j in range(ns)]
+    else:
+        key = (str(dev), tuple(int(c.numel()) for c in clens))
+        counts = _COUNTS.get(key)
+        if counts is None:
+            counts = _COUNTS[key] = torch.tensor(key[1], dtype=torch.int64).to(dev)
+        meta = torch.cat([torch.cat([t.reshape(1).to(torch.int64) for t in totals]), counts])
+        dist.all_gather_into_tensor(allmeta, meta)
+        m = allmeta.tolist()
+        sizes = [[(m[2 * ns * r + j], m[2 * ns * r + ns + j]) for r in range(world)] for j in range(ns)]
     ops, got = [], {}
     for j in range(ns):
         root = j % world
@@ -148,6 +157,72 @@ def exchange_group(dist, rank, world, totals, clens, payloads, recv_clen=None, r
         for w in dist.batch_isend_irecv(ops):
             w.wait()
     return sizes, got
+
+
+class StagedDist:
+    """torch.distributed over a backend that moves HOST tensors (gloo), for DEVICE tensors: every call stages through host
+    memory -- the current stream is synchronised before a tensor is read, results are copied back on the current stream.
+    Not a transport of the product: it lets the device-side schedule of `bench.py --gpus N` (StepPipeline on CudaRuntime: side
+    stream, events, both banks, rotating roots, preallocated receive buffers, views of CUDA tensors) run against REAL peer
+    processes on a box where RCCL has nobody to talk to (`bench.py --backend gloo --same-device`: all ranks on cuda:0).
+    Pairs of ranks post their transfers in the same order on both sides, which is what gloo matches by."""
+    class P2POp:
+        def __init__(self, op, tensor, peer):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    class _Work:
+        def __init__(self, work, host, dst):
+            self.work, self.host, self.dst = work, host, dst
+
+        def wait(self):
+            self.work.wait()
+            if self.dst is not None:
+                self.dst.copy_(self.host)                       # on the current stream (the pipeline's side stream)
+
+    def __init__(self, dist, torch):
+        self.dist, self.torch = dist, torch
+        self.ReduceOp = dist.ReduceOp
+        self.isend, self.irecv = "isend", "irecv"
+
+    def _sync(self, t):
+        if t.is_cuda:
+            self.torch.cuda.current_stream(t.device).synchronize()
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def all_reduce(self, t, op=None):
+        op = self.dist.ReduceOp.SUM if op is None else op
+        self._sync(t)
+        h = t.cpu()
+        self.dist.all_reduce(h, op=op)
+        t.copy_(h)
+
+    def all_gather_into_tensor(self, out, inp):
+        self._sync(inp)
+        h = inp.cpu().contiguous()
+        parts = [self.torch.empty_like(h) for _ in range(self.dist.get_world_size())]
+        self.dist.all_gather(parts, h)
+        out.copy_(self.torch.cat(parts))
+
+    def all_gather_object(self, lst, obj):
+        self.dist.all_gather_object(lst, obj)
+
+    def batch_isend_irecv(self, ops):
+        works = []
+        if ops:
+            self._sync(ops[0].tensor)
+        for o in ops:
+            if o.op == "isend":
+                h = o.tensor.cpu().contiguous()
+                works.append(self._Work(self.dist.isend(h, o.peer), h, None))
+            else:
+                h = self.torch.empty(o.tensor.shape, dtype=o.tensor.dtype)
+                works.append(self._Work(self.dist.irecv(h, o.peer), h, o.tensor))
+        return works
+
+    def destroy_process_group(self):
+        self.dist.destroy_process_group()
 
 
 class HostRuntime:
@@ -215,10 +290,11 @@ class StepPipeline:
     on_gathered(first_step_of_group, sizes, got)  optional hook, called on every rank after its part of a group's
                exchange has been issued (tests assert every step's container there)
     """
-    def __init__(self, dist, rank, world, group, banks, recv, nch, rt, rotate=True, on_gathered=None, lag=1):
+    def __init__(self, dist, rank, world, group, banks, recv, nch, rt, rotate=True, on_gathered=None, lag=1, metas=None):
         self.dist, self.rank, self.world, self.group = dist, rank, world, group
         self.banks, self.recv, self.nch, self.rt, self.rotate = banks, recv, nch, rt, rotate
         self.on_gathered = on_gathered
+        self.metas = metas                                     # [2] int64 tensors [group, 2]: (total, chunks) per step of the bank; the totals of `banks` are views into them
         self.done = [None, None]
         self.pending = []
         # `lag`: how many steps after a group's last step its exchange is issued (the host reads the sizes then and waits for
@@ -238,7 +314,7 @@ class StepPipeline:
         if self.recv[bank] is not None and mine < ns and (self.rotate or self.rank == 0):
             rc, rp = {mine: self.recv[bank][0]}, {mine: self.recv[bank][1]}
         sizes, got = exchange_group(self.dist, self.rank, self.world, [r[2][:1] for r in res], [r[0][:self.nch] for r in res],
-                                    [r[1] for r in res], rc, rp)
+                                    [r[1] for r in res], rc, rp, meta=None if self.metas is None else self.metas[bank])
         if self.on_gathered:
             self.on_gathered(first, sizes, got)
 
