@@ -201,11 +201,7 @@ __global__ __launch_bounds__(128 * TRC_WPG) void trc_ansa_model2_kernel(
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) qout.put((u32)j, make_uint4(r[4 * j], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]));
-#ifndef ANSA_ABL_NOSTORE                                      // timing ablation: the records never leave the CU (output wrong)
             qout.flush(wr, p0 * 8u + (lo_wave ? 64u : 0u));
-#else
-            if (p0 == 0xffffffffu) qout.flush(wr, p0 * 8u + (lo_wave ? 64u : 0u));
-#endif
         }
     }
 }

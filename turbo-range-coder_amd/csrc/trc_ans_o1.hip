@@ -111,9 +111,6 @@ struct O1Cache {
     {
         typedef __attribute__((address_space(3))) u32 lds_u32;
         const u32 id = cx * 17u;
-#ifdef TRC_O1_ABL_NOMEM                                         // timing ablation (results wrong by construction): no table ever moves
-        if (on && id != hid) { hid = id; return; }
-#endif
         if (on && id != hid) {
             if (hid != ~0u) { NibTable W = H; W.d[0] |= hmask; o1_store(mine + (size_t)hid * 32u, W); }
             const u32 a = seen + ((cx >> 5) << 2), bits = *(const lds_u32 *)(uintptr_t)a, bit = 1u << (cx & 31u);
@@ -126,9 +123,6 @@ struct O1Cache {
     __device__ __forceinline__ void need_lo(bool on, u32 cx, u32 h)
     {
         const u32 id = cx * 17u + 1u + h;
-#ifdef TRC_O1_ABL_NOMEM
-        if (on && id != lid) { lid = id; return; }
-#endif
         if (on && id != lid) {
             if (lid != ~0u) o1_store(mine + (size_t)lid * 32u, L);
             if ((hmask >> h) & 1u) L = o1_load(mine + (size_t)id * 32u);
@@ -883,12 +877,8 @@ __global__ __launch_bounds__(64) void trc_o1_dec_rows_kernel(
         {
             const u32 noff = (cb ^ swz) + moff;
             if (act && noff != hoff) {                         // the row's hi table goes back to memory, the context's comes in
-#ifdef TRC_O1_ABL_NOMEM                                         // timing ablation (results wrong by construction): no table ever moves
-                const u32 ld = H;
-#else
                 *(u32 *)(mbase + hoff) = H;
                 const u32 ld = *(const u32 *)(mbase + noff);   // (a table never written: whatever is there, dropped below)
-#endif
                 const u32 a = seen + 512u + ((cx >> 5) << 2), bit = 1u << (cx & 31u);
                 const u32 bits = *(const lds_u32 *)(uintptr_t)a;
                 *(lds_u32 *)(uintptr_t)a = bits | bit;         // (every lane of the row writes the same word)
@@ -900,12 +890,8 @@ __global__ __launch_bounds__(64) void trc_o1_dec_rows_kernel(
         {
             const u32 noff = ((cb + 32u + (h << 5)) ^ swz) + moff;
             if (act && noff != loff) {
-#ifdef TRC_O1_ABL_NOMEM
-                const u32 ld = L;
-#else
                 *(u32 *)(mbase + loff) = L;
                 const u32 ld = *(const u32 *)(mbase + noff);
-#endif
                 const u32 a = seen + cx * 2u, bit = 1u << h;
                 const u32 bits = *(const lds_u16 *)(uintptr_t)a;
                 *(lds_u16 *)(uintptr_t)a = (u16)(bits | bit);

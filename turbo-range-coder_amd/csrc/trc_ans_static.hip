@@ -82,13 +82,6 @@ __device__ __forceinline__ void ans_put(u32 &st, const trc_v4u e, u32 rbase, u32
                  "v_cndmask_b32_sdwa %0, %0, %0, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
                  "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc"
                  : "+v"(st), "+v"(wn), "=&v"(t), "=&s"(sv) : "v"(e.z), "v"(rbase) : "vcc", "memory");
-#elif defined(TRC_ENC_ABL_NOWRITE)                             // timing experiment: no ring store at all (output is garbage)
-    asm volatile("v_cmp_ge_u32_e32 vcc, %0, %3\n\t"
-                 "v_and_b32_e32 %2, 63, %1\n\t"
-                 "v_lshl_add_u32 %2, %2, 1, %4\n\t"
-                 "v_cndmask_b32_sdwa %0, %0, %0, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
-                 "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc"
-                 : "+v"(st), "+v"(wn), "=&v"(t) : "v"(e.z), "v"(rbase) : "vcc", "memory");
 #else
     // the whole step in one block, division included (mul_hi, SDWA shift by the entry's shift byte, mul24, add3): the compiler puts
     // a wait state behind an asm block whose result the next instruction reads (it cannot see which instruction wrote it),
@@ -114,9 +107,6 @@ template <int K>
 __device__ __forceinline__ u32 ans_taddr(u32 w, u32 sh, u32 tbase, bool replicated)
 {
     u32 a;
-#ifdef TRC_ENC_ABL_ONEENTRY                                    // timing experiment: every lane reads entry 32 (broadcast, no conflicts)
-    w = 0x20202020u;
-#endif
     if (K == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(a) : "v"(sh), "v"(w));
     if (K == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(a) : "v"(sh), "v"(w));
     if (K == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(a) : "v"(sh), "v"(w));
@@ -370,18 +360,10 @@ __device__ __forceinline__ void ans_get_pair(u32 &s0, u32 &s1, u32 &sl0, u32 &sl
     asm("v_bfe_u32 %0, %1, 1, 5\n\tv_lshl_add_u32 %0, %0, 8, %2" : "=&v"(a) : "v"(hc), "v"(lbase));
     const u32 dw0 = *(const trc_lds_u32 *)(uintptr_t)a;
     const u32 dw1 = *(const trc_lds_u32 *)(uintptr_t)(a + 256u);
-#ifdef TRC_DEC_ABL_NOLUT                                        // timing ablations (results wrong by construction)
-    x0 = sl0 >> 7; x1 = sl1 >> 7;
-#else
     x0 = *(const trc_lds_u8 *)(uintptr_t)(DEC_LDS_LUT + sl0);
     x1 = *(const trc_lds_u8 *)(uintptr_t)(DEC_LDS_LUT + sl1);
-#endif
-#ifdef TRC_DEC_ABL_NODTAB
-    const trc_v2u e0 = { x0 + 1u, sl0 }, e1 = { x1 + 1u, sl1 };
-#else
     const trc_v2u e0 = *(const trc_lds_u64 *)(uintptr_t)(DEC_LDS_DTAB + (x0 << 3));
     const trc_v2u e1 = *(const trc_lds_u64 *)(uintptr_t)(DEC_LDS_DTAB + (x1 << 3));
-#endif
     u32 t0 = __umul24(e0.x, s0 >> TRC_PROB_BITS) + e0.y + sl0;
     u32 t1 = __umul24(e1.x, s1 >> TRC_PROB_BITS) + e1.y + sl1;
 #ifndef TRC_DEC_ALIGNBYTE
@@ -500,9 +482,6 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
     si.prime_issue(coded, P);
     trc_lds_barrier();                                         // the tables are in place (LDS only: the loads above stay in flight)
     if (!valid) return;
-#ifdef TRC_DEC_ABL_EXIT
-    return;
-#endif
     si.prime_land(P, 0, coded);
     si.prime_land(P, 1, coded);                                // (both halves before the first period: of the first one up to 62 bytes are skipped)
     si.rpos = r0;
@@ -511,9 +490,6 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
     const u32 body4 = len & ~3u;
     u8 *dst = out + (u64)c * chunk;
     const u32 rbase = (u32)(uintptr_t)(si.rings - smem) + AnsStreamIn::ra(lane, 0);    // this lane's ring, as an LDS byte address
-#ifdef TRC_DEC_ABL_EXIT2
-    if (chunk) return;
-#endif
     u32 sel_lo = 0x05040100u, sel_hi = 0x05040302u;            // byte selectors of the pair step's permutes (VGPR operands: VCC takes the one constant-bus slot)
     asm volatile("" : "+v"(sel_lo), "+v"(sel_hi));
     PROF_T(pt2);
@@ -527,14 +503,10 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
             if (TRC_DEC_BALANCE == 1 || k == 0 || (TRC_DEC_BALANCE == 3 && k == 2)) pace.step(s * 4u + (u32)k + 1u);
 #endif
             // period boundary: land the round requested 16 symbols ago, request the next one
-#ifdef TRC_DEC_ABL_NOPERIOD
-            si.lbytes = si.rpos + TRC_SRING;
-#else
             PROF_T(qa);
             si.period(coded && p0 < len, k & 1);
             PROF_T(qb); PROF_ACC(acc_p, qa, qb);
-#endif
-#if TRC_DEC_LATE_FLUSH && !defined(TRC_DEC_ABL_NOFLUSH)
+#if TRC_DEC_LATE_FLUSH
             if (k == 0 && s > 0) tout.flush(wc, (s - 1u) * TRC_SEG);   // the segment before: behind this period's commit (header comment)
 #endif
             PROF_T(qc); PROF_ACC(acc_f, qb, qc);
@@ -542,13 +514,8 @@ __global__ __launch_bounds__(896) void trc_ans4s_dec_kernel(
                 u32 w[4];
                 u32 hc = si.rpos >> 1;
                 u32 slb = sb & (TRC_PROB_ONE - 1), sla = sa & (TRC_PROB_ONE - 1);
-#ifdef TRC_DEC_ABL_NOSYMS
-                w[0] = sa; w[1] = sb; w[2] = hc; w[3] = p0; hc += 5;
-                for (int d = 0; d < 0; d++) {
-#else
 #pragma unroll
                 for (int d = 0; d < 4; d++) {
-#endif
                     u32 x0, x1, x2, x3;
                     ans_get_pair(sb, sa, slb, sla, rbase, hc, x0, x1, sel_lo, sel_hi);
                     ans_get_pair(sb, sa, slb, sla, rbase, hc, x2, x3, sel_lo, sel_hi);

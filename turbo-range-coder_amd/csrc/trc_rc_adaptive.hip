@@ -209,10 +209,6 @@ __global__ __launch_bounds__(192 * TRC_WPG) void trc_rca_enc_mc_kernel(
                     const u32 w = v.x; v.x = v.y; v.y = v.z; v.z = v.w;
                     const u32 x[4] = { w & 255u, (w >> 8) & 255u, (w >> 16) & 255u, w >> 24 };
                     u32 rc[4];
-#ifdef RCA_ABL_NOMODEL                                          // timing ablation: the model waves only keep the barriers company
-#pragma unroll
-                    for (int i = 0; i < 4; i++) rc[i] = (x[i] << 15) | 2048u;
-#else
                     // the lo records one byte at a time: with two more waves on the SIMD nothing waits for the LDS round trips a batch of four
                     // requests up front, and the batch's fix-ups between bytes of equal hi nibble (8 selects per earlier byte) are gone (0.612 -> 0.583 ms)
                     if (role == 0u) m.template record_hi<4>(T0, x, rc);
@@ -220,7 +216,6 @@ __global__ __launch_bounds__(192 * TRC_WPG) void trc_rca_enc_mc_kernel(
 #pragma unroll
                         for (int i = 0; i < 4; i++) { const u32 x1[1] = { x[i] }; u32 r1[1]; m.template record_lo<1>(x1, r1); rc[i] = r1[0]; }
                     }
-#endif
                     trc_ldsw128(qa + buf * 2048u + role * 1024u, make_uint4(rc[0], rc[1], rc[2], rc[3]));
                     trc_lds_barrier();
                     buf ^= 1u;
@@ -253,9 +248,6 @@ __global__ __launch_bounds__(192 * TRC_WPG) void trc_rca_enc_mc_kernel(
         const u32 a = qa + buf * 2048u;
         const uint4 ra = trc_ldsr128(a), rb = trc_ldsr128(a + 1024u);          // four hi records, four lo records
         const u32 rc[8] = { ra.x, rb.x, ra.y, rb.y, ra.z, rb.z, ra.w, rb.w };
-#ifdef RCA_ABL_NOCODER                                          // timing ablation: the coder wave only keeps the barriers company
-        o0.wpos += rc[0] & rc[7] & 4u; return;
-#endif
         const bool run = alive && !ovf && !done;
         auto body = [&](auto pred) __attribute__((always_inline)) {
             constexpr bool PRED = decltype(pred)::value;

@@ -34,15 +34,9 @@
 #include "trc_lane_io.h"
 #include "trc_launch.h"
 
-#ifdef RCB_ABL_HALFMODEL                                   // timing experiment (profiles/r02_notes.md): nodes mod 128, twice the waves; output wrong
-#define RCB_MODEL_BYTES (128u * 64u * 2u)
-#define RCB_AMASK 0x3fffu
-#define RCB_A(x) ((x) & RCB_AMASK)
-#else
 #define RCB_A(x) (x)
 #define RCB_MODEL_BYTES (256u * 64u * 2u)                  // [ctx][lane] u16
 #define RCB_AMASK 0x7fffu
-#endif
 #define RCB_WAVE_LDS    RCB_MODEL_BYTES
 #define RCB_ENC_WAVE_LDS(L7G) ((L7G) ? RCB_MODEL_BYTES / 2u : RCB_MODEL_BYTES)
 
@@ -306,10 +300,8 @@ __global__ __launch_bounds__(128 * TRC_WPG) void trc_rcb_enc_mc_kernel(
 #pragma unroll
                     for (u32 h = 0; h < 2; h++) {
                         const u32 a = qa + buf * 2048u;
-#ifndef RCB_ABL_NOMODEL                                         // timing ablation: the model wave only keeps the barriers company
                         model_byte((w >> (16 * h)) & 255u, a);
                         model_byte((w >> (16 * h + 8)) & 255u, a + 1024u);
-#endif
                         trc_lds_barrier();
                         buf ^= 1u;
                     }
@@ -398,9 +390,6 @@ __global__ __launch_bounds__(128 * TRC_WPG) void trc_rcb_enc_mc_kernel(
     };
     // the words of NP renormalisation points (rnb / cyb: point 0 in bit NP - 1), in order
     auto emit_points = [&](u32 rnb, u32 cyb, u32 pw, const u32 (&pa)[4], const u32 (&pb)[4], const int NP) __attribute__((always_inline)) {
-#ifdef RCB_ABL_NOEMIT                                           // timing ablation (profiles/r04_notes.md): no emit logic, output wrong
-        so.wpos += rnb + cyb + (pw & 1u) + (pa[1] & pb[2] & 1u); return;
-#endif
         const u32 cnt = (u32)__builtin_popcount(rnb);
         if (__ballot(cnt >= 2u && live)) {                      // rare: some lane has several words in this period
 #pragma unroll
@@ -430,9 +419,6 @@ __global__ __launch_bounds__(128 * TRC_WPG) void trc_rcb_enc_mc_kernel(
         if (!__ballot(live)) return;
         const u32 a = qa + buf * 2048u;
         const uint4 r0 = trc_ldsr128(a), r1 = trc_ldsr128(a + 1024u);
-#ifdef RCB_ABL_NOCODER                                          // timing ablation: the coder wave only keeps the barriers company
-        so.wpos += r0.x & r1.y & 4u; return;
-#endif
         const bool ends = __ballot(live && len - q0 < 2u) != 0;        // a short last chunk ends inside this period (once per grid)
         u32 nrnb = 0, cyb = 0, pw = 0, pa[4], pb[4] = { 0, 0, 0, 0 };        // nrnb: one bit per point, SET where the point emits nothing
         if (ends && live && q0 == len) { if ((int)(4u * cw.nwords) < lim) { finish(); out_len = so.wpos; } live = false; }
