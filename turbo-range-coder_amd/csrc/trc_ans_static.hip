@@ -743,6 +743,7 @@ bool trc_launch_ans4s_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const T
     if (env_wpb == 1 || env_wpb == 4 || env_wpb == 12) wpb = (u32)env_wpb;      // (tuning aid / tests: forces the shape whatever the size)
     // the twelve-wave workgroups of a one-round launch gather their own payload (no scan kernel in the way: w.goff == NULL)
     const bool fused = env_fused && wpb == 12u && !w.goff && (nwaves + 11u) / 12u <= TRC_SYNC_MAX_WG;
+    if (fused) (void)hipMemsetAsync(w.tables + TRC_TAB_SYNC, 0, TRC_SYNC_BYTES, s);      // (not "left zero by the last launch": ADVICE r5)
     if (rep == 8) ans4s_enc_launch<8>(wpb, fused, d_in, n, chunk, w, d_clen, d_payload, d_total, s);
     else ans4s_enc_launch<1>(wpb, fused, d_in, n, chunk, w, d_clen, d_payload, d_total, s);
 #ifdef TRC_ENC_PROF

@@ -22,8 +22,12 @@
 #define TRC_SYNC_MAX_WG  256u
 #define TRC_SYNC_VALID   (1ull << 63)
 
-__device__ __forceinline__ u64 trc_sync_load(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void trc_sync_store(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// (round 6, ADVICE r5: publish with release, poll with acquire; the host zeroes the area in front of every fused launch --
+// trc_launch_ans4s_enc -- so a launch that was aborted, or a workspace shared by two encodes, cannot leave stale tickets behind;
+// and the poll is BOUNDED: a ticket that never arrives ends the kernel in a trap, a launch failure the caller sees, not a hang)
+__device__ __forceinline__ u64 trc_sync_load(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void trc_sync_store(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+#define TRC_SYNC_SPIN_MAX (1u << 24)                            // polls of ~0.3 us: seconds, where a launch lasts 50 us
 
 // Sum of the totals published by tickets below `t` (one wave, all lanes call; t <= TRC_SYNC_MAX_WG).  Spins until each is there.
 __device__ __forceinline__ u64 trc_sync_prefix(const u64 *pub, u32 t)
@@ -31,7 +35,9 @@ __device__ __forceinline__ u64 trc_sync_prefix(const u64 *pub, u32 t)
     const u32 lane = trc_lane();
     u64 v[4] = { 0, 0, 0, 0 };
     bool pend;
+    u32 spins = 0;
     do {
+        if (++spins > TRC_SYNC_SPIN_MAX) __builtin_trap();
         pend = false;
 #pragma unroll
         for (u32 k = 0; k < 4u; k++) {

@@ -289,7 +289,11 @@ struct QuadOut {
 // WT (round 5): the drain's 64-byte stores go out write-through at agent scope (`global_store_dwordx4 ... sc1`) instead of staying
 // dirty in the L2: the kernel's end no longer writes back up to 32 MB of dirty lines at once (static rANS encoder 55.0 -> 53.2 us,
 // rocprofv3; the gather behind it unchanged at 29.8 -- unlike the nontemporal hint, which took the staged payload out of the L2 and
-// cost the gather 9 us).  Only for coders that never store into a drained segment again (no length header written afterwards).
+// cost the gather 9 us).  INVARIANT of every WT = true instantiation (the static rANS encoder, `rcs` with one stream, the code-quad
+// passes of `anscdf` / `ansb`): nothing in the kernel loads from, or stores again into, a segment that has been drained -- the store is
+// inline asm, outside the compiler's vmcnt accounting, so neither a later access nor a release at the kernel's end would wait for it
+// on the compiler's say-so.  A coder that patches a header behind a drain (the two-stream range coders) must keep WT = false; code that
+// READS drained bytes in the same kernel (the fused gather, trc_gather.h) puts its own `s_waitcnt vmcnt(0)` + barrier in between.
 template <bool DOWN, bool PAIR = false, bool QUAD = false, bool WT = false>
 struct StreamOut {
     u8 *rings;           // this wave's ring array (LDS)

@@ -169,7 +169,10 @@ struct LaneInWide {
 // the VALU write of it, where the compiler keeps two wait states on gfx950: scripts/check_isa_hazards.py), the moves are bit-selects, and a point only
 // moves what the points behind it can still reach (point 3 moves nothing).  One 16-byte load per group, from the stream position at
 // the START of the group (units 0-7): the group consumes cnt <= 4 units, so the next look-ahead is units cnt .. cnt + 3 of it, taken
-// out at the end of the group with a three-level bit-select.  LaneInWide's peek (a three-level select of a 32-byte register window
+// out at the end of the group with a three-level bit-select.  PRECONDITION of the sign form: states below 2^31, which every state of a
+// valid stream is (anscdf_.h:33-44: [2^15, 2^31)); a forged stream may load an initial state >= 2^31, which this form reads as "below
+// 2^15" where the borrow form read it as "not below": the (garbage) output of a corrupt stream then differs from round 4's and from a
+// host decoder's -- reads stay bounded (cnt <= 4 per group, `lim`), so it is a matter of defined garbage, not of safety.  LaneInWide's peek (a three-level select of a 32-byte register window
 // per POINT) and window move were ~37 instructions per byte of the decoder's ~165; this is ~22.
 struct LaneLook16 {
     const u8 *src;       // this lane's stream (2-byte aligned; the payload buffer carries TRC_PAD bytes of slack)
