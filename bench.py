@@ -145,6 +145,9 @@ def cpu_baseline(codec, d, cdf, cdfnum, sample):
     import concurrent.futures as cf
     import trc_testlib as T
     use_ref = T.have_ref()
+    if not use_ref:
+        print("bench.py: oracle/_ref/libtrc_ref.so ABSENT (built from /root/reference in the build container only; it travels to the GPU box with "
+              "the snapshot, a fresh clone does not have it): cpu_baseline is the oracle restatement, kind = \"port\"", file=sys.stderr)
     enc = (lambda x: T.ref_enc(codec, x, cdf, cdfnum)) if use_ref else (lambda x: T.orc_enc(codec, x, cdf, cdfnum))
     ref_dec_ok = use_ref and codec not in (T.ANS4S, T.ANSA4)
     dec_fn = (lambda c, n_: T.ref_dec(codec, c, n_, cdf, cdfnum)) if ref_dec_ok else (lambda c, n_: T.orc_dec(codec, c, n_, cdf, cdfnum))
