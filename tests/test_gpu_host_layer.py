@@ -143,3 +143,68 @@ def test_device_list_from_the_environment(torch_cuda):
     assert one[-1] == "0" and three[-1] == "3" and int(every[-1]) >= 1
     bad = _child(code, {"TRC_DEVICES": "0,x"}).split()
     assert bad[:-1] == one[:-1] and bad[-1] == "0"
+
+
+STRIPED = r"""
+import sys
+sys.path.insert(0, "tests"); sys.path.insert(0, "turbo-range-coder_amd")
+import numpy as np, trc, trc_testlib as T
+from golden.make_golden import gen
+rng = np.random.default_rng(5)
+n_calls = 0
+for codec in (trc.RCA, trc.RCAI, trc.ANSA, trc.RCB):
+    for it in range(7):
+        # the same staging / device buffers call after call, different bytes every time: anything read before its pass has landed, or
+        # left in a cache by the call before, shows as a payload that differs from the oracle's
+        n = int(rng.integers(1, 6 * 1000 * 1000)) if it else 4096 * 517
+        if it == 1: n = 4096 * 64 * 3 + 1
+        if it == 2: n = 4095
+        d = gen(("text", "zipf", "runs")[it % 3], n, 900 + 31 * it + codec)
+        if it == 4:
+            u = gen("uniform", n, 77); d[n // 3:n // 3 + 50000] = u[n // 3:n // 3 + 50000]      # raw chunks among coded ones
+        comp = trc.host_encode(codec, d)
+        if comp.size == n:
+            assert np.array_equal(comp, d); continue
+        hdr, clen, payload = trc.parse_container(comp)
+        chunk = hdr["chunk"]
+        assert chunk == trc.lib().trc_auto_chunk_codec(codec, n) and chunk >= 2048
+        exp_payload, exp_clen = T.orc_chunked_enc_mt(codec, d, chunk, None, 0)
+        assert np.array_equal(clen, exp_clen) and np.array_equal(payload, exp_payload), (codec, it, n)
+        assert np.array_equal(trc.host_decode(codec, comp, n), d)
+        n_calls += 1
+print("ok", n_calls)
+"""
+
+
+def test_striped_encode_matches_the_oracle_call_after_call(torch_cuda):
+    """round 6: the encoders of rccdf / rccdfi / anscdf / rcs are launched BEFORE their input has arrived and wait at an arrival gate
+    for each of its K passes (trc_io.h, trc_host.inc).  28 calls on the same buffers, sizes from one chunk to 6 MB, ragged ends, raw
+    chunks: every payload equals the oracle's per-chunk output; the same through the slice pipeline (TRC_HOST_NO_STRIPE) and over
+    a device list; pageable buffers (numpy arrays are)."""
+    for env in ({}, {"TRC_HOST_NO_STRIPE": "1"}, {"TRC_DEVICES": "0,0"}, {"TRC_HOST_PIECE": "262144"}):
+        out = _child(STRIPED, env).split()
+        assert out[0] == "ok" and int(out[1]) >= 20, (env, out)
+
+
+def test_a_gate_that_never_opens_fails_over_to_the_slice_pipeline(torch_cuda):
+    """TRC_HOST_GATE_SABOTAGE (test hook): the last pass of every striped slice never opens its gate.  The waiting waves give up after
+    about a second and say so (word 63 of the gate area), the host repeats the call through the slice pipeline and stops using gates in
+    this process: the caller gets the right container, late, and one line on stderr -- no trap, no hang"""
+    code = r'''
+import sys, time
+sys.path.insert(0, "tests"); sys.path.insert(0, "turbo-range-coder_amd")
+import numpy as np, trc, trc_testlib as T
+from golden.make_golden import gen
+d = gen("text", 3000001, 5)
+t0 = time.time(); a = trc.host_encode(trc.RCA, d); t1 = time.time(); b = trc.host_encode(trc.RCA, d); t2 = time.time()
+hdr, clen, payload = trc.parse_container(a)
+ep, ec = T.orc_chunked_enc_mt(trc.RCA, d, hdr["chunk"], None, 0)
+assert np.array_equal(clen, ec) and np.array_equal(payload, ep) and np.array_equal(a, b)
+assert np.array_equal(trc.host_decode(trc.RCA, a, d.size), d)
+print("ok %.2f %.2f" % (t1 - t0, t2 - t1))
+'''
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, TRC_HOST_GATE_SABOTAGE="1"), cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.split()[0] == "ok" and "an arrival gate timed out" in r.stderr, r.stdout + r.stderr[-2000:]
+    first, second = float(r.stdout.split()[1]), float(r.stdout.split()[2])
+    assert first > 0.3 and second < 0.3, (first, second)               # the first call waited for the timeout, the second one no longer uses gates

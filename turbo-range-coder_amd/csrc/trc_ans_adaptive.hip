@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64 * (NIB ? TRC_NIB_WPG : TRC_WPG)) void trc_ansa_m
 // Two waves per SIMD on the LDS footprint of one: each wave's issue gaps (a lone wave issues every ~1.5 quad-cycles) are the
 // other's slots.  The record space is PLANAR (above) so that both write whole segments.
 __global__ __launch_bounds__(128 * TRC_WPG) void trc_ansa_model2_kernel(
-    const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ recs)
+    const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ recs, const u32 *__restrict__ gate, u32 gate_part)
 {
     // a workgroup = 4 hi waves (0-3) + 4 lo waves (4-7): pair k = waves k and k + 4 on SIMD k (trc_dev.h, TRC_WPG)
     extern __shared__ __attribute__((aligned(16))) u8 smem_wg_[];
@@ -148,6 +148,7 @@ __global__ __launch_bounds__(128 * TRC_WPG) void trc_ansa_model2_kernel(
     wc.c0 = grp_ * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
     wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
     wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
+    wc.gate = gate; wc.gate_part = gate_part;                  // (host-pointer encodes: the input arrives while the waves code, trc_io.h)
     const WaveChunks wr = ansa_record_space_planar(wc);
     const bool alive = lane < wc.rows;
     const u32 len = alive ? wc.len_of(lane) : 0u;
@@ -715,13 +716,14 @@ static bool ansa_mc_enabled()
     static const int env = getenv("TRC_ANSA_MC") ? atoi(getenv("TRC_ANSA_MC")) : 1;
     return env != 0;
 }
+bool trc_ansa_enc_gate_ok() { return ansa_mc_enabled(); }
 template <bool NIB>
 static void launch_ansa_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
 {
     if (!NIB && ansa_mc_enabled()) {
         TRC_RAISE_LDS_ONCE(trc_ansa_model2_kernel, TRC_WPG * ANSA_MODEL_LDS(false) + 64u);
         TRC_RAISE_LDS_ONCE(trc_ansa_code_planar_kernel, TRC_WPG * ANSA_CODE_PLANAR_LDS);
-        TRC_LAUNCH_TIMED(trc_ansa_model2_kernel, TRC_QUAD_GRID(w.ngroups), dim3(128 * TRC_WPG), TRC_WPG * ANSA_MODEL_LDS(false) + 64u, s, d_in, (u64)n, chunk, w.nchunks, w.scratch2);
+        TRC_LAUNCH_TIMED(trc_ansa_model2_kernel, TRC_QUAD_GRID(w.ngroups), dim3(128 * TRC_WPG), TRC_WPG * ANSA_MODEL_LDS(false) + 64u, s, d_in, (u64)n, chunk, w.nchunks, w.scratch2, trc_gate_tls.flag, trc_gate_tls.part);
         trc_launch_ansa_code_planar(n, chunk, w, d_clen, s);
         return;
     }

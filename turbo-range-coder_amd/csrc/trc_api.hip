@@ -299,6 +299,18 @@ extern "C" int trc_timing_read(int decode, double *total_ms, int *launches)
     if (launches) *launches = nc;
     return TRC_OK;
 }
+thread_local TrcGate trc_gate_tls = { nullptr, 0 };
+bool trc_gate_ok(int codec)
+{
+    static const bool off = getenv("TRC_HOST_NO_GATE") != nullptr;       // tuning aid / tests: the slice pipeline for every coder
+    if (off) return false;
+    switch (codec) {
+    case TRC_RCA: case TRC_RCAI: return trc_rca_enc_gate_ok();
+    case TRC_ANSA: return trc_ansa_enc_gate_ok();
+    case TRC_RCB: return trc_rcb_enc_gate_ok();
+    }
+    return false;
+}
 bool trc_first_use_on_device(unsigned long long *mask)
 {
     int dev = 0;

@@ -44,6 +44,32 @@ __device__ __forceinline__ u32 trc_mbcnt(u64 mask)   // number of set bits of ma
     return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
 }
 
+// Round 6, the ARRIVAL GATE of an input that is still on its way (host-pointer encodes, trc_host.inc): the host delivers the input in
+// K passes -- pass k = bytes [k * part, (k + 1) * part) of EVERY chunk, one 2-D DMA copy -- and sets *gate = k + 1 behind each pass (a
+// 4-byte copy on the same stream); the kernel is launched before the first byte has arrived and a wave waits here before it asks for
+// the first segment of a part.  The wave's coding time then overlaps the transfer instead of following it.  Rules that make this
+// safe: chunk and part are multiples of 128 bytes, so no cache line holds bytes of two passes; a line of part k is first touched
+// after the flag says it is there (the caches were invalidated at the kernel's start); the flag is read at system scope, past the
+// caches; the wait is BOUNDED -- a pass that never arrives is reported to the host (word 63 of the gate area), not waited for forever.
+#define TRC_GATE_SPIN_MAX (1u << 20)                            // polls ~1 us apart: about a second
+#define TRC_GATE_AREA 256u                                      // the gates of a call: 64 words, 256-byte aligned; word 63 = "a wait timed out"
+// returns false when the pass never arrived: the wave then stops waiting (its output is garbage) and the host, which reads word 63
+// behind the kernel, fails the call loudly and stops using gates (trc_host.inc) -- no trap, no hang
+__device__ __forceinline__ bool trc_gate_wait(const u32 *gate, u32 need)
+{
+    u32 spins = 0;
+    while (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < need) {
+        __builtin_amdgcn_s_sleep(32);
+        if (++spins > TRC_GATE_SPIN_MAX) {
+            u32 *err = (u32 *)(((uintptr_t)gate & ~(uintptr_t)(TRC_GATE_AREA - 1u)) + TRC_GATE_AREA - 4u);
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return false;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // (nothing of the part is in this CU's L1 either; cheap, once per part)
+    return true;
+}
+
 // Geometry of the 64 chunks one wave owns.
 struct WaveChunks {
     u32 c0;        // first chunk of this wave
@@ -51,7 +77,17 @@ struct WaveChunks {
     u32 chunk;     // nominal chunk bytes
     u32 lastlen;   // length of chunk nchunks-1
     u32 nchunks;
+    const u32 *gate = nullptr;   // arrival gate of the input (above), or null: the input is all there
+    u32 gate_part = 0;           // bytes of a chunk per pass
+    mutable u32 gate_seen = 0;   // passes this wave knows to have arrived
     __device__ __forceinline__ u32 len_of(u32 row) const { return (c0 + row == nchunks - 1) ? lastlen : chunk; }
+    // before the loads of the segment at `segoff` of every chunk are issued (wave-uniform)
+    __device__ __forceinline__ void wait_for(u32 segoff) const
+    {
+        if (!gate) return;
+        const u32 need = segoff / gate_part + 1u;
+        if (need > gate_seen) gate_seen = trc_gate_wait(gate, need) ? need : ~0u;     // (timed out: stop waiting)
+    }
 };
 
 // ------------------------------------------------------------------------------------ TileIn ---
@@ -184,6 +220,7 @@ struct QuadIn {
     __device__ __forceinline__ void issue(const WaveChunks &w, u32 segoff, bool pair = false)
     {
         const u32 lane = trc_lane(), part = (lane & 3u) << 4;
+        w.wait_for(segoff);                                    // (host-pointer encodes: the part this segment belongs to has arrived)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             u32 row = (lane & ~3u) + (u32)j;

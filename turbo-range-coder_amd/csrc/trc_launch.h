@@ -40,6 +40,15 @@ static inline bool trc_nib_big(uint32_t ngroups)
     return env >= 0 ? env != 0 : (ngroups >= 2048u && ngroups <= 12u * 256u);
 }
 
+// The arrival gate of the NEXT encode launched by this thread (trc_io.h, WaveChunks::gate): set by the host layer around its
+// trc_encode_dev call, read by the launchers of the encoders that honour it (trc_gate_ok), null otherwise.
+struct TrcGate { const uint32_t *flag; uint32_t part; };
+extern thread_local TrcGate trc_gate_tls;
+bool trc_gate_ok(int codec);                                   // the default encoder form of `codec` waits at the gate (trc_api.hip)
+bool trc_rca_enc_gate_ok();
+bool trc_ansa_enc_gate_ok();
+bool trc_rcb_enc_gate_ok();
+
 // Workspace carve-up shared by encode and decode (all offsets 256-byte aligned).
 struct TrcWork {
     uint8_t  *tables;    // per-call coder tables derived from the CDF (static coders)

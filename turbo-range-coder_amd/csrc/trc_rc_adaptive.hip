@@ -164,7 +164,7 @@ template <int NS>
 __global__ __launch_bounds__(192 * TRC_WPG) void trc_rca_enc_mc_kernel(
     const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks,
     u8 *__restrict__ scratch, u32 stride, u8 *__restrict__ scratch2, u32 stride2,
-    u32 *__restrict__ clen, u32 *__restrict__ gsum)
+    u32 *__restrict__ clen, u32 *__restrict__ gsum, const u32 *__restrict__ gate, u32 gate_part)
 {
     // a workgroup = 4 hi-model waves (0-3) + 4 lo-model waves (4-7) + 4 coder waves (8-11): set k = waves k, k + 4, k + 8 = group
     // 4 blockIdx + k; the dispatcher deals a workgroup's waves over consecutive SIMDs, so SIMD k of the CU holds set k (trc_dev.h,
@@ -188,6 +188,7 @@ __global__ __launch_bounds__(192 * TRC_WPG) void trc_rca_enc_mc_kernel(
     wc.c0 = grp_ * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
     wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
     wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
+    wc.gate = gate; wc.gate_part = gate_part;                  // (host-pointer encodes: the input arrives while the waves code, trc_io.h)
     const u32 S = chunk / TRC_SEG;
 
     if (!coder) {
@@ -643,8 +644,9 @@ static void launch_rca_enc_mc(const uint8_t *d_in, size_t n, uint32_t chunk, con
 {
     TRC_RAISE_LDS_ONCE(trc_rca_enc_mc_kernel<NS>, TRC_WPG * RCA_MC_LDS);
     TRC_LAUNCH_TIMED((trc_rca_enc_mc_kernel<NS>), TRC_QUAD_GRID(w.ngroups), dim3(192 * TRC_WPG), TRC_WPG * RCA_MC_LDS, s,
-                       d_in, (u64)n, chunk, w.nchunks, w.scratch, w.stride, w.scratch2, w.stride2, d_clen, w.gsum);
+                       d_in, (u64)n, chunk, w.nchunks, w.scratch, w.stride, w.scratch2, w.stride2, d_clen, w.gsum, trc_gate_tls.flag, trc_gate_tls.part);
 }
+bool trc_rca_enc_gate_ok() { return rca_mc_enabled(); }
 void trc_launch_rca_enc(int nstreams, int nibble, const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
 {
     if (!nibble && rca_mc_enabled()) {

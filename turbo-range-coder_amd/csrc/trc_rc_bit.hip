@@ -237,7 +237,7 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_rcb_enc_kernel(
 
 __global__ __launch_bounds__(128 * TRC_WPG) void trc_rcb_enc_mc_kernel(
     const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks,
-    u8 *__restrict__ scratch, u32 stride, u32 *__restrict__ clen, u32 *__restrict__ gsum)
+    u8 *__restrict__ scratch, u32 stride, u32 *__restrict__ clen, u32 *__restrict__ gsum, const u32 *__restrict__ gate, u32 gate_part)
 {
     // a workgroup = 4 model waves (0-3) + 4 coder waves (4-7): pair k = waves k and k + 4 on SIMD k (trc_dev.h, TRC_WPG)
     extern __shared__ __attribute__((aligned(16))) u8 smem_wg_[];
@@ -253,6 +253,7 @@ __global__ __launch_bounds__(128 * TRC_WPG) void trc_rcb_enc_mc_kernel(
     wc.c0 = grp_ * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
     wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
     wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
+    wc.gate = gate; wc.gate_part = gate_part;                  // (host-pointer encodes: the input arrives while the waves code, trc_io.h)
     const u32 S = chunk / TRC_SEG;
 
     if (!coder) {
@@ -605,6 +606,11 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_rcb_dec_kernel(
     trc_wave_copy_raw(__ballot(alive && cl == len && len != 0), off, len, out + (u64)wc.c0 * chunk, chunk, payload);
 }
 
+bool trc_rcb_enc_gate_ok()
+{
+    const int env = getenv("TRC_RCB_L7G") ? atoi(getenv("TRC_RCB_L7G")) : -1, env_mc = getenv("TRC_RCB_MC") ? atoi(getenv("TRC_RCB_MC")) : -1;
+    return env_mc >= 0 ? env_mc != 0 : (env < 0);              // the model wave + coder wave form (the default) is the one that waits at the gate
+}
 void trc_launch_rcb_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)
 {
     // Level 7 in global memory buys residency (9 waves per CU instead of 5), not throughput: its two scattered 2-byte accesses
@@ -619,7 +625,7 @@ void trc_launch_rcb_enc(const uint8_t *d_in, size_t n, uint32_t chunk, const Trc
     if (mc) {
         TRC_RAISE_LDS_ONCE(trc_rcb_enc_mc_kernel, TRC_WPG * RCB_MC_LDS);
         TRC_LAUNCH_TIMED(trc_rcb_enc_mc_kernel, TRC_QUAD_GRID(w.ngroups), dim3(128 * TRC_WPG), TRC_WPG * RCB_MC_LDS, s,
-                           d_in, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum);
+                           d_in, (u64)n, chunk, w.nchunks, w.scratch, w.stride, d_clen, w.gsum, trc_gate_tls.flag, trc_gate_tls.part);
         return;
     }
     if (l7g) {
