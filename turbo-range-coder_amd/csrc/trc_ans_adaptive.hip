@@ -466,7 +466,7 @@ __global__ __launch_bounds__(256 * GPW) void trc_ansa_codeq_kernel(
 template <bool NIB>
 __global__ __launch_bounds__(64 * TRC_WPG) void trc_ansa_dec_kernel(
     const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
-    u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ out)
+    u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ out, u32 *__restrict__ prog, u32 *__restrict__ prog_host, u32 prog_part)
 {
     TRC_QUAD_PROLOGUE(ANSA_MODEL_LDS(NIB));
     NibModel<NIB ? 1 : 17> m; m.init(smem);
@@ -475,6 +475,7 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_ansa_dec_kernel(
     wc.c0 = grp_ * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
     wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
     wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
+    wc.prog = prog; wc.prog_host = prog_host; wc.prog_part = prog_part;      // (host-pointer decodes: the output leaves while the waves decode, trc_io.h)
     const bool alive = lane < wc.rows;
     const u32 c = wc.c0 + lane;
     const u32 len = alive ? wc.len_of(lane) : 0u;
@@ -520,6 +521,11 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_ansa_dec_kernel(
         si.skip_if(rn);
     };
 
+    if (wc.prog) {                                             // chunks stored raw go first: a part is reported only when ALL its bytes are out
+        wc.skip_rows = __ballot(alive && cl == len && len != 0);  // (and the loop's stores of those rows -- zeros -- stay away from them)
+        trc_wave_copy_raw(wc.skip_rows, off, len, out + (u64)wc.c0 * chunk, chunk, payload);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // (plain stores: written back to memory before this wave reports anything)
+    }
     QuadOut qout; qout.base = out + (u64)wc.c0 * chunk;
     u8 *dst = out + (u64)c * chunk;
     const u32 S = chunk / TRC_SEG;
@@ -574,7 +580,7 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_ansa_dec_kernel(
         qout.put(0, pc0); qout.put(1, pc1); qout.put(2, pc2); qout.put(3, pc3);
         qout.flush(wc, s * TRC_SEG);
     }
-    trc_wave_copy_raw(__ballot(alive && cl == len && len != 0), off, len, out + (u64)wc.c0 * chunk, chunk, payload);
+    if (!wc.prog) trc_wave_copy_raw(__ballot(alive && cl == len && len != 0), off, len, out + (u64)wc.c0 * chunk, chunk, payload);
 }
 
 // ---- ANSA's decoder as two waves per 64 chunks (round 4; the scheme of trc_rca_dec_mc_kernel, trc_rc_adaptive.hip) -------
@@ -743,6 +749,7 @@ static bool ansa_dmc_enabled()
     static const int env = getenv("TRC_ANSA_DMC") ? atoi(getenv("TRC_ANSA_DMC")) : 0;
     return env != 0;
 }
+bool trc_ansa_dec_prog_ok() { return !ansa_dmc_enabled(); }       // the one-wave decoder (the default) reports its progress
 template <bool NIB>
 static void launch_ansa_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                             const TrcWork &w, uint8_t *d_out, hipStream_t s)
@@ -757,7 +764,7 @@ static void launch_ansa_dec(const uint8_t *d_payload, const uint32_t *d_clen, si
     // not taken, profiles/r05q_ab.txt)
     TRC_RAISE_LDS_ONCE((trc_ansa_dec_kernel<NIB>), TRC_WPG * ANSA_MODEL_LDS(NIB));
     TRC_LAUNCH_TIMED((trc_ansa_dec_kernel<NIB>), TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (ANSA_MODEL_LDS(NIB)), s,
-                       d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, d_out);
+                       d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, d_out, NIB ? nullptr : trc_prog_tls.counters, NIB ? nullptr : trc_prog_tls.host_flags, NIB ? 0u : trc_prog_tls.part);
 }
 // pass 2 over the planar record space (ANSA's two-wave model pass, and the order-1 coder's)
 void trc_launch_ansa_code_planar(size_t n, uint32_t chunk, const TrcWork &w, uint32_t *d_clen, hipStream_t s)

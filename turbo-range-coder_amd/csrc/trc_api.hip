@@ -311,6 +311,18 @@ bool trc_gate_ok(int codec)
     }
     return false;
 }
+thread_local TrcProg trc_prog_tls = { nullptr, nullptr, 0 };
+bool trc_prog_ok(int codec)
+{
+    static const bool off = getenv("TRC_HOST_NO_GATE") != nullptr;
+    if (off) return false;
+    switch (codec) {
+    case TRC_RCA: case TRC_RCAI: return trc_rca_dec_prog_ok();
+    case TRC_ANSA: return trc_ansa_dec_prog_ok();
+    case TRC_RCB: return trc_rcb_dec_prog_ok();
+    }
+    return false;
+}
 bool trc_first_use_on_device(unsigned long long *mask)
 {
     int dev = 0;

@@ -47,6 +47,14 @@ __device__ __forceinline__ void trc_st16_nt(u8 *p, uint4 q)
     __builtin_nontemporal_store(v, (trc_v4u *)p);
 }
 
+// write-through to memory at system scope: for bytes another agent (a copy engine) reads before the kernel has ended.  Inline asm:
+// outside the compiler's vmcnt accounting -- the only reader is outside the kernel, and WaveChunks::after_flush waits before it signals.
+__device__ __forceinline__ void trc_st16_sys(u8 *p, uint4 q)
+{
+    const trc_v4u v = { q.x, q.y, q.z, q.w };
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory");
+}
+
 // ---- LDS accesses written out by hand (the symbol loops of the static coders) ----------------------------------------
 // Not in the compiler's s_waitcnt bookkeeping: a read's destination is valid only after a counted s_waitcnt statement
 // that names it "+v" (cdna_hip_programming.md 5.7 form ii); `addr` is an LDS byte address.

@@ -80,7 +80,27 @@ struct WaveChunks {
     const u32 *gate = nullptr;   // arrival gate of the input (above), or null: the input is all there
     u32 gate_part = 0;           // bytes of a chunk per pass
     mutable u32 gate_seen = 0;   // passes this wave knows to have arrived
+    // Round 6, the PROGRESS of an output that starts its way back before the kernel has ended (host-pointer decodes, trc_host.inc): the
+    // mirror of the arrival gate.  Every wave, when it has stored bytes [k part, (k + 1) part) of its chunks -- write-through to memory
+    // (QuadOut::flush under `prog`), and waited for -- adds one to prog[k]; the wave that completes the count sets prog_host[k] (page-
+    // locked host memory) and the host, which polls it, starts the 2-D copy of part k of every chunk while the waves decode part k + 1.
+    u32 *prog = nullptr;         // device: one counter per part, zero at the launch; or null: nobody is listening
+    u32 *prog_host = nullptr;    // host (page-locked): one flag per part
+    u32 prog_part = 0;           // bytes of a chunk per part
+    u64 skip_rows = 0;           // rows QuadOut::flush leaves alone (chunks stored raw, copied BEFORE the loop when somebody listens to `prog`)
     __device__ __forceinline__ u32 len_of(u32 row) const { return (c0 + row == nchunks - 1) ? lastlen : chunk; }
+    // behind the stores of the segment that ends at `end` of every chunk (wave-uniform)
+    __device__ __forceinline__ void after_flush(u32 end) const
+    {
+        if (!prog) return;
+        if (end % prog_part != 0u && end != chunk) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's write-through stores of the part have been acknowledged
+        if (trc_lane() == 0u) {
+            const u32 k = (end + prog_part - 1u) / prog_part - 1u, nwaves = (nchunks + 63u) / 64u;
+            const u32 old = __hip_atomic_fetch_add(prog + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == nwaves - 1u) __hip_atomic_store(prog_host + k, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     // before the loads of the segment at `segoff` of every chunk are issued (wave-uniform)
     __device__ __forceinline__ void wait_for(u32 segoff) const
     {
@@ -309,9 +329,13 @@ struct QuadOut {
         for (int j = 0; j < 4; j++) {                          // m[j] = piece (lane&3) of the chunk of lane (lane&~3)+j
             if (pair && (j & 1)) continue;
             const u32 vrow = (lane & ~3u) + (u32)j, row = pair ? vrow >> 1 : vrow;
-            if (row < w.rows && segoff + part + 16u <= w.len_of(row))
-                trc_st16_nt(base + (size_t)row * w.chunk + segoff + part, make_uint4(m[j][0], m[j][1], m[j][2], m[j][3]));
+            if (row < w.rows && segoff + part + 16u <= w.len_of(row) && !((w.skip_rows >> row) & 1ull)) {
+                u8 *const a = base + (size_t)row * w.chunk + segoff + part;
+                const uint4 v = make_uint4(m[j][0], m[j][1], m[j][2], m[j][3]);
+                if (w.prog) trc_st16_sys(a, v); else trc_st16_nt(a, v);       // (somebody copies the part away before the kernel ends: past the caches)
+            }
         }
+        w.after_flush(segoff + TRC_SEG);
     }
 };
 

@@ -44,6 +44,12 @@ static inline bool trc_nib_big(uint32_t ngroups)
 // trc_encode_dev call, read by the launchers of the encoders that honour it (trc_gate_ok), null otherwise.
 struct TrcGate { const uint32_t *flag; uint32_t part; };
 extern thread_local TrcGate trc_gate_tls;
+struct TrcProg { uint32_t *counters; uint32_t *host_flags; uint32_t part; };  // ... and the progress counters of the next DECODE (WaveChunks::prog)
+extern thread_local TrcProg trc_prog_tls;
+bool trc_prog_ok(int codec);                                   // the default decoder form of `codec` reports its progress
+bool trc_rca_dec_prog_ok();
+bool trc_ansa_dec_prog_ok();
+bool trc_rcb_dec_prog_ok();
 bool trc_gate_ok(int codec);                                   // the default encoder form of `codec` waits at the gate (trc_api.hip)
 bool trc_rca_enc_gate_ok();
 bool trc_ansa_enc_gate_ok();

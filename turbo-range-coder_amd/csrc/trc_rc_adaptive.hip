@@ -309,7 +309,7 @@ __global__ __launch_bounds__(192 * TRC_WPG) void trc_rca_enc_mc_kernel(
 template <int NS, bool NIB>
 __global__ __launch_bounds__(64 * (NIB ? TRC_NIB_WPG : TRC_WPG)) void trc_rca_dec_kernel(
     const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
-    u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ out)
+    u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ out, u32 *__restrict__ prog, u32 *__restrict__ prog_host, u32 prog_part)
 {
     TRC_QUAD_PROLOGUE(RCA_WAVE_LDS(NIB));
     NibModel<NIB ? 1 : 17> m; m.init(smem);
@@ -318,6 +318,7 @@ __global__ __launch_bounds__(64 * (NIB ? TRC_NIB_WPG : TRC_WPG)) void trc_rca_de
     wc.c0 = grp_ * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
     wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
     wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
+    wc.prog = prog; wc.prog_host = prog_host; wc.prog_part = prog_part;      // (host-pointer decodes: the output leaves while the waves decode, trc_io.h)
     const bool alive = lane < wc.rows;
     const u32 c = wc.c0 + lane;
     const u32 len = alive ? wc.len_of(lane) : 0u;
@@ -368,6 +369,11 @@ __global__ __launch_bounds__(64 * (NIB ? TRC_NIB_WPG : TRC_WPG)) void trc_rca_de
         return x | rf;
     };
 
+    if (wc.prog) {                                             // chunks stored raw go first: a part is reported only when ALL its bytes are out
+        wc.skip_rows = __ballot(alive && cl == len && len != 0);  // (and the loop's stores of those rows -- zeros -- stay away from them)
+        trc_wave_copy_raw(wc.skip_rows, off, len, out + (u64)wc.c0 * chunk, chunk, payload);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // (plain stores: written back to memory before this wave reports anything)
+    }
     QuadOut qout; qout.base = out + (u64)wc.c0 * chunk;
     u8 *dst = out + (u64)c * chunk;
     const u32 S = chunk / TRC_SEG;
@@ -450,7 +456,7 @@ __global__ __launch_bounds__(64 * (NIB ? TRC_NIB_WPG : TRC_WPG)) void trc_rca_de
         qout.put(0, pc0); qout.put(1, pc1); qout.put(2, pc2); qout.put(3, pc3);
         qout.flush(wc, s * TRC_SEG);
     }
-    trc_wave_copy_raw(__ballot(alive && cl == len && len != 0), off, len, out + (u64)wc.c0 * chunk, chunk, payload);
+    if (!wc.prog) trc_wave_copy_raw(__ballot(alive && cl == len && len != 0), off, len, out + (u64)wc.c0 * chunk, chunk, payload);
 }
 
 // ---- the byte coders' DECODER as two waves per 64 chunks (round 4) -------------------------------------------------
@@ -626,12 +632,12 @@ static void launch_rca_dec(const uint8_t *d_payload, const uint32_t *d_clen, siz
     if (NIB && trc_nib_big(w.ngroups)) {
         TRC_RAISE_LDS_ONCE((trc_rca_dec_kernel<NS, NIB>), TRC_LDS_ONE_PER_CU);
         TRC_LAUNCH_TIMED((trc_rca_dec_kernel<NS, NIB>), dim3((w.ngroups + TRC_NIB_WPG - 1u) / TRC_NIB_WPG), dim3(64 * TRC_NIB_WPG), TRC_LDS_ONE_PER_CU, s,
-                           d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, d_out);
+                           d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, d_out, (u32 *)nullptr, (u32 *)nullptr, 0u);
         return;
     }
     TRC_RAISE_LDS_ONCE((trc_rca_dec_kernel<NS, NIB>), NIB ? TRC_LDS_ONE_PER_CU : TRC_WPG * RCA_WAVE_LDS(NIB));   // (one limit for both shapes of the nibble form: the attribute is set once per call site)
     TRC_LAUNCH_TIMED((trc_rca_dec_kernel<NS, NIB>), TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (RCA_WAVE_LDS(NIB)), s,
-                       d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, d_out);
+                       d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, d_out, NIB ? nullptr : trc_prog_tls.counters, NIB ? nullptr : trc_prog_tls.host_flags, NIB ? 0u : trc_prog_tls.part);
 }
 // TRC_RCA_MC=0 selects the one-wave encoder of rounds 1-3 for the byte coders (A/B measurements, tests of both forms)
 static bool rca_mc_enabled()
@@ -672,6 +678,7 @@ static bool rca_dmc_enabled()
     static const int env = getenv("TRC_RCA_DMC") ? atoi(getenv("TRC_RCA_DMC")) : 0;
     return env != 0;
 }
+bool trc_rca_dec_prog_ok() { return !rca_dmc_enabled(); }         // the one-wave decoder (the default) reports its progress
 void trc_launch_rca_dec(int nstreams, int nibble, const uint8_t *d_payload, const uint32_t *d_clen, size_t n, uint32_t chunk,
                         const TrcWork &w, uint8_t *d_out, hipStream_t s)
 {

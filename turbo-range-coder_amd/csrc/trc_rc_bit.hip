@@ -455,7 +455,7 @@ __global__ __launch_bounds__(128 * TRC_WPG) void trc_rcb_enc_mc_kernel(
 
 __global__ __launch_bounds__(64 * TRC_WPG) void trc_rcb_dec_kernel(
     const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
-    u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ out)
+    u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ out, u32 *__restrict__ prog, u32 *__restrict__ prog_host, u32 prog_part)
 {
     TRC_QUAD_PROLOGUE(RCB_WAVE_LDS);
     u16 *mb = (u16 *)smem + lane;
@@ -465,6 +465,7 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_rcb_dec_kernel(
     wc.c0 = grp_ * 64u; wc.chunk = chunk; wc.nchunks = nchunks;
     wc.lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
     wc.rows = nchunks - wc.c0 < 64u ? nchunks - wc.c0 : 64u;
+    wc.prog = prog; wc.prog_host = prog_host; wc.prog_part = prog_part;      // (host-pointer decodes: the output leaves while the waves decode, trc_io.h)
     const bool alive = lane < wc.rows;
     const u32 c = wc.c0 + lane;
     const u32 len = alive ? wc.len_of(lane) : 0u;
@@ -576,6 +577,11 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_rcb_dec_kernel(
         return ((a + negm) >> 7) & 255u;
     };
 
+    if (wc.prog) {                                             // chunks stored raw go first: a part is reported only when ALL its bytes are out
+        wc.skip_rows = __ballot(alive && cl == len && len != 0);  // (and the loop's stores of those rows -- zeros -- stay away from them)
+        trc_wave_copy_raw(wc.skip_rows, off, len, out + (u64)wc.c0 * chunk, chunk, payload);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // (plain stores: written back to memory before this wave reports anything)
+    }
     QuadOut qout; qout.base = out + (u64)wc.c0 * chunk;
     u8 *dst = out + (u64)c * chunk;
     const u32 S = chunk / TRC_SEG;
@@ -603,9 +609,10 @@ __global__ __launch_bounds__(64 * TRC_WPG) void trc_rcb_dec_kernel(
         qout.put(0, pc0); qout.put(1, pc1); qout.put(2, pc2); qout.put(3, pc3);
         qout.flush(wc, s * TRC_SEG);
     }
-    trc_wave_copy_raw(__ballot(alive && cl == len && len != 0), off, len, out + (u64)wc.c0 * chunk, chunk, payload);
+    if (!wc.prog) trc_wave_copy_raw(__ballot(alive && cl == len && len != 0), off, len, out + (u64)wc.c0 * chunk, chunk, payload);
 }
 
+bool trc_rcb_dec_prog_ok() { return true; }
 bool trc_rcb_enc_gate_ok()
 {
     const int env = getenv("TRC_RCB_L7G") ? atoi(getenv("TRC_RCB_L7G")) : -1, env_mc = getenv("TRC_RCB_MC") ? atoi(getenv("TRC_RCB_MC")) : -1;
@@ -643,5 +650,5 @@ void trc_launch_rcb_dec(const uint8_t *d_payload, const uint32_t *d_clen, size_t
 {
     TRC_RAISE_LDS_ONCE(trc_rcb_dec_kernel, TRC_WPG * RCB_WAVE_LDS);
     TRC_LAUNCH_TIMED(trc_rcb_dec_kernel, TRC_QUAD_GRID(w.ngroups), dim3(64 * TRC_WPG), TRC_WPG * (RCB_WAVE_LDS), s,
-                       d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, d_out);
+                       d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, d_out, trc_prog_tls.counters, trc_prog_tls.host_flags, trc_prog_tls.part);
 }
