@@ -22,6 +22,13 @@
  * Host-pointer calls wrap this in a self-describing container:
  *        trc_container_hdr (32 B) | uint32 clen[nchunks] | payload bytes
  * and keep the reference's return convention (== inlen  =>  out is a raw copy of in).
+ *
+ * How a host-pointer call runs (csrc/trc_host.inc): a PCIe pipeline per device -- the chunk chosen for the
+ * stored size (trc_auto_chunk_codec), slices coded concurrently on two coder streams, pageable memory staged in 8 MB pieces by copy
+ * threads, page-locked caller buffers (trc_host_pin) read and written by DMA directly.  For rccdf / rccdfi / anscdf / rcs the input
+ * is delivered in striped passes (the k-th part of every chunk per 2-D copy) to an encoder that is already waiting at an arrival
+ * gate, and a decoder's output is fetched part by part while it is still running; trc_set_devices / TRC_DEVICES spread a call over
+ * several GPUs.  None of this changes a byte of the container.
  */
 #ifndef TRC_HIP_H_
 #define TRC_HIP_H_
