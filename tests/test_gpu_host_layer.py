@@ -150,6 +150,10 @@ import sys
 sys.path.insert(0, "tests"); sys.path.insert(0, "turbo-range-coder_amd")
 import numpy as np, trc, trc_testlib as T
 from golden.make_golden import gen
+import ctypes
+lib = trc.lib()
+lib.trc_host_pin.restype = ctypes.c_int; lib.trc_host_pin.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+lib.trc_host_unpin.restype = ctypes.c_int; lib.trc_host_unpin.argtypes = [ctypes.c_void_p]
 rng = np.random.default_rng(5)
 n_calls = 0
 for codec in (trc.RCA, trc.RCAI, trc.ANSA, trc.RCB):
@@ -162,7 +166,10 @@ for codec in (trc.RCA, trc.RCAI, trc.ANSA, trc.RCB):
         d = gen(("text", "zipf", "runs")[it % 3], n, 900 + 31 * it + codec)
         if it == 4:
             u = gen("uniform", n, 77); d[n // 3:n // 3 + 50000] = u[n // 3:n // 3 + 50000]      # raw chunks among coded ones
+        pin = it != 5                                      # striped input needs a page-locked source (every copy queued before the waiting kernel)
+        if pin: assert lib.trc_host_pin(d.ctypes.data, d.nbytes) == 0
         comp = trc.host_encode(codec, d)
+        if pin: lib.trc_host_unpin(d.ctypes.data)
         if comp.size == n:
             assert np.array_equal(comp, d); continue
         hdr, clen, payload = trc.parse_container(comp)
@@ -180,7 +187,8 @@ def test_striped_encode_matches_the_oracle_call_after_call(torch_cuda):
     """round 6: the encoders of rccdf / rccdfi / anscdf / rcs are launched BEFORE their input has arrived and wait at an arrival gate
     for each of its K passes (trc_io.h, trc_host.inc).  28 calls on the same buffers, sizes from one chunk to 6 MB, ragged ends, raw
     chunks: every payload equals the oracle's per-chunk output; the same through the slice pipeline (TRC_HOST_NO_STRIPE) and over
-    a device list; pageable buffers (numpy arrays are)."""
+    a device list.  The input is page-locked (striping needs every copy queued before the waiting kernel); one call in seven and every
+    output buffer are pageable (streamed decodes scatter through the staging slots)."""
     for env in ({}, {"TRC_HOST_NO_STRIPE": "1"}, {"TRC_DEVICES": "0,0"}, {"TRC_HOST_PIECE": "262144"}):
         out = _child(STRIPED, env).split()
         assert out[0] == "ok" and int(out[1]) >= 20, (env, out)
@@ -195,7 +203,10 @@ import sys, time
 sys.path.insert(0, "tests"); sys.path.insert(0, "turbo-range-coder_amd")
 import numpy as np, trc, trc_testlib as T
 from golden.make_golden import gen
+import ctypes
 d = gen("text", 3000001, 5)
+trc.lib().trc_host_pin.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+assert trc.lib().trc_host_pin(d.ctypes.data, d.nbytes) == 0
 t0 = time.time(); a = trc.host_encode(trc.RCA, d); t1 = time.time(); b = trc.host_encode(trc.RCA, d); t2 = time.time()
 hdr, clen, payload = trc.parse_container(a)
 ep, ec = T.orc_chunked_enc_mt(trc.RCA, d, hdr["chunk"], None, 0)
