@@ -121,6 +121,11 @@ uint32_t trc_auto_chunk_codec(int codec, size_t n);
  * pipelines on one device: what the tests do on a one-GPU box).  trc_get_devices returns the list length. */
 int trc_set_devices(const int *devs, int ndev);
 int trc_get_devices(int *devs, int cap);
+/* Diagnostic (needs no device): how a host-pointer call of n bytes would run on one pipeline.  chunk 0 = the automatic one; decode 0 / 1;
+ * page_locked: the caller's input (encode) or output (decode) buffer is page-locked.  first_chunk[0 .. slices] <- the first chunk of every
+ * slice (launch), the last entry = the number of chunks (at most `cap` entries are written); *part_bytes <- bytes of a chunk per pass when
+ * the call is striped (encode) / streamed (decode), else 0.  Returns the number of slices, or a negative error code. */
+int trc_host_plan(int codec, size_t n, uint32_t chunk, int decode, int page_locked, size_t *first_chunk, int cap, uint32_t *part_bytes);
 /* the chunk for a DEVICE-RESIDENT call of n bytes (one launch over the whole input): the largest multiple of 64 <= 4096 that
  * makes the input a whole number of residency rounds of the coder's lanes, barely (a launch lasts rounds x one wave's time:
  * 100 MB of the model-per-lane coders at 1280 instead of 1536 is half the throughput).  What bench.py runs every coder at. */

@@ -133,3 +133,46 @@ size_t f(unsigned char *a, size_t n, unsigned char *b, cdf_t *c) { return _anscd
 ''')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)])
     subprocess.check_call(["g++", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-x", "c++", str(src)])
+
+
+def test_host_call_plans(lib):
+    """the slices (launches) and parts of a host-pointer call, for every coder / size / chunk / buffer kind (trc_host_plan needs no device):
+    slices tile the chunk range and start on group boundaries (the decoders find a slice's payload through per-group sums: a slice that
+    started inside a group decoded from the wrong offset in the first version of round 6's plan); striped / streamed calls only for the
+    coders that support them, from page-locked input (encode), with parts that are multiples of 128 bytes of at least 1 KB, at most
+    eight of them (pageable output: four), and launches of at most one residency round"""
+    import numpy as np
+    lib.trc_host_plan.restype = ctypes.c_int
+    lib.trc_host_plan.argtypes = [ctypes.c_int, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t), ctypes.c_int, ctypes.POINTER(ctypes.c_uint32)]
+    lib.trc_auto_chunk_codec.restype = ctypes.c_uint32
+    lib.trc_auto_chunk_codec.argtypes = [ctypes.c_int, ctypes.c_size_t]
+    first = (ctypes.c_size_t * 4096)()
+    part = ctypes.c_uint32(0)
+    gated_codecs = {4, 5, 6, 7}                                  # rccdf, anscdf, rcs, rccdfi
+    rounds = {1: 196608, 2: 196608, 3: 98304, 11: 196608, 4: 65536, 5: 65536, 6: 65536, 7: 65536, 13: 65536}
+    seen_gated = 0
+    for codec in (1, 2, 3, 4, 5, 6, 7, 11, 12, 13, 26):
+        for n in (1, 4095, 4096, 70001, 1 << 20, 5 * 10**6 + 3, 100 * 10**6, 333 * 10**6 + 77, 10**9, 3 * 10**9 + 5):
+            for chunk in (0, 512, 1024, 2048, 4096, 4160, 16384, 65536):
+                for decode in (0, 1):
+                    for pinned in (0, 1):
+                        ch = chunk or lib.trc_auto_chunk_codec(codec, n)
+                        if codec == 13 and ch > 8192:
+                            continue
+                        nsl = lib.trc_host_plan(codec, n, chunk, decode, pinned, first, 4096, ctypes.byref(part))
+                        assert 1 <= nsl <= 2100, (codec, n, chunk, decode, pinned, nsl)
+                        f = np.array(first[:nsl + 1], dtype=np.int64)
+                        nch = -(-n // ch)
+                        assert f[0] == 0 and f[-1] == nch and np.all(np.diff(f) > 0), (codec, n, chunk, f[:5])
+                        assert np.all(f[:-1] % 64 == 0), (codec, n, chunk, decode, pinned, f[:8])
+                        if part.value:
+                            seen_gated += 1
+                            assert codec in gated_codecs and ch % 128 == 0 and ch >= 2048 and n >= ch
+                            assert decode or pinned, "striped input needs page-locked memory"
+                            assert part.value % 128 == 0 and part.value >= 1024 and -(-ch // part.value) <= (8 if (pinned or not decode) else 4)
+                            assert np.all(np.diff(f) <= rounds[codec]), "a gated launch is at most one residency round"
+                            if decode:
+                                assert n <= (512 << 20 if pinned else 256 << 20)
+                        else:
+                            assert not (codec in gated_codecs and ch % 128 == 0 and ch >= 2048 and n >= ch and pinned and (not decode or n <= (512 << 20)) and "TRC_HOST_NO_STRIPE" not in os.environ and "TRC_HOST_NO_GATE" not in os.environ and nsl <= 16), (codec, n, chunk, decode)
+    assert seen_gated > 100
