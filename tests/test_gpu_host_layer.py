@@ -219,3 +219,12 @@ print("ok %.2f %.2f" % (t1 - t0, t2 - t1))
     assert r.stdout.split()[0] == "ok" and "an arrival gate timed out" in r.stderr, r.stdout + r.stderr[-2000:]
     first, second = float(r.stdout.split()[1]), float(r.stdout.split()[2])
     assert first > 0.3 and second < 0.3, (first, second)               # the first call waited for the timeout, the second one no longer uses gates
+
+
+def test_soak_of_the_host_layer(torch_cuda):
+    """scripts/soak_host_layer.py for half a minute: random calls (nine coders, 1 B ... 40 MB, five kinds of data, pageable and page-locked
+    buffers, one pipeline or a device list, one caller or three at once), every container against the oracle, every decode against the
+    input -- and no arrival gate may time out on the way (the first soak of round 6 found a copy stuck behind a waiting kernel)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "soak_host_layer.py"), "30", "3"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and "all containers equal the oracle's" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "timed out" not in r.stderr, r.stderr[-2000:]
