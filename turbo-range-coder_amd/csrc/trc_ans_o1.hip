@@ -487,58 +487,117 @@ __global__ __launch_bounds__(64) void trc_o1_sort_kernel(
     }
 }
 
+// Round 6: FOUR waves per workgroup, ONE workgroup per CU (its LDS request is padded past half a CU's), G chunks per workgroup -- a wave has
+// its SIMD to itself.  Per-wave clocks (-DTRC_O1W_PROF, profiles/r06_o1_walk_prof.txt) showed what the kernel's time is: its longest
+// chain (drift100m: 259 rounds, a chain as long as its chunk) times a wave's time per round, and a wave alone on its SIMD makes a round in
+// 3.0 us where two sharing one take 4.1-5.8 each.  G = 96 puts 100 MB (24 414 chunks) on 255 workgroups with 244 rounds of work per lane --
+// every wave ends with the longest chain.  The long chains' order of length comes from a counting sort over 80 length classes (the rank
+// by comparison of every pair took 27 us of the prologue at G = 32 and 150 at G = 96).
 #ifndef O1W_WAVES
-#define O1W_WAVES    2u
+#define O1W_WAVES    4u
 #endif
-#ifndef O1W_GROUP
-#define O1W_GROUP    32u                                        // chunks per workgroup
+#ifndef O1W_GROUP_MAX
+#define O1W_GROUP_MAX 96u                                       // chunks per workgroup, at most (the launch picks G: trc_launch_anso1_model)
 #endif
-#define O1W_NH       (TRC_NIBK_BYTES + 16u)
-#define O1W_BIG      (O1W_NH + O1W_GROUP * O1S_NHN * 2u)        // u32[GROUP x 16] as read, then the same sorted by length
-#define O1W_TAKEN    (O1W_BIG + 2u * O1W_GROUP * 64u)           // one bit per unit: somebody walks it
-#define O1W_STAGE    (O1W_TAKEN + O1W_GROUP * 32u)
-#define O1W_LDS      (O1W_STAGE + O1W_WAVES * 8u * 1024u)
-__global__ __launch_bounds__(64 * O1W_WAVES) void trc_o1_walk_kernel(u32 nchunks, u8 *__restrict__ model)
+#define O1W_NCLS     80u                                        // length classes of the long chains (64 entries wide, longest first)
+#define O1W_HIST     (TRC_NIBK_BYTES + 32u)                     // u32[NCLS]
+#define O1W_NH       (TRC_NIBK_BYTES + 32u + O1W_NCLS * 4u)
+#define O1W_BIG(G)   (O1W_NH + (G) * O1S_NHN * 2u)              // u32[G x 16] as read, then the same by length class
+#define O1W_TAKEN(G) (O1W_BIG(G) + 2u * (G) * 64u)              // one bit per unit: on the list already (a long chain's unit)
+#define O1W_ULIST(G) (O1W_TAKEN(G) + (G) * 32u)                 // u16[G x (16 + SEGS)]: the units to walk, chunk << 8 | unit (0xffff: none)
+#define O1W_STAGE(G) (O1W_ULIST(G) + (G) * (16u + O1S_SEGS) * 2u)
+#define O1W_LDS(G)   (O1W_STAGE(G) + O1W_WAVES * 8u * 1024u)
+#ifdef TRC_O1W_PROF                                              // variant builds only: wall clocks (100 MHz) and rounds per wave
+__device__ unsigned long long trc_o1w_prof[4 * 4096];
+#endif
+__global__ __launch_bounds__(64 * O1W_WAVES) void trc_o1_walk_kernel(u32 nchunks, u32 G, u8 *__restrict__ model)
 {
+#ifdef TRC_O1W_PROF
+    const u64 pw0 = wall_clock64(); u64 pw1 = 0, prounds = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) u8 smem_wg_[];
     u8 *const kb = smem_wg_;
-    u32 *const ctr = (u32 *)(smem_wg_ + TRC_NIBK_BYTES);
+    u32 *const ctr = (u32 *)(smem_wg_ + TRC_NIBK_BYTES);        // [0] the next list entry, [1] long chains, [4 + w] wave w's share of the other units
+    u32 *const hist = (u32 *)(smem_wg_ + O1W_HIST);
     const u16 *const nh = (const u16 *)(smem_wg_ + O1W_NH);
-    u32 *const big = (u32 *)(smem_wg_ + O1W_BIG), *const bigs = big + O1W_GROUP * 16u;
-    u32 *const taken = (u32 *)(smem_wg_ + O1W_TAKEN);           // [chunk][8]
+    u32 *const big = (u32 *)(smem_wg_ + O1W_BIG(G)), *const bigs = big + G * 16u;
+    u32 *const taken = (u32 *)(smem_wg_ + O1W_TAKEN(G));        // [chunk][8]
+    u16 *const ulist = (u16 *)(smem_wg_ + O1W_ULIST(G));
     const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = trc_lane();
-    const u32 stage_a = (u32)__builtin_amdgcn_readfirstlane((int)trc_lds_addr(smem_wg_ + O1W_STAGE + wv * 8192u));
-    const u32 c0 = blockIdx.x * O1W_GROUP;
-    const u32 rows = nchunks - c0 < O1W_GROUP ? nchunks - c0 : O1W_GROUP;
+    const u32 stage_a = (u32)__builtin_amdgcn_readfirstlane((int)trc_lds_addr(smem_wg_ + O1W_STAGE(G) + wv * 8192u));
+    const u32 c0 = blockIdx.x * G;
+    const u32 rows = nchunks - c0 < G ? nchunks - c0 : G;
     u8 *const gbase = model + (u64)c0 * O1_MODEL_BYTES;
-    if (threadIdx.x == 0u) ctr[0] = 0u;
-    for (u32 i = threadIdx.x; i < O1W_GROUP * O1S_NHN / 8u; i += 64u * O1W_WAVES) {       // the group's unit directory
+    if (threadIdx.x < 8u) ctr[threadIdx.x] = 0u;
+    for (u32 i = threadIdx.x; i < O1W_NCLS; i += 64u * O1W_WAVES) hist[i] = 0u;
+    for (u32 i = threadIdx.x; i < G * O1S_NHN / 8u; i += 64u * O1W_WAVES) {               // the group's unit directory
         const u32 ci = i / (O1S_NHN / 8u), q = i % (O1S_NHN / 8u);
         ((uint4 *)(smem_wg_ + O1W_NH))[i] = ci < rows ? *(const uint4 *)(gbase + (size_t)ci * O1_MODEL_BYTES + O1S_NH + q * 16u)
                                                       : make_uint4(0, 0, 0, 0);
     }
-    for (u32 i = threadIdx.x; i < O1W_GROUP * 16u; i += 64u * O1W_WAVES) {                // its long chains: length << 16 | chunk << 8 | unit
+    for (u32 i = threadIdx.x; i < G * 8u; i += 64u * O1W_WAVES) taken[i] = 0u;
+    o1_init_k(kb);                                              // (every wave writes the same K; ends with the barrier)
+    // its long chains (length << 16 | chunk << 8 | unit), longest first: counted by length class, scanned, placed
+    auto cls_of = [](u32 v) -> u32 { const u32 q = v >> 22; return O1W_NCLS - 1u - (q < O1W_NCLS ? q : O1W_NCLS - 1u); };
+    for (u32 i = threadIdx.x; i < G * 16u; i += 64u * O1W_WAVES) {
         const u32 ci = i >> 4;
         const u32 v = ci < rows ? ((const u32 *)(gbase + (size_t)ci * O1_MODEL_BYTES + O1S_BIG))[i & 15u] : 0u;
-        big[i] = v ? (v >> 8) << 16 | ci << 8 | (v & 255u) : 0u;
-        bigs[i] = 0u;
+        const u32 it = v ? (v >> 8) << 16 | ci << 8 | (v & 255u) : 0u;
+        big[i] = it;
+        if (it) atomicAdd(&hist[cls_of(it)], 1u);
     }
-    for (u32 i = threadIdx.x; i < O1W_GROUP * 8u; i += 64u * O1W_WAVES) taken[i] = 0u;
-    o1_init_k(kb);                                              // (every wave writes the same K; ends with the barrier)
-    for (u32 i = threadIdx.x; i < O1W_GROUP * 16u; i += 64u * O1W_WAVES) {                // longest first: an item's rank is the number of items before it
-        const u32 v = big[i];
-        if (v) {
-            u32 rk = 0;
-            for (u32 k = 0; k < O1W_GROUP * 16u; k++) { const u32 o = big[k]; rk += (o > v || (o == v && k < i)) ? 1u : 0u; }
-            bigs[rk] = v;
+    __syncthreads();
+    if (wv == 0u) {                                             // class counts -> class starts (two classes per lane)
+        const u32 h0 = lane < O1W_NCLS / 2u ? hist[2u * lane] : 0u, h1 = lane < O1W_NCLS / 2u ? hist[2u * lane + 1u] : 0u;
+        const u32 incl = trc_wave_incl_scan(h0 + h1);
+        if (lane < O1W_NCLS / 2u) { hist[2u * lane] = incl - h0 - h1; hist[2u * lane + 1u] = incl - h1; }
+        if (lane == 63u) ctr[1] = incl;
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < G * 16u; i += 64u * O1W_WAVES) {
+        const u32 it = big[i];
+        if (it) bigs[atomicAdd(&hist[cls_of(it)], 1u)] = it;
+    }
+    __syncthreads();
+    // The list of units to walk (round 6; until then every lane asked for "the next unit" in each of a round's four slots and learnt by
+    // three dependent LDS round trips whether a chain started in it and nobody had it -- and half of a chunk's 168 units lie behind the
+    // end of its stream): the long chains' units in order of length (a unit two long chains start in: once), then every other unit a
+    // chain starts in, every wave compacting its share of them (counted first: no atomics).
+    const u32 nbig = ctr[1];
+    for (u32 i = threadIdx.x; i < nbig; i += 64u * O1W_WAVES) {
+        const u32 it = bigs[i], ci = (it >> 8) & 255u, j = it & 255u, bit = 1u << (j & 31u);
+        ulist[i] = (atomicOr(&taken[ci * 8u + (j >> 5)], bit) & bit) ? (u16)0xffffu : (u16)(it & 0xffffu);
+    }
+    __syncthreads();
+    {
+        const u32 U = G * O1S_SEGS, per = ((U + 64u * O1W_WAVES - 1u) / (64u * O1W_WAVES)) * 64u;   // units per wave, in rows of 64
+        const u32 u0 = wv * per;
+        auto is_put = [&](u32 i) -> bool {
+            const u32 ci = i / O1S_SEGS, j = i % O1S_SEGS;
+            return i < U && ci < rows && nh[ci * O1S_NHN + j] < j * 128u + 128u && !((taken[ci * 8u + (j >> 5)] >> (j & 31u)) & 1u);
+        };
+        u32 cnt = 0;
+        for (u32 i0 = 0; i0 < per; i0 += 64u) cnt += (u32)__popcll(__ballot(is_put(u0 + i0 + lane)));
+        if (lane == 0u) ctr[4u + wv] = cnt;
+        __syncthreads();
+        u32 at = nbig;
+        for (u32 k = 0; k < wv; k++) at += ctr[4u + k];
+        for (u32 i0 = 0; i0 < per; i0 += 64u) {
+            const u32 i = u0 + i0 + lane;
+            const bool put = is_put(i);
+            const u64 m = __ballot(put);
+            if (put) ulist[at + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u))] = (u16)((i / O1S_SEGS) << 8 | (i % O1S_SEGS));
+            at += (u32)__popcll(m);
         }
     }
     __syncthreads();
+    u32 nunits = nbig;
+    for (u32 k = 0; k < O1W_WAVES; k++) nunits += ctr[4u + k];
 
-    const u32 nbig = O1W_GROUP * 16u, nunits = nbig + rows * O1S_SEGS;      // the long chains' units (zeros: none), then every unit
     NibTable T = O1Cache::fresh();
-    bool active = false, done = false;
+    bool active = false, done = false, spare = false;
     u32 widx = 0, uend = 0;                                     // the window to ask for next, the end of the unit
+    u32 sp_ci = 0, sp_us = 0, sp_ue = 0;                        // the unit in reserve
     u8 *sbase = gbase;
     uint4 rec[4];
     u8 *recp[4], *reqp[4];                                      // where the records of the windows walked / asked for in this round go
@@ -547,10 +606,32 @@ __global__ __launch_bounds__(64 * O1W_WAVES) void trc_o1_walk_kernel(u32 nchunks
     for (u32 w = 0; w < 4u; w++) { recp[w] = gbase; reqp[w] = gbase; recv[w] = false; reqv[w] = false; rec[w] = make_uint4(0, 0, 0, 0); }
     u32 buf = 0;
     bool more = true;
+#ifdef TRC_O1W_PROF
+    pw1 = wall_clock64();
+#endif
     while (more) {
+#ifdef TRC_O1W_PROF
+        prounds++;
+#endif
         // A round = four windows per lane.  Everything asked for a round ago -- the windows of this round, the record stores of the
         // last -- is a round old here: the one wait of the loop finds it done.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // This round's windows (asked for a round ago) are read here, and the K rows (K[sym], 32 bytes per entry) of a window are asked for
+        // a window ahead: a wave alone on its SIMD has nobody to hide its LDS round trips behind (0.79 -> 0.73 ms).
+        uint4 W[4];
+#pragma unroll
+        for (u32 w = 0; w < 4u; w++) W[w] = trc_ldsr128(stage_a + buf * 4096u + w * 1024u + lane * 16u);
+        const u32 kb_a = trc_lds_addr(kb);
+        uint4 Ka[2][4], Kb[2][4];
+        auto ask = [&](u32 w, u32 b) __attribute__((always_inline)) {
+            const u32 e[4] = { W[w].x, W[w].y, W[w].z, W[w].w };
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const u32 a = kb_a + ((e[i] >> 7) & 0x1e0u);       // 32 x the symbol (bits 12..15)
+                Ka[b][i] = trc_ldsr128(a); Kb[b][i] = trc_ldsr128(a + 16u);
+            }
+        };
+        ask(0, 0);
         {   // The four windows of a lane are usually 64 consecutive bytes.  Stored lane by lane they are 16-byte pieces of 64 different
             // lines per instruction, and a piece costs the memory system what a whole sector does (this kernel: 1.43 ms, 0.99 without
             // its stores).  Transposed across the quad -- records AND addresses -- instruction j has the quad's four lanes write the
@@ -568,25 +649,26 @@ __global__ __launch_bounds__(64 * O1W_WAVES) void trc_o1_walk_kernel(u32 nchunks
         }
 #pragma unroll
         for (u32 w = 0; w < 4u; w++) { recp[w] = reqp[w]; recv[w] = reqv[w]; }
-        const u32 rd = stage_a + buf * 4096u, wr = stage_a + (buf ^ 1u) * 4096u;
+        const u32 wr = stage_a + (buf ^ 1u) * 4096u;
         buf ^= 1u;
+        if (!spare && !done && (!active || uend - widx <= 32u)) {   // a unit in reserve when this one is within two rounds of its end (not earlier: whoever is free first takes the next longest)
+            const u32 g = atomicAdd(&ctr[0], 1u);
+            if (g >= nunits) done = true;
+            else {
+                const u32 u = ulist[g];
+                if (u != 0xffffu) {
+                    sp_ci = u >> 8;
+                    sp_us = nh[sp_ci * O1S_NHN + (u & 255u)]; sp_ue = nh[sp_ci * O1S_NHN + (u & 255u) + 1u];
+                    spare = true;
+                }
+            }
+        }
 #pragma unroll
         for (u32 w = 0; w < 4u; w++) {                          // ask for the next round's windows
             if (active && widx >= uend) active = false;
-            if (!active && !done) {                             // take the next unit
-                const u32 g = atomicAdd(&ctr[0], 1u);
-                if (g >= nunits) done = true;
-                else {
-                    const u32 it = g < nbig ? bigs[g] : 0u, h = g - nbig;
-                    const u32 ci = g < nbig ? (it >> 8) & 255u : h / O1S_SEGS, j = g < nbig ? it & 255u : h % O1S_SEGS;
-                    const u32 us = nh[ci * O1S_NHN + j], ue = nh[ci * O1S_NHN + j + 1u];
-                    const bool mine = (g >= nbig || it != 0u) && us < j * 128u + 128u &&
-                                      !(atomicOr(&taken[ci * 8u + (j >> 5)], 1u << (j & 31u)) & (1u << (j & 31u)));
-                    if (mine) {                                 // a chain starts in this unit and nobody has it: walk from there to the first start behind the unit
-                        sbase = gbase + (size_t)ci * O1_MODEL_BYTES + O1S_STREAM;
-                        widx = us; uend = ue; active = true;
-                    }
-                }
+            if (!active && spare) {                             // on to the unit in reserve
+                sbase = gbase + (size_t)sp_ci * O1_MODEL_BYTES + O1S_STREAM;
+                widx = sp_us; uend = sp_ue; active = true; spare = false;
             }
             // window k of a stream only in slot k mod 4 of a round: a lane's four windows of a round are then ONE 64-byte sector
             // (a unit that starts elsewhere idles up to three slots first)
@@ -599,28 +681,39 @@ __global__ __launch_bounds__(64 * O1W_WAVES) void trc_o1_walk_kernel(u32 nchunks
                          : "=&s"(keep) : "v"(src), "s"(row) : "memory");
             if (go) widx += 4u;
         }
+        {   // walk this round's windows
 #pragma unroll
-        for (u32 w = 0; w < 4u; w++) {                          // walk this round's windows (asked for a round ago)
-            const uint4 W = trc_ldsr128(rd + w * 1024u + lane * 16u);
-            const u32 e[4] = { W.x, W.y, W.z, W.w };
-            u32 r[4];
-            if (e[0] & O1S_HEAD) T = O1Cache::fresh();          // (chains start on windows; behind a chain's last entry the table is garbage until then: nobody reads it)
+            for (u32 w = 0; w < 4u; w++) {
+                if (w + 1u < 4u) ask(w + 1u, (w + 1u) & 1u);
+                const u32 e[4] = { W[w].x, W[w].y, W[w].z, W[w].w };
+                u32 r[4];
+                if (e[0] & O1S_HEAD) T = O1Cache::fresh();      // (chains start on windows; behind a chain's last entry the table is garbage until then: nobody reads it)
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const u32 sym = (e[i] >> 12) & 15u;
-                u32 a0, a1;
-                o1_bounds(T, sym, a0, a1);
-                o1_adapt(T, kb, sym);
-                r[i] = (a0 << TRC_PROB_BITS) | (a1 - a0);
+                for (int i = 0; i < 4; i++) {
+                    const u32 sym = (e[i] >> 12) & 15u;
+                    u32 a0, a1;
+                    o1_bounds(T, sym, a0, a1);
+                    const uint4 ka = Ka[w & 1u][i], kc = Kb[w & 1u][i];
+                    const u32 K[8] = { ka.x, ka.y, ka.z, ka.w, kc.x, kc.y, kc.z, kc.w };
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const trc_s2 v = trc_as_s2(T.d[k]);
+                        T.d[k] = trc_as_u32(v + ((trc_as_s2(K[k]) - v) >> (trc_s2)7));
+                    }
+                    r[i] = (a0 << TRC_PROB_BITS) | (a1 - a0);
+                }
+                rec[w] = make_uint4(r[0], r[1], r[2], r[3]);
             }
-            rec[w] = make_uint4(r[0], r[1], r[2], r[3]);
         }
-        bool pend = !done || active;
+        bool pend = !done || active || spare;
 #pragma unroll
         for (u32 w = 0; w < 4u; w++) pend = pend || recv[w] || reqv[w];
         more = __ballot(pend) != 0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (the last round's requests write LDS: not behind the wave's end)
+#ifdef TRC_O1W_PROF
+    if (lane == 0u) { const u32 wid = (blockIdx.x * O1W_WAVES + wv) & 4095u; trc_o1w_prof[4 * wid] = pw0; trc_o1w_prof[4 * wid + 1] = pw1; trc_o1w_prof[4 * wid + 2] = wall_clock64(); trc_o1w_prof[4 * wid + 3] = prounds; }
+#endif
 }
 
 #define O1P_SLOTS    9216u
@@ -948,7 +1041,12 @@ bool trc_launch_anso1_model(const uint8_t *d_in, size_t n, uint32_t chunk, const
     static const int chains = getenv("TRC_O1_CHAINS") ? atoi(getenv("TRC_O1_CHAINS")) : 1;   // 0: the position-order passes below
     if (chains && chunk <= 4096u) {
         TRC_LAUNCH_TIMED(trc_o1_sort_kernel, dim3(w.nchunks), dim3(64), 0, s, d_in, (u64)n, chunk, w.nchunks, w.model);
-        TRC_LAUNCH_TIMED(trc_o1_walk_kernel, dim3((w.nchunks + O1W_GROUP - 1u) / O1W_GROUP), dim3(64 * O1W_WAVES), O1W_LDS, s, w.nchunks, w.model);
+        // G chunks per workgroup: the chip's 256 CUs take one workgroup each (four waves, a SIMD each); beyond 96 a lane's share of the
+        // work outlasts the longest chain a chunk can hold (4096 entries: 259 rounds) and several workgroups per CU take turns
+        const u32 gq = (w.nchunks + 255u) / 256u, G = gq > O1W_GROUP_MAX ? O1W_GROUP_MAX : gq ? gq : 1u;
+        const u32 lds = O1W_LDS(G) > TRC_LDS_ONE_PER_CU ? O1W_LDS(G) : TRC_LDS_ONE_PER_CU;
+        TRC_RAISE_LDS_ONCE(trc_o1_walk_kernel, O1W_LDS(O1W_GROUP_MAX) > TRC_LDS_ONE_PER_CU ? O1W_LDS(O1W_GROUP_MAX) : TRC_LDS_ONE_PER_CU);
+        TRC_LAUNCH_TIMED(trc_o1_walk_kernel, dim3((w.nchunks + G - 1u) / G), dim3(64 * O1W_WAVES), lds, s, w.nchunks, G, w.model);
         TRC_LAUNCH_TIMED(trc_o1_place_kernel, dim3(w.nchunks), dim3(256), 0, s, (u64)n, chunk, w.nchunks, (const u8 *)w.model, w.scratch2);
         return true;
     }
@@ -982,3 +1080,9 @@ void trc_launch_anso1_dec(const uint8_t *d_payload, const uint32_t *d_clen, size
     else
         TRC_LAUNCH_TIMED(trc_o1_dec_kernel<64>, dim3(w.ngroups), dim3(64), 0, s, d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, w.model, d_out);
 }
+#ifdef TRC_O1W_PROF
+extern "C" __attribute__((visibility("default"))) int trc_o1w_prof_read(void *dst, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(trc_o1w_prof), bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
