@@ -423,7 +423,7 @@ __global__ __launch_bounds__(64) void trc_o1_sort_kernel(
             if (a >= O1S_BIGMIN) { const u32 k = atomicAdd(&big_[16], 1u); if (k < 16u) big_[k] = a << 8 | sa >> 7; }
             if (b >= O1S_BIGMIN) { const u32 k = atomicAdd(&big_[16], 1u); if (k < 16u) big_[k] = b << 8 | sb >> 7; }
             start = sb + o1s_up4(b);
-            ((u32 *)(bins + lane * 136u))[i] = sa | sb << 16;
+            ((u32 *)(bins + lane * 136u))[i] = (sa | (a ? 0x8000u : 0u)) | (sb | (b ? 0x8000u : 0u)) << 16;   // bit 15: the chain has not begun (starts are below 21 252)
         }
         const u32 L = (u32)__builtin_amdgcn_readlane((int)incl, 63);
         if (lane == 0u) *(u32 *)(blk + O1S_LEN) = L;
@@ -453,36 +453,44 @@ __global__ __launch_bounds__(64) void trc_o1_sort_kernel(
         if (lane * 3u + 2u < O1S_NHN) nh[lane * 3u + 2u] = (u16)n2;
     }
     u32 *const perm = (u32 *)(blk + O1S_PERM);
+    // The lanes of this row with the same hi key / the same lo key as mine: the key's bits as ballots, lane order = position order, so a
+    // lane's rank among them is a count of lower bits (deterministic, no atomics).  Round 6: a bit's ballot B and the lane's own bit s
+    // (0 / -1) give "differs from me in this bit" as B ^ s, the differences are ORed three at a time -- five instructions per bit where
+    // the selects between B and ~B took eight -- and a chain's first entry is whoever finds bit 15 of its bin still set (was: two reads
+    // of the marks).  (The masks from LDS instead -- every lane ORing its bit into the word of its context and of its hi nibble, one
+    // read back -- is SLOWER, 0.80 -> 1.00 ms: same-address 64-bit atomics serialise, and a row's lanes share a handful of contexts.)
     for (u32 r = 0; r < R; r++) {
         const u32 pos = r * 64u + lane;
         const bool valid = pos < plen;
         const u32 x = valid && pos < len ? bytes[pos] : 0u, pv = valid && pos ? bytes[pos - 1u] : 0u;
-        // lanes of this row with the same hi key / the same lo key as mine (the key's bits as ballots; lane order = position order)
-        u64 mh = __ballot(valid);
+        const u64 vm = __ballot(valid);
+        u32 dh0 = 0, dh1 = 0, dl0 = 0, dl1 = 0;                 // lanes that differ from this one in some bit of pv / of x >> 4
 #pragma unroll
         for (int b = 0; b < 8; b++) {
-            const u64 B = __ballot((pv >> b) & 1u);
-            mh &= ((pv >> b) & 1u) ? B : ~B;
+            const u32 sb = (u32)__builtin_amdgcn_sbfe((int)pv, (u32)b, 1u);
+            const u64 B = __ballot(sb != 0u);
+            dh0 |= (u32)B ^ sb; dh1 |= (u32)(B >> 32) ^ sb;
         }
-        u64 ml = mh;
 #pragma unroll
         for (int b = 4; b < 8; b++) {
-            const u64 B = __ballot((x >> b) & 1u);
-            ml &= ((x >> b) & 1u) ? B : ~B;
+            const u32 sb = (u32)__builtin_amdgcn_sbfe((int)x, (u32)b, 1u);
+            const u64 B = __ballot(sb != 0u);
+            dl0 |= (u32)B ^ sb; dl1 |= (u32)(B >> 32) ^ sb;
         }
         if (valid) {
+            const u32 mh0 = (u32)vm & ~dh0, mh1 = (u32)(vm >> 32) & ~dh1, ml0 = mh0 & ~dl0, ml1 = mh1 & ~dl1;
             const u32 kh = pv, kl = 256u + (pv << 4) + (x >> 4);
             u16 *const bh = (u16 *)(bins + kh * 2u), *const bl = (u16 *)(bins + kl * 2u);
             const u32 sh = *bh, sl = *bl;
-            const u32 rh = __builtin_amdgcn_mbcnt_hi((u32)(mh >> 32), __builtin_amdgcn_mbcnt_lo((u32)mh, 0u));
-            const u32 rl = __builtin_amdgcn_mbcnt_hi((u32)(ml >> 32), __builtin_amdgcn_mbcnt_lo((u32)ml, 0u));
-            const u32 nh = (u32)__popcll(mh), nl = (u32)__popcll(ml);
-            const u32 ih = sh + rh, il = sl + rl;
-            ent[ih] = pos | (x >> 4) << 12 | ((hbits[ih >> 5] >> (ih & 31u)) & 1u) << 16;
-            ent[il] = pos | (x & 15u) << 12 | ((hbits[il >> 5] >> (il & 31u)) & 1u) << 16;
+            const u32 rh = __builtin_amdgcn_mbcnt_hi(mh1, __builtin_amdgcn_mbcnt_lo(mh0, 0u));
+            const u32 rl = __builtin_amdgcn_mbcnt_hi(ml1, __builtin_amdgcn_mbcnt_lo(ml0, 0u));
+            const u32 nh = (u32)__popc(mh0) + (u32)__popc(mh1), nl = (u32)__popc(ml0) + (u32)__popc(ml1);
+            const u32 ih = (sh & 0x7fffu) + rh, il = (sl & 0x7fffu) + rl;
+            ent[ih] = pos | (x >> 4) << 12 | (rh == 0u ? (sh >> 15) << 16 : 0u);
+            ent[il] = pos | (x & 15u) << 12 | (rl == 0u ? (sl >> 15) << 16 : 0u);
             perm[pos] = ih | il << 16;
-            if (rh == nh - 1u) *bh = (u16)(sh + nh);           // the key's last lane moves the bin on (after every lane of the row has read it)
-            if (rl == nl - 1u) *bl = (u16)(sl + nl);
+            if (rh == nh - 1u) *bh = (u16)((sh & 0x7fffu) + nh);   // the key's last lane moves the bin on (after every lane of the row has read it)
+            if (rl == nl - 1u) *bl = (u16)((sl & 0x7fffu) + nl);
         }
     }
 }
