@@ -952,12 +952,17 @@ __global__ __launch_bounds__(64) void trc_o1_dec_rows_kernel(
     const u32 lenc = coded ? len : 0u;
     u32 rpos = 0, cx = 0;
 
-    // cdf16ansdec on the row's table T (anscdf_.h:164-174): the symbol, the state update, the table update
-    auto get_nibble = [&](u32 &s, u32 &T) -> u32 {
-        const u32 slot = s & (TRC_PROB_ONE - 1u);
-        const u32 t = trc_as_u32(trc_as_s2(T) - trc_as_s2(__umul24(slot, 0x10001u) + 0x10001u));
-        const u32 f = (t >> 15) & 0x10001u;                    // per half: entry <= slot
-        u32 cnt = (u32)__popc(f);                              // the row's sum, in every lane: xor 1, xor 2, mirror of the eight
+    // cdf16ansdec on the row's table T (anscdf_.h:164-174) in two halves: the symbol; then the state update and the table update.
+    // Round 6: between the two the NEXT table's dword is asked for -- the lo table's address exists as soon as the hi nibble does, the next
+    // byte's hi table's as soon as the lo nibble does -- so its round trip runs under the ~25 instructions of the update instead of
+    // after them (the timing ablation of round 5 put 0.8 of the 3.6 ms on exposed round trips).  No table is stored between the early
+    // load and the swap that uses it, and a load of a table that turns out not to be needed is dropped.
+    struct Nib { u32 slot, f, cc; };
+    auto find = [&](u32 s, u32 T, Nib &q) -> u32 {
+        q.slot = s & (TRC_PROB_ONE - 1u);
+        const u32 t = trc_as_u32(trc_as_s2(T) - trc_as_s2(__umul24(q.slot, 0x10001u) + 0x10001u));
+        q.f = (t >> 15) & 0x10001u;                            // per half: entry <= slot
+        u32 cnt = (u32)__popc(q.f);                            // the row's sum, in every lane: xor 1, xor 2, mirror of the eight
         cnt += (u32)__builtin_amdgcn_update_dpp(0, (int)cnt, 0xB1, 0xf, 0xf, true);      // quad_perm:[1,0,3,2]
         cnt += (u32)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x4E, 0xf, 0xf, true);      // quad_perm:[2,3,0,1]
         cnt += (u32)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x141, 0xf, 0xf, true);     // row_half_mirror
@@ -965,44 +970,53 @@ __global__ __launch_bounds__(64) void trc_o1_dec_rows_kernel(
         u32 N = (u32)__builtin_amdgcn_update_dpp(0, (int)T, 0x101, 0xf, 0xf, true);      // row_shl:1 -- lane i takes lane i + 1
         N = last_lane ? TRC_PROB_ONE : N;
         const u32 V = __builtin_amdgcn_alignbit(N, T, (x << 4) & 16u);       // x even: T; odd: T.hi | N.lo << 16
-        const u32 cc = (u32)__builtin_amdgcn_ds_bpermute((int)(((x << 1) & 0x1cu) | rowb4), (int)V);
-        const u32 c0 = cc & 0xffffu;
-        s = __umul24((cc >> 16) - c0, s >> TRC_PROB_BITS) + slot - c0;
-        const u32 K = (u32)(__mul24((int)f, -32736) + (int)kbase1);
-        const trc_s2 d = (trc_as_s2(K) - trc_as_s2(T)) >> (trc_s2)7;
-        T = trc_as_u32(trc_as_s2(T) + d);
+        q.cc = (u32)__builtin_amdgcn_ds_bpermute((int)(((x << 1) & 0x1cu) | rowb4), (int)V);
         return x;
     };
+    auto finish = [&](u32 &s, u32 &T, const Nib &q) {
+        const u32 c0 = q.cc & 0xffffu;
+        s = __umul24((q.cc >> 16) - c0, s >> TRC_PROB_BITS) + q.slot - c0;
+        const u32 K = (u32)(__mul24((int)q.f, -32736) + (int)kbase1);
+        const trc_s2 d = (trc_as_s2(K) - trc_as_s2(T)) >> (trc_s2)7;
+        T = trc_as_u32(trc_as_s2(T) + d);
+    };
+    u32 pendH = 0;                                             // the dword of the next byte's hi table, asked for at the end of this byte
     auto get_byte = [&](bool act, u32 &sh, u32 &sl) -> u32 {    // context cx -> byte, which becomes the context
         const u32 cb = (cx << 9) + (cx << 5);                 // 32 x the context's first table (17 tables per context: 544 bytes)
         {
             const u32 noff = (cb ^ swz) + moff;
             if (act && noff != hoff) {                         // the row's hi table goes back to memory, the context's comes in
                 *(u32 *)(mbase + hoff) = H;
-                const u32 ld = *(const u32 *)(mbase + noff);   // (a table never written: whatever is there, dropped below)
                 const u32 a = seen + 512u + ((cx >> 5) << 2), bit = 1u << (cx & 31u);
                 const u32 bits = *(const lds_u32 *)(uintptr_t)a;
                 *(lds_u32 *)(uintptr_t)a = bits | bit;         // (every lane of the row writes the same word)
-                H = (bits & bit) ? ld : fresh;
+                H = (bits & bit) ? pendH : fresh;              // (a table never written: whatever was loaded, dropped)
                 hoff = noff;
             }
         }
-        const u32 h = get_nibble(sh, H) & 15u;
-        {
-            const u32 noff = ((cb + 32u + (h << 5)) ^ swz) + moff;
-            if (act && noff != loff) {
-                *(u32 *)(mbase + loff) = L;
-                const u32 ld = *(const u32 *)(mbase + noff);
-                const u32 a = seen + cx * 2u, bit = 1u << h;
-                const u32 bits = *(const lds_u16 *)(uintptr_t)a;
-                *(lds_u16 *)(uintptr_t)a = (u16)(bits | bit);
-                L = (bits & bit) ? ld : fresh;
-                loff = noff;
-            }
+        Nib qh, ql;
+        const u32 h = find(sh, H, qh) & 15u;
+        const u32 noffl = ((cb + 32u + (h << 5)) ^ swz) + moff;
+        const bool needl = act && noffl != loff;
+        u32 pendL = 0;
+        if (needl) pendL = *(const u32 *)(mbase + noffl);
+        finish(sh, H, qh);
+        if (needl) {
+            *(u32 *)(mbase + loff) = L;
+            const u32 a = seen + cx * 2u, bit = 1u << h;
+            const u32 bits = *(const lds_u16 *)(uintptr_t)a;
+            *(lds_u16 *)(uintptr_t)a = (u16)(bits | bit);
+            L = (bits & bit) ? pendL : fresh;
+            loff = noffl;
         }
-        const u32 l = get_nibble(sl, L) & 15u;
+        const u32 l = find(sl, L, ql) & 15u;
         const u32 b = h << 4 | l;
         cx = act ? b : cx;
+        {
+            const u32 nh = (((cx << 9) + (cx << 5)) ^ swz) + moff;
+            if (nh != hoff) pendH = *(const u32 *)(mbase + nh);
+        }
+        finish(sl, L, ql);
         return b;
     };
 
