@@ -22,7 +22,7 @@ if sys.argv[1] == "--cfg34":
             "anscdf": (1536, ["trc_ansa_model2_kernel", "trc_ansa_codeq_kernel"], ["trc_ansa_dec_kernel"]),
             "rcs": (1536, ["trc_rcb_enc_mc_kernel"], ["trc_rcb_dec_kernel"]),
             "rccdfs2": (1024, ["trc_rcs2p_enc_kernel"], ["trc_rcs2p_dec_kernel"]),
-            "anscdf1": (4096, ["trc_o1_sort_kernel", "trc_o1_walk_kernel", "trc_o1_place_kernel", "trc_ansa_codeq_kernel"], ["trc_o1_dec_rows_kernel"])}
+            "anscdf1": (4096, ["trc_o1_sort_kernel", "trc_o1_walk_kernel", "trc_o1_place_kernel", "trc_ansa_codeq_kernel"], ["trc_o1_dec_rows"])}
     sect, cur, vals = None, None, {}
     for line in open(txt):
         if line.startswith("####"):

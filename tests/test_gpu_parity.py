@@ -412,7 +412,7 @@ def test_round5_workgroup_shapes(torch_cuda):
     """) % (os.path.dirname(os.path.abspath(trc.__file__)), os.path.dirname(os.path.abspath(__file__)))
     forms = (dict(TRC_ENC_WPB="12", TRC_RCS_ENC_WPB="12", TRC_CODEQ_GPW="4", TRC_O1_ROWS="16", TRC_NIB_BIG="1"),    # the large shapes, on small inputs
              dict(TRC_ENC_WPB="4", TRC_RCS_ENC_WPB="1", TRC_CODEQ_GPW="1", TRC_O1_ROWS="64", TRC_NIB_BIG="0"),      # the small shapes
-             dict(TRC_O1_ROWS="8"))
+             dict(TRC_O1_ROWS="8"), dict(TRC_O1_ROWS="4"), dict(TRC_O1_ROWS="2"), dict(TRC_O1_ROWS="1"))     # (order-1 decoder: 4 / 2 / 1 = four / two / eight lanes per chunk)
     for env in forms:
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
         assert r.returncode == 0 and "ok" in r.stdout, (env, r.stdout[-2000:] + r.stderr[-3000:])

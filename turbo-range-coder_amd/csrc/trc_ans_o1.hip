@@ -30,7 +30,7 @@
 
 #define O1_MODEL_BYTES TRC_O1_MODEL_BYTES
 #ifndef TRC_O1_DEC_DEFAULT_ROWS                               // decoder form: 1 = eight lanes per chunk; 16 / 64 = one lane per chunk, that many chunks per wave
-#define TRC_O1_DEC_DEFAULT_ROWS(ngroups) 1
+#define TRC_O1_DEC_DEFAULT_ROWS(ngroups) ((ngroups) <= 128u ? 1 : 4)
 #endif                    // 139264 per chunk
 
 __device__ __forceinline__ NibTable o1_load(const u8 *tb)
@@ -1056,6 +1056,195 @@ __global__ __launch_bounds__(64) void trc_o1_dec_rows_kernel(
                       out + (u64)c0w * chunk, chunk, payload);
 }
 
+// --------------------------------------------------------------- decode, FOUR or TWO lanes per chunk ---
+// Round 6.  The rows form above with a CDF16 table over LANES = 4 or 2 lanes (lane e = entries 2D e .. 2D e + 2D - 1 as D = 8 / LANES packed
+// dwords: a table move is one 4D-byte access per lane, 32 bytes per row as before) and 64 / LANES chunks per wave.  Two findings behind it
+// (profiles/r06_notes.md): the eight-lane kernel is bound by what its SIMDs can issue (97 instructions per byte for eight chunks, three waves
+// per SIMD) -- this one issues ~115 for sixteen or ~150 for thirty-two -- and a wave's chain runs a third faster with its SIMD to itself (decode
+// of 4096-byte chunks: 2.2 ms alone, 2.9-3.0 sharing), so the launch picks the widest form that still puts at most one wave on a SIMD.
+// The row's sum is log2(LANES) DPP steps; the pair (t[x], t[x+1]) is a window over (T[0] .. T[D-1], the next lane's T[0]) picked by
+// x mod 2D in the lane x / 2D.
+template <u32 LANES>
+__global__ __launch_bounds__(64) void trc_o1_dec_rowsn_kernel(
+    const u8 *__restrict__ payload, const u32 *__restrict__ clen, const u64 *__restrict__ goff, const u32 *__restrict__ gsum,
+    u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ model, u8 *__restrict__ out)
+{
+    typedef __attribute__((address_space(3))) u32 lds_u32;
+    typedef __attribute__((address_space(3))) u16 lds_u16;
+    constexpr u32 D = 8u / LANES, CHUNKS = 64u / LANES;        // dwords of a table per lane; chunks per wave
+    static_assert(LANES == 2u || LANES == 4u, "two or four lanes per chunk");
+    struct Tab { u32 d[D]; };
+    __shared__ __attribute__((aligned(16))) u8 seen_s[CHUNKS * O1R_SEEN_BYTES];
+    const u32 lane = threadIdx.x, e = lane & (LANES - 1u), row = lane / LANES;
+    for (u32 i = lane; i < CHUNKS * O1R_SEEN_BYTES / 4u; i += 64u) ((u32 *)seen_s)[i] = 0u;
+    __syncthreads();
+
+    constexpr u32 WPG = 64u / CHUNKS;                          // waves per group of 64 chunks
+    const u32 g0 = (blockIdx.x / WPG) * 64u, wq = blockIdx.x % WPG;
+    const u32 lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
+    const u32 cg = g0 + lane;                                  // the directory of the whole group: lane L reads chunk g0 + L
+    const u32 lenL = cg < nchunks ? ((cg == nchunks - 1u) ? lastlen : chunk) : 0u;
+    const u32 clL = cg < nchunks ? trc_min(clen[cg], lenL) : 0u;   // a directory entry above the chunk length (corrupt input) reads as raw
+    const u32 exL = trc_wave_incl_scan(clL) - clL;
+    const u64 gbase = trc_group_base(goff, gsum, g0 >> 6);
+    // lanes 0 .. CHUNKS - 1 as "chunk wq * CHUNKS + lane of the group" (the raw copy at the end), then every lane as its row's chunk
+    const u32 srcl = (wq * CHUNKS + lane) & 63u;
+    const u32 cl_w = (u32)__shfl((int)clL, (int)srcl, 64), ex_w = (u32)__shfl((int)exL, (int)srcl, 64), len_w = (u32)__shfl((int)lenL, (int)srcl, 64);
+    const u32 cl = (u32)__shfl((int)cl_w, (int)row, 64), ex = (u32)__shfl((int)ex_w, (int)row, 64), len = (u32)__shfl((int)len_w, (int)row, 64);
+    const u32 c0w = g0 + wq * CHUNKS, c = c0w + row;
+    const bool alive = c < nchunks;
+    const u64 off = gbase + ex;
+    const bool coded = alive && cl != len;
+
+    u8 *const mbase = model + (u64)(c0w < nchunks ? c0w : 0u) * O1_MODEL_BYTES;
+    const u32 moff = row * O1_MODEL_BYTES + e * (4u * D);      // this lane's dwords of table `id`: mbase[((32 id) ^ swz) + moff]
+    const u32 swz = TRC_O1_SWIZZLE ? (c & 127u) << 5 : 0u;
+    const u32 seen = trc_lds_addr(seen_s) + row * O1R_SEEN_BYTES;
+    Tab fresh, kbase;
+#pragma unroll
+    for (u32 k = 0; k < D; k++) {
+        const u32 i0 = 2u * D * e + 2u * k;
+        fresh.d[k] = trc_pk(i0 << 11, (i0 + 1u) << 11);
+        kbase.d[k] = trc_pk(10u * i0, 10u * i0 + 10u) + 0x7fe07fe0u;   // K of a dword none of whose entries is <= slot; every such entry takes 32736 off
+    }
+    const u32 rowb4 = (lane & ~(LANES - 1u)) << 2;
+    const bool last_lane = e == LANES - 1u;
+    auto ld_tab = [&](u32 o) -> Tab {
+        Tab t;
+        if constexpr (D == 2u) { const uint2 v = *(const uint2 *)(mbase + o); t.d[0] = v.x; t.d[1] = v.y; }
+        else { const uint4 v = *(const uint4 *)(mbase + o); t.d[0] = v.x; t.d[1] = v.y; t.d[2] = v.z; t.d[3] = v.w; }
+        return t;
+    };
+    auto st_tab = [&](u32 o, const Tab &t) {
+        if constexpr (D == 2u) *(uint2 *)(mbase + o) = make_uint2(t.d[0], t.d[1]);
+        else *(uint4 *)(mbase + o) = make_uint4(t.d[0], t.d[1], t.d[2], t.d[3]);
+    };
+    // the row starts out HOLDING the hi table of context 0 and the lo table (0, 0), both fresh, both marked "seen" (as above)
+    Tab H = fresh, L = fresh;
+    u32 hoff = (0u ^ swz) + moff, loff = (32u ^ swz) + moff;
+    if (e == 0u) { *(lds_u32 *)(uintptr_t)(seen + 512u) = 1u; *(lds_u16 *)(uintptr_t)seen = (u16)1u; }
+    trc_wave_lds_fence();
+
+    u32 st0 = TRC_ANS_LOW, st1 = TRC_ANS_LOW, st2 = TRC_ANS_LOW, st3 = TRC_ANS_LOW;
+    if (coded) {                                               // decoder st[i] = encoder st[3-i] (mnfill)
+        st0 = trc_ld32_a2(payload + off); st1 = trc_ld32_a2(payload + off + 4u);
+        st2 = trc_ld32_a2(payload + off + 8u); st3 = trc_ld32_a2(payload + off + 12u);
+    }
+    const u8 *const sbase = payload + gbase;                   // the words follow the four states: sbase[soff + position]
+    const u32 soff = ex + 16u;
+    const u32 lim = trc_sub_sat(cl, 16u);
+    const u32 lenc = coded ? len : 0u;
+    u32 rpos = 0, cx = 0;
+
+    struct Nib { u32 slot, cc; Tab f; };
+    auto find = [&](u32 s, const Tab &T, Nib &q) -> u32 {
+        q.slot = s & (TRC_PROB_ONE - 1u);
+        const u32 sp = __umul24(q.slot, 0x10001u) + 0x10001u;
+        u32 cnt = 0;
+#pragma unroll
+        for (u32 k = 0; k < D; k++) {
+            const u32 t = trc_as_u32(trc_as_s2(T.d[k]) - trc_as_s2(sp));
+            q.f.d[k] = (t >> 15) & 0x10001u;                   // per half: entry <= slot
+            cnt += (u32)__popc(q.f.d[k]);
+        }
+        cnt += (u32)__builtin_amdgcn_update_dpp(0, (int)cnt, 0xB1, 0xf, 0xf, true);      // quad_perm:[1,0,3,2]
+        if constexpr (LANES >= 4u) cnt += (u32)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x4E, 0xf, 0xf, true);   // quad_perm:[2,3,0,1]
+        const u32 x = cnt - 1u;                                // the row's sum, in every lane
+        u32 N0 = (u32)__builtin_amdgcn_update_dpp(0, (int)T.d[0], 0x101, 0xf, 0xf, true);    // row_shl:1 -- lane i takes lane i + 1
+        N0 = last_lane ? TRC_PROB_ONE : N0;
+        const u32 kk = (x >> 1) & (D - 1u);                    // the pair starts in dword kk of lane x / 2D
+        u32 lo = T.d[0], hi = T.d[1];
+#pragma unroll
+        for (u32 k = 1; k < D; k++) { const bool ge = kk >= k; lo = ge ? T.d[k] : lo; hi = ge ? (k + 1u < D ? T.d[k + 1u < D ? k + 1u : 0u] : N0) : hi; }
+        const u32 V = __builtin_amdgcn_alignbit(hi, lo, (x << 4) & 16u);     // x even: lo; odd: lo.hi | hi.lo << 16
+        q.cc = (u32)__builtin_amdgcn_ds_bpermute((int)((((x / (2u * D)) & (LANES - 1u)) << 2) | rowb4), (int)V);
+        return x;
+    };
+    auto finish = [&](u32 &s, Tab &T, const Nib &q) {
+        const u32 c0 = q.cc & 0xffffu;
+        s = __umul24((q.cc >> 16) - c0, s >> TRC_PROB_BITS) + q.slot - c0;
+#pragma unroll
+        for (u32 k = 0; k < D; k++) {
+            const u32 K = (u32)(__mul24((int)q.f.d[k], -32736) + (int)kbase.d[k]);
+            T.d[k] = trc_as_u32(trc_as_s2(T.d[k]) + ((trc_as_s2(K) - trc_as_s2(T.d[k])) >> (trc_s2)7));
+        }
+    };
+    Tab pendH = fresh;                                         // the next byte's hi table, asked for at the end of this byte
+    auto get_byte = [&](bool act, u32 &sh, u32 &sl) -> u32 {    // context cx -> byte, which becomes the context
+        const u32 cb = (cx << 9) + (cx << 5);                 // 32 x the context's first table (17 tables per context: 544 bytes)
+        {
+            const u32 noff = (cb ^ swz) + moff;
+            if (act && noff != hoff) {                         // the row's hi table goes back to memory, the context's comes in
+                st_tab(hoff, H);
+                const u32 a = seen + 512u + ((cx >> 5) << 2), bit = 1u << (cx & 31u);
+                const u32 bits = *(const lds_u32 *)(uintptr_t)a;
+                *(lds_u32 *)(uintptr_t)a = bits | bit;         // (every lane of the row writes the same word)
+                H = (bits & bit) ? pendH : fresh;              // (a table never written: whatever was loaded, dropped)
+                hoff = noff;
+            }
+        }
+        Nib qh, ql;
+        const u32 h = find(sh, H, qh) & 15u;
+        const u32 noffl = ((cb + 32u + (h << 5)) ^ swz) + moff;
+        const bool needl = act && noffl != loff;
+        Tab pendL = fresh;
+        if (needl) pendL = ld_tab(noffl);
+        finish(sh, H, qh);
+        if (needl) {
+            st_tab(loff, L);
+            const u32 a = seen + cx * 2u, bit = 1u << h;
+            const u32 bits = *(const lds_u16 *)(uintptr_t)a;
+            *(lds_u16 *)(uintptr_t)a = (u16)(bits | bit);
+            L = (bits & bit) ? pendL : fresh;
+            loff = noffl;
+        }
+        const u32 l = find(sl, L, ql) & 15u;
+        const u32 b = h << 4 | l;
+        cx = act ? b : cx;
+        {
+            const u32 nh = (((cx << 9) + (cx << 5)) ^ swz) + moff;
+            if (nh != hoff) pendH = ld_tab(nh);
+        }
+        finish(sl, L, ql);
+        return b;
+    };
+
+    struct __attribute__((packed, aligned(2))) W2 { u32 lo, hi; };
+    u8 *const dst = out + (u64)(alive ? c : 0u) * chunk;
+    for (u32 p0 = 0; p0 < chunk; p0 += 4u * LANES) {           // 4 LANES output bytes per trip: lane e keeps dword e of them
+        if (!__ballot(p0 < lenc)) break;
+        u32 acc = 0;
+#pragma nounroll
+        for (u32 d = 0; d < LANES; d++) {
+            u32 w = 0;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {                      // mndec8x2x: two bytes, then four renorms in order st0..st3
+                const bool act = p0 + 4u * d + 2u * (u32)j < lenc;             // the second byte of an odd tail is the dummy
+                const W2 w2 = *(const W2 *)(sbase + (soff + trc_min(rpos, lim)));   // the (up to) four words this pair's renorms take, requested now
+                const u64 ww = ((u64)w2.hi << 32) | w2.lo;
+                u32 taken = 0;                                 // bits of ww used up
+                auto renorm = [&](u32 &s) {                    // (rows that are done or raw run on garbage: nothing of theirs is used)
+                    const bool rn = s < TRC_ANS_LOW;
+                    s = rn ? __builtin_amdgcn_perm(s, (u32)(ww >> taken), 0x05040100u) : s;      // (s << 16) | next word
+                    taken += rn ? 16u : 0u;
+                };
+                const u32 x0 = get_byte(act, st0, st1);
+                const u32 x1 = get_byte(act, st2, st3);
+                w |= (x0 | x1 << 8) << (16 * j);
+                renorm(st0); renorm(st1); renorm(st2); renorm(st3);   // (the first two moved up between the bytes, under the second byte's hi table load: no change, 3.19-3.20 ms either way)
+                rpos += act ? taken >> 3 : 0u;
+            }
+            acc = e == d ? w : acc;
+        }
+        const u32 pos = p0 + 4u * e;
+        if (pos + 4u <= lenc) *(u32 *)(dst + pos) = acc;
+        else if (pos < lenc)                                    // ragged end of the last chunk
+            for (u32 k = 0; pos + k < lenc; k++) dst[pos + k] = (u8)(acc >> (8u * k));
+    }
+    trc_wave_copy_raw(__ballot(lane < CHUNKS && c0w + lane < nchunks && cl_w == len_w && len_w != 0u), gbase + ex_w, len_w,
+                      out + (u64)c0w * chunk, chunk, payload);
+}
+
 // ------------------------------------------------------------------------------------- launch ---
 // returns true when the records were written to the PLANAR record space (the caller then runs the planar coding pass)
 bool trc_launch_anso1_model(const uint8_t *d_in, size_t n, uint32_t chunk, const TrcWork &w, hipStream_t s)
@@ -1093,7 +1282,11 @@ void trc_launch_anso1_dec(const uint8_t *d_payload, const uint32_t *d_clen, size
     // eight lanes per chunk at every size (100 MB: chunk 4096 5.28 -> 3.79 ms, 2048 3.67 -> 3.71, 1024 3.83 -> 3.71: profiles/r05_notes.md);
     // the one-lane-per-chunk forms (64 / 16 / 8 chunks per wave) stay behind TRC_O1_ROWS
     const int rows = env_rows ? env_rows : TRC_O1_DEC_DEFAULT_ROWS(w.ngroups);
-    if (rows == 1)                                              // eight lanes per chunk (trc_o1_dec_rows_kernel)
+    if (rows == 4)                                              // four lanes per chunk
+        TRC_LAUNCH_TIMED(trc_o1_dec_rowsn_kernel<4>, dim3(w.ngroups * 4u), dim3(64), 0, s, d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, w.model, d_out);
+    else if (rows == 2)                                         // two lanes per chunk
+        TRC_LAUNCH_TIMED(trc_o1_dec_rowsn_kernel<2>, dim3(w.ngroups * 2u), dim3(64), 0, s, d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, w.model, d_out);
+    else if (rows == 1)                                         // eight lanes per chunk (trc_o1_dec_rows_kernel)
         TRC_LAUNCH_TIMED(trc_o1_dec_rows_kernel, dim3(w.ngroups * (64u / O1R_CHUNKS)), dim3(64), 0, s, d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, w.model, d_out);
     else if (rows == 16)
         TRC_LAUNCH_TIMED(trc_o1_dec_kernel<16>, dim3(w.ngroups * 4u), dim3(64), 0, s, d_payload, d_clen, w.goff, w.gsum, (u64)n, chunk, w.nchunks, w.model, d_out);

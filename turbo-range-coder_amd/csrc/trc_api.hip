@@ -488,7 +488,7 @@ extern "C" const char *trc_kernel_name(int codec, int decode)
     case TRC_RCA4: case TRC_RCAI4: return decode ? "trc_rca_dec_kernel" : "trc_rca_enc_kernel";
     case TRC_ANSA: return decode ? "trc_ansa_dec_kernel" : "trc_ansa_model2_kernel";
     case TRC_ANSA4: return decode ? "trc_ansa_dec_kernel" : "trc_ansa_model_kernel";
-    case TRC_ANSO1: return decode ? "trc_o1_dec_rows_kernel" : "trc_o1_walk_kernel";
+    case TRC_ANSO1: return decode ? "trc_o1_dec_rowsn_kernel" : "trc_o1_sort_kernel";
     case TRC_ANSB: return decode ? "trc_ansb_dec_kernel" : "trc_ansb_model_kernel";
     case TRC_RCV8: case TRC_RCVI8: return decode ? "trc_rcv_dec_kernel" : "trc_rcv_enc_kernel";
     default: if (is_vlc(codec)) return decode ? "trc_vlc_dec_kernel" : "trc_vlc_enc_kernel";
