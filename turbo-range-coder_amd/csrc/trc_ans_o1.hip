@@ -372,35 +372,50 @@ __global__ __launch_bounds__(128 * W) void trc_o1_model2_kernel(
 #define O1S_HEAD     0x10000u
 #define O1S_BINS     4352u
 #define O1S_MARKS    (4u * O1S_SEGS * 4u)                       // one bit per stream slot
-#define O1S_SORT_LDS (4096u + 16u + O1S_BINS * 2u + O1S_MARKS)               // the chunk's bytes, packed u16 bins, one bit per stream slot: a chain starts here
+#define O1S_SORT_LDS (O1S_BINS * 2u + O1S_MARKS)                // packed u16 bins, one bit per stream slot: a chain starts here
 __device__ __forceinline__ u32 o1s_up4(u32 v) { return (v + 3u) & ~3u; }
-__global__ __launch_bounds__(64) void trc_o1_sort_kernel(
+#ifndef O1S_EU_ATTR
+#define O1S_EU_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))
+#endif
+// Round 6: the chunk's bytes are no longer staged in LDS (4 KiB of a workgroup's 15.7: ten workgroups per CU) -- a row of 64 positions is one
+// coalesced byte load, asked for a row ahead, and a position's context is its left neighbour's byte (DPP wave_shr:1, the row before's last byte
+// carried in) -- so that three waves share a SIMD: the kernel waited 45 % of its wave-cycles on LDS round trips at two (r06_pmc_o1.txt).
+__global__ __launch_bounds__(64) O1S_EU_ATTR void trc_o1_sort_kernel(
     const u8 *__restrict__ in, u64 n, u32 chunk, u32 nchunks, u8 *__restrict__ model)
 {
     __shared__ __attribute__((aligned(16))) u8 smem_[O1S_SORT_LDS];
     __shared__ u32 big_[17];                                    // [16]: how many
     const u32 lane = threadIdx.x;
     if (lane < 17u) big_[lane] = 0u;
-    u8 *const bytes = smem_;
-    u8 *const bins = bytes + 4112u;
+    u8 *const bins = smem_;
     u32 *const hbits = (u32 *)(bins + O1S_BINS * 2u);
     const u32 c = blockIdx.x;
     const u32 lastlen = (u32)(n - (u64)(nchunks - 1) * chunk);
     const u32 len = c == nchunks - 1u ? lastlen : chunk, plen = len + (len & 1u);
     u8 *const blk = model + (u64)c * O1_MODEL_BYTES;
     const u8 *src = in + (u64)c * chunk;
-    for (u32 off = lane * 16u; off < chunk; off += 1024u)
-        if (off < len) *(uint4 *)(bytes + off) = *(const uint4 *)(src + off);
     for (u32 i = lane; i < (O1S_BINS * 2u + O1S_MARKS) / 16u; i += 64u) ((uint4 *)bins)[i] = make_uint4(0, 0, 0, 0);
     trc_wave_lds_fence();
     const u32 R = (plen + 63u) >> 6;
-    for (u32 r = 0; r < R; r++) {
-        const u32 pos = r * 64u + lane;
-        if (pos < plen) {
-            const u32 x = pos < len ? bytes[pos] : 0u, pv = pos ? bytes[pos - 1u] : 0u;
-            const u32 kh = pv, kl = 256u + (pv << 4) + (x >> 4);
-            atomicAdd((u32 *)(bins + (kh >> 1) * 4u), 1u << ((kh & 1u) * 16u));
-            atomicAdd((u32 *)(bins + (kl >> 1) * 4u), 1u << ((kl & 1u) * 16u));
+    // a row's bytes: x = the byte at the lane's position (0 behind the chunk's end: the coded dummy), pv = the byte before it
+    auto row_load = [&](u32 r) -> u32 { const u32 p = r * 64u + lane; return p < len ? (u32)src[p] : 0u; };
+    auto left_of = [&](u32 x, u32 &carry) -> u32 {
+        const u32 pv = (u32)__builtin_amdgcn_update_dpp((int)carry, (int)x, 0x138, 0xf, 0xf, false);   // wave_shr:1 -- lane 0 keeps `carry`
+        carry = (u32)__builtin_amdgcn_readlane((int)x, 63);
+        return pv;
+    };
+    {
+        u32 xn = row_load(0), carry = 0;
+        for (u32 r = 0; r < R; r++) {
+            const u32 pos = r * 64u + lane;
+            const u32 x = xn;
+            if (r + 1u < R) xn = row_load(r + 1u);
+            const u32 pv = left_of(x, carry);
+            if (pos < plen) {
+                const u32 kh = pv, kl = 256u + (pv << 4) + (x >> 4);
+                atomicAdd((u32 *)(bins + (kh >> 1) * 4u), 1u << ((kh & 1u) * 16u));
+                atomicAdd((u32 *)(bins + (kl >> 1) * 4u), 1u << ((kl & 1u) * 16u));
+            }
         }
     }
     trc_wave_lds_fence();
@@ -459,10 +474,13 @@ __global__ __launch_bounds__(64) void trc_o1_sort_kernel(
     // the selects between B and ~B took eight -- and a chain's first entry is whoever finds bit 15 of its bin still set (was: two reads
     // of the marks).  (The masks from LDS instead -- every lane ORing its bit into the word of its context and of its hi nibble, one
     // read back -- is SLOWER, 0.80 -> 1.00 ms: same-address 64-bit atomics serialise, and a row's lanes share a handful of contexts.)
+    u32 xn = row_load(0), carry = 0;
     for (u32 r = 0; r < R; r++) {
         const u32 pos = r * 64u + lane;
         const bool valid = pos < plen;
-        const u32 x = valid && pos < len ? bytes[pos] : 0u, pv = valid && pos ? bytes[pos - 1u] : 0u;
+        const u32 x = xn;
+        if (r + 1u < R) xn = row_load(r + 1u);
+        const u32 pv = left_of(x, carry);
         const u64 vm = __ballot(valid);
         u32 dh0 = 0, dh1 = 0, dl0 = 0, dl1 = 0;                 // lanes that differ from this one in some bit of pv / of x >> 4
 #pragma unroll
