@@ -12,6 +12,8 @@ import trc  # noqa: E402
 import trc_testlib as T  # noqa: E402
 
 full = T.drift_bytes(100 * 1000 * 1000, 3)
+rows = int(os.environ.get("TRC_O1_ROWS", "0"))
+per_wave = {1: 8, 4: 16, 2: 32, 16: 16, 8: 8, 64: 64}.get(rows, 0)      # chunks per wave of the forced form (0: the default picks by size)
 for mb in (25, 50, 67, 100):
     n = mb * 1000 * 1000
     d = full[:n]
@@ -25,4 +27,6 @@ for mb in (25, 50, 67, 100):
         e0.record(); dc.decode(out, n, dir_ready=True); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
     assert torch.equal(out[:n], d_in[:n])
-    print("%4d MB: %6d chunks, %5d waves of 16 chunks  decode %.3f ms (min of 4; %s)" % (mb, (n + 4095) // 4096, ((n + 4095) // 4096 + 15) // 16, min(ts), " ".join("%.3f" % t for t in ts)))
+    nch = (n + 4095) // 4096
+    waves = ("%5d waves of %d chunks" % ((nch + per_wave - 1) // per_wave, per_wave)) if per_wave else "default form"
+    print("%4d MB: %6d chunks, %s  decode %.3f ms (min of 4; %s)" % (mb, nch, waves, min(ts), " ".join("%.3f" % t for t in ts)))

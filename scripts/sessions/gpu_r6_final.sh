@@ -19,6 +19,7 @@ done
 } > gpurun_out/${TAG}_pmc_traffic_cfg34.txt 2>&1
 bash scripts/gpu_pmc.sh ${TAG}sq "" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "TA_TA_BUSY_sum TA_BUSY_avr TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum GRBM_GUI_ACTIVE" > gpurun_out/${TAG}_pmc_sq.txt 2>&1
 for c in rccdf anscdf rcs anscdf1 ansb rccdfs2 rccdfs; do bash scripts/gpu_kstats.sh ${TAG}_$c --codec $c --no-beyond; done > gpurun_out/${TAG}_kernel_stats_cfg34.txt 2>&1
+bash scripts/sessions/gpu_r6_o1.sh > /dev/null 2>&1
 bash scripts/gpu_all_codecs.sh > /dev/null 2>&1; cp gpurun_out/all_codecs.txt gpurun_out/${TAG}_all_codecs.txt
 python bench.py --no-cpu --workload zipf1g 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_zipf1g.json
 python bench.py --no-cpu --no-beyond --force-dist --group 8 2>/dev/null | grep "^{" | tail -1 > gpurun_out/${TAG}_bench_forcedist_g8.json
