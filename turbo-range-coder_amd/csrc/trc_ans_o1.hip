@@ -338,15 +338,15 @@ __global__ __launch_bounds__(128 * W) void trc_o1_model2_kernel(
 // and a chain that starts from the initial table needs no model memory: its one table lives in the registers of the lane walking it.
 //   A  trc_o1_sort_kernel (a wave per chunk): a stable counting sort of the chunk's positions by table -- histogram by LDS atomics,
 //      one scan over the 4352 bins, then row by row (64 positions) the rank of a position among the lanes with the same key (the
-//      key's bits as ballots: deterministic, no atomics).  Writes the chunk's STREAM -- u32 entries `pos | nibble << 12`, every
+//      key's bits as ballots: deterministic, no returning atomics).  Writes the chunk's STREAM -- u32 entries `pos | nibble << 12`, every
 //      chain contiguous and starting on a multiple of four entries (a WINDOW, 16 bytes), hi chains first; HEAD on a chain's first
 //      entry (the up to three slots behind its last one hold whatever memory held: walked like entries, their records never read)
 //      -- for every 128 entries the first chain start at or behind them (`nh`), the chunk's long chains, and for every position
 //      where its two records will lie in that order (`perm`).
-//   B  trc_o1_walk_kernel (a workgroup per O1W_GROUP chunks): the unit of work is "the chains that START in entries
-//      [128 j, 128 j + 128) of chunk i", taken off an LDS counter -- first the units of the group's long chains, longest first (the
+//   B  trc_o1_walk_kernel (a workgroup per G chunks, G <= 96: round 6, below): the unit of work is "the chains that START in entries
+//      [128 j, 128 j + 128) of chunk i", taken off a list in LDS -- first the units of the group's long chains, longest first (the
 //      tail of this kernel is its longest chain: drift100m has 16 hi chains per chunk, the longest 1400 entries on average, up to
-//      3400), then every unit nobody has taken.  A lane walks from the unit's first chain start to the first chain start behind
+//      a whole chunk's 4096), then every other unit a chain starts in.  A lane walks from the unit's first chain start to the first chain start behind
 //      the unit (both in `nh`: no lane ever looks at a slot another lane writes) -- bounds, adapt, record -- so every chain is
 //      walked by exactly one lane, whole.  All lanes busy whatever the statistics.  The lanes advance in lockstep, a ROUND = four
 //      windows per lane: at its top the next round's windows are asked for (`global_load_lds_dwordx4` into the other half of an
