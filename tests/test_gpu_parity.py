@@ -424,7 +424,8 @@ def test_order1_model_pass_by_chains_and_by_position(torch_cuda):
     1-4 for longer chunks or TRC_O1_CHAINS=0.  Both are forced, each in a process of its own (the switch is read once), on what
     the chain pass has special cases for: incompressible bytes (thousands of one-entry chains: the stream outgrows the placement
     kernel's LDS stage and is gathered from memory), one byte value (two chains as long as the chunk), two alternating values, text,
-    runs; odd lengths (the coded dummy), a lone byte, chunk sizes below 4096, several groups of 64 chunks with a short last one.
+    runs; odd lengths (the coded dummy), a lone byte, chunk sizes below 4096, several groups of 64 chunks with a short last one,
+    inputs of hundreds and thousands of chunks (the walk kernel's workgroups take ceil(chunks / 256) chunks each, 96 at most).
     Per-chunk payloads equal the oracle's; the round trip returns the input."""
     import subprocess, sys, textwrap
     code = textwrap.dedent("""
@@ -441,7 +442,8 @@ def test_order1_model_pass_by_chains_and_by_position(torch_cuda):
             return gen(kind, n, 9)
         cases = [("random", 64 * 4096 * 2 + 4097, 4096), ("const", 4096 * 70, 4096), ("const", 4095, 4096), ("alt", 4096 * 3 + 1, 4096),
                  ("hi16", 4096 * 5, 4096), ("text", 64 * 4096 + 1234, 4096), ("runs", 4096 * 130 + 7, 4096), ("zipf", 100001, 2048),
-                 ("random", 30001, 1024), ("text", 1, 4096), ("text", 2, 4096), ("random", 3, 1024), ("text", 1 << 20, 65536)]
+                 ("random", 30001, 1024), ("text", 1, 4096), ("text", 2, 4096), ("random", 3, 1024), ("text", 1 << 20, 65536),
+                 ("text", 4096 * 700 + 123, 4096), ("runs", 4096 * 5000 + 1, 4096), ("zipf", 2048 * 9000, 2048)]   # (round 6: the walk kernel takes 3 / 20 / 36 chunks per workgroup here)
         for kind, n, chunk in cases:
             d = data(kind, n)
             dc = trc.DeviceCoder(trc.ANSO1, n, chunk, "cuda:0")
