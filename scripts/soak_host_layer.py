@@ -22,7 +22,7 @@ rng = np.random.default_rng(seed)
 lib = trc.lib()
 lib.trc_host_pin.restype = C.c_int; lib.trc_host_pin.argtypes = [C.c_void_p, C.c_size_t]
 lib.trc_host_unpin.restype = C.c_int; lib.trc_host_unpin.argtypes = [C.c_void_p]
-CODECS = (trc.ANS4S, trc.RCS1, trc.RCS2, trc.RCA, trc.RCAI, trc.ANSA, trc.RCB, trc.ANSB, trc.RCV8)
+CODECS = (trc.ANS4S, trc.RCS1, trc.RCS2, trc.RCA, trc.RCAI, trc.ANSA, trc.RCB, trc.ANSB, trc.RCV8, trc.ANSO1)
 u8p = C.POINTER(C.c_uint8)
 
 
